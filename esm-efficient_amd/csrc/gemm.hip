@@ -1,0 +1,286 @@
+// bf16 MFMA GEMM for the packed forward pass:  C = epilogue(A (M,K) @ W (N,K)^T + bias).
+//
+// Both operands are K-contiguous ("NT" GEMM: activations (T,E) row-major, nn.Linear
+// weights (out,in) row-major), which is exactly what v_mfma_f32_32x32x16_bf16 wants: each
+// lane feeds 8 consecutive k of one row.  The product is computed TRANSPOSED -- the MFMA
+// A operand is a 32-row slab of W, the B operand a 32-row slab of activations -- so a lane
+// ends up holding 4 consecutive output columns of one token row per accumulator quad and
+// the epilogue (bias, exact-erf GELU, SiLU*mul, residual add + scale, bf16 rounding) and
+// the C store work on 8-byte row segments without any cross-lane traffic.
+//
+// Data path per K-tile (BK = 64):  HBM --global_load_lds (16 B/lane, no VGPR round trip)-->
+// LDS [rows][64] bf16, two stages --ds_read_b128--> MFMA fragments.  LDS rows are 128 B, so
+// a 32-row fragment read would hit one 16-B slot 16 ways; the 16-B chunk index is XORed
+// with (row>>1)&7, applied on the per-lane GLOBAL source address (the LDS-DMA destination is
+// lane-linear) and again on the read: conflict-free for both ds_read_b128 lane groupings.
+//
+// M/N edges: loads clamp the row index (re-reading a valid row), stores are guarded; the
+// only shape requirement is K % 64 == 0.
+#include "common.h"
+#include "launch.h"
+
+namespace esme {
+
+struct GemmArgs {
+    const u16* A; int64_t lda;
+    const u16* W;
+    const u16* bias;
+    const u16* resid; int64_t ldr;
+    u16* C; int64_t ldc;
+    int64_t M; int N; int K;
+    float alpha;
+    int tiles_n;
+    int vec_ok;                  // C/resid rows allow 8-byte accesses (ld % 4 == 0, 8-B aligned base)
+};
+
+static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+    constexpr int NW = WM * WN;               // waves per block
+    constexpr int NT = NW * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    constexpr int A_ROWS_BYTES = BM * 128, W_ROWS_BYTES = BN * 128;
+    constexpr int STAGE = A_ROWS_BYTES + W_ROWS_BYTES;
+    constexpr int IA = BM * 8 / NT, IW = BN * 8 / NT;      // 16-B chunks per thread per tile
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+    static_assert(EPI != ESME_EPI_SWIGLU || WTN == 64, "swiglu needs 64-wide wave tiles");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = pid % a.tiles_n;
+    const int64_t tile_m = pid / a.tiles_n;
+    const int64_t m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- per-thread staging sources (k0 = 0); chunk swizzle folded into the address
+    const u16* srcA[IA];
+    const u16* srcW[IW];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int q = (i * NW + wave) * 64 + lane;
+        const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+        int64_t gr = m0 + row;
+        gr = gr < a.M ? gr : a.M - 1;
+        srcA[i] = a.A + gr * a.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < IW; ++i) {
+        const int q = (i * NW + wave) * 64 + lane;
+        const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+        int gr = n0 + row;
+        gr = gr < a.N ? gr : a.N - 1;
+        srcW[i] = a.W + (int64_t)gr * a.K + c * 8;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(base + (i * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IW; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0),
+                                             (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets: row*128 + ((chunk ^ swz) << 4); swz depends on lane only
+    const int swz = (l31 >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + hi) ^ swz) << 4;
+    const int rowA = (wm * WTM + l31) * 128;                     // activation slab rows (MFMA B operand)
+    const int rowW = A_ROWS_BYTES + (wn * WTN + l31) * 128;      // weight slab rows (MFMA A operand)
+
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = a.K / BK;
+    stage(0, 0);
+    __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+        const char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 32 * 128 + coff[ks]);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 32 * 128 + coff[ks]);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                      // next stage landed; everyone done with this one
+    }
+
+    // ---- epilogue: lane owns token row m, accumulator quad g = 4 consecutive columns
+    if constexpr (EPI == ESME_EPI_SWIGLU) {
+        const int NO = a.N >> 1;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int64_t m = m0 + wm * WTM + j * 32 + l31;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f = ((n0 + wn * WTN) >> 1) + 8 * g + 4 * hi;
+                if (f >= NO) continue;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gate = acc[0][j][4 * g + e], fc = acc[1][j][4 * g + e];
+                    o[e] = gate / (1.0f + __expf(-gate)) * fc;
+                }
+                u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(a.C + m * a.ldc + f) = pk;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi;
+                if (n >= a.N) continue;
+                const bool full = a.vec_ok && n + 3 < a.N;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) {
+                    if (full) {
+                        const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + n);
+                        bv[0] = bf_lo(bw[0]); bv[1] = bf_hi(bw[0]); bv[2] = bf_lo(bw[1]); bv[3] = bf_hi(bw[1]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < a.N) bv[e] = bf2f(a.bias[n + e]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const int64_t m = m0 + wm * WTM + j * 32 + l31;
+                    if (m >= a.M) continue;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] + bv[e];
+                    if constexpr (EPI == ESME_EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+                    }
+                    u16* cp = a.C + m * a.ldc + n;
+                    if (full) {
+                        if constexpr (EPI == ESME_EPI_RESIDUAL) {
+                            const u32x2 rw = *reinterpret_cast<const u32x2*>(a.resid + m * a.ldr + n);
+                            o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
+                            o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
+                        }
+                        u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                        *reinterpret_cast<u32x2*>(cp) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < a.N) {
+                                float v = o[e];
+                                if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
+                                cp[e] = f2bf(v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(GemmArgs& a, int epi, hipStream_t s) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    const int64_t tiles_m = (a.M + BM - 1) / BM;
+    const int64_t blocks = tiles_m * a.tiles_n;
+    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
+    const dim3 grid((unsigned int)blocks), block(WM * WN * 64);
+#define ESME_GEMM_CASE(E)                                                                         \
+    case E: {                                                                                     \
+        auto kern = gemm_bf16_kernel<BM, BN, WM, WN, E>;                                          \
+        if (smem > 64 * 1024) {                                                                   \
+            static bool once = false;                                                             \
+            if (!once) {                                                                          \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+                once = true;                                                                      \
+            }                                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL(kern, grid, block, smem, s, a);                                        \
+        break;                                                                                    \
+    }
+    switch (epi) {
+        ESME_GEMM_CASE(ESME_EPI_NONE)
+        ESME_GEMM_CASE(ESME_EPI_GELU)
+        ESME_GEMM_CASE(ESME_EPI_RESIDUAL)
+        ESME_GEMM_CASE(ESME_EPI_SWIGLU)
+        default: return fail(ESME_ERR_ARG, "gemm: unknown epilogue");
+    }
+#undef ESME_GEMM_CASE
+    return check_launch("gemm_bf16");
+}
+
+}  // namespace esme
+
+using namespace esme;
+
+// test hook: force a tile configuration (0 = heuristic).  Not part of the documented ABI.
+static int g_force_tile = 0;
+extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
+
+extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
+                                  int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                                  float alpha, void* stream) {
+    ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad sizes");
+    ESME_CHECK_ARG(epilogue >= ESME_EPI_NONE && epilogue <= ESME_EPI_SWIGLU, "gemm: unknown epilogue");
+    if (M == 0) return ESME_OK;
+    ESME_CHECK_ARG(A && W && C, "gemm: null pointer");
+    if (K % BK != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: K must be a multiple of 64");
+    const int n_out = epilogue == ESME_EPI_SWIGLU ? N / 2 : N;
+    if (epilogue == ESME_EPI_SWIGLU && N % 64 != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs N % 64 == 0");
+    ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= n_out, "gemm: bad lda/ldc");
+    ESME_CHECK_ARG(aligned16(A) && aligned16(W), "gemm: A and W must be 16-byte aligned");
+    ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm: misaligned bias");
+    // 8-byte row-segment stores need ld % 4 == 0 and 8-B aligned bases; otherwise (e.g. the
+    // (T, 33) vocab projection) the epilogue falls back to 2-byte accesses.
+    int vec_ok = (ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
+    if (epilogue == ESME_EPI_RESIDUAL) {
+        ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
+        vec_ok = vec_ok && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(resid) & 7u) == 0;
+    }
+    if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 4 == 0 and an 8-byte aligned C");
+    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok};
+    const hipStream_t s = (hipStream_t)stream;
+    int tile = g_force_tile;
+    if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
+    if (epilogue == ESME_EPI_SWIGLU && tile == 2) tile = 3;
+    switch (tile) {
+        case 1: return launch_gemm<128, 128, 2, 2>(a, epilogue, s);
+        case 2: return launch_gemm<256, 256, 2, 4>(a, epilogue, s);      // wave tile 128(m) x 64(n)
+        case 3: return launch_gemm<256, 256, 2, 4>(a, epilogue, s);
+        default: ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
+    }
+}

@@ -1,0 +1,261 @@
+// HBM-bound row kernels of the packed forward pass: embedding gather, sequence
+// positions, LayerNorm, varlen rotary, row softmax, row gather/scatter.
+// All of them move 16 B per lane per access along the packed-residue axis; none of
+// them has inter-block reuse, so no XCD remap (guide T1: 0 % on LayerNorm).
+#include "common.h"
+#include "launch.h"
+
+namespace esme {
+
+// ---------------------------------------------------------------- embedding
+// one lane per 16-byte chunk of an output row
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens,
+                                                    const u32x4* __restrict__ table, u32x4* __restrict__ out,
+                                                    int64_t T, int chunks, int V, int mask_idx, int pad_idx) {
+    const int64_t total = T * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / chunks;
+        const int c = (int)(i - t * chunks);
+        const int64_t tok = tokens[t];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tok != mask_idx && tok != pad_idx && tok >= 0 && tok < V) v = table[tok * chunks + c];
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------- sequence positions
+// binary search of the row in cu_lens (B+1 entries, L2 resident)
+__global__ __launch_bounds__(256) void seqpos_kernel(const int32_t* __restrict__ cu, int B, int64_t T,
+                                                     int32_t* __restrict__ pos, int32_t* __restrict__ seq) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    int lo = 0, hi = B;              // invariant: cu[lo] <= t < cu[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    if (pos) pos[t] = (int32_t)(t - cu[lo]);
+    if (seq) seq[t] = lo;
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// One wave per row; the row stays in registers (NCH chunks of 8 bf16 per lane), so HBM
+// traffic is exactly one read + one write of the row: 4*E bytes.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ x, int64_t ldx,
+                                                        const u16* __restrict__ w, const u16* __restrict__ b,
+                                                        u16* __restrict__ y, int64_t ldy, int64_t T, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const u16* xr = x + row * ldx;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float inv_e = 1.0f / (float)E;
+    const float mean = wave_sum(s) * inv_e;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
+    u16* yr = y + row * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            float wf[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(w + e0), wf);
+            if (b) {
+                float bfv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(b + e0), bfv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
+            }
+            *reinterpret_cast<u32x4*>(yr + e0) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- rotary
+// One lane per (row, tensor, head, 8-wide chunk of the first half of the head): it
+// rotates that chunk together with its partner chunk d/2 further on.  Tables are tiny
+// (max_len*d*2 B) and L2 resident; q and k rows are read and written once: 8*E B/row.
+__global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* __restrict__ k, int64_t ld,
+                                                     const u16* __restrict__ cosT, const u16* __restrict__ sinT,
+                                                     const int32_t* __restrict__ pos, int64_t T, int H, int d,
+                                                     int max_len) {
+    const int half_chunks = d >> 4;                 // 8-wide chunks in d/2
+    const int per_tensor = H * half_chunks;         // work items per row per tensor
+    const int per_row = 2 * per_tensor;
+    const int64_t total = T * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / per_row;
+        int r = (int)(i - t * per_row);
+        u16* base = q;
+        if (r >= per_tensor) { r -= per_tensor; base = k; }
+        const int h = r / half_chunks;
+        const int jc = r - h * half_chunks;
+        int p = pos[t];
+        p = p < max_len ? p : max_len - 1;
+        u16* xp = base + t * ld + h * d + jc * 8;
+        float lo[8], hi[8], c[8], s[8], olo[8], ohi[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xp), lo);
+        unpack8(*reinterpret_cast<const u32x4*>(xp + (d >> 1)), hi);
+        unpack8(*reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc * 8), c);
+        unpack8(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc * 8), s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            olo[j] = lo[j] * c[j] - hi[j] * s[j];
+            ohi[j] = hi[j] * c[j] + lo[j] * s[j];
+        }
+        *reinterpret_cast<u32x4*>(xp) = pack8(olo);
+        *reinterpret_cast<u32x4*>(xp + (d >> 1)) = pack8(ohi);
+    }
+}
+
+// ------------------------------------------------------------- row softmax
+// V <= 64: one wave per row, one lane per column.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* __restrict__ x, int64_t ldx,
+                                                           u16* __restrict__ y, int64_t ldy, int64_t T, int V,
+                                                           int log_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float v = lane < V ? bf2f(x[row * ldx + lane]) : -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < V ? __expf(v - m) : 0.f;
+    const float sum = wave_sum(e);
+    if (lane < V) y[row * ldy + lane] = f2bf(log_flag ? (v - m) - __logf(sum) : e / sum);
+}
+
+// ------------------------------------------------------ row gather / scatter
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src,
+                                                          const int64_t* __restrict__ idx, u32x4* __restrict__ dst,
+                                                          int64_t n, int chunks, int scatter) {
+    const int64_t total = n * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        const int64_t j = idx[r];
+        if (scatter) dst[j * chunks + c] = src[i];
+        else dst[i] = src[j * chunks + c];
+    }
+}
+
+}  // namespace esme
+
+using namespace esme;
+
+static inline unsigned int grid_for(int64_t items, int per_block, unsigned int cap = 256u * 16u) {
+    int64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned int)(g > (int64_t)cap ? cap : g);
+}
+
+extern "C" int esme_hip_embed(const int64_t* tokens, const void* table, void* out, int64_t T, int E, int V,
+                              int mask_idx, int pad_idx, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0 && V > 0, "embed: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(tokens && table && out, "embed: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && aligned16(table) && aligned16(out), "embed: E %% 8 != 0 or misaligned");
+    const int chunks = E / 8;
+    hipLaunchKernelGGL(embed_kernel, dim3(grid_for(T * chunks, 256)), dim3(256), 0, (hipStream_t)stream, tokens,
+                       (const u32x4*)table, (u32x4*)out, T, chunks, V, mask_idx, pad_idx);
+    return check_launch("embed");
+}
+
+extern "C" int esme_hip_seq_positions(const int32_t* cu_lens, int B, int64_t T, int32_t* pos, int32_t* seq_id,
+                                      void* stream) {
+    ESME_CHECK_ARG(B >= 0 && T >= 0, "seq_positions: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(cu_lens && B >= 1, "seq_positions: null cu_lens or B < 1 with T > 0");
+    hipLaunchKernelGGL(seqpos_kernel, dim3((unsigned int)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cu_lens, B, T, pos, seq_id);
+    return check_launch("seq_positions");
+}
+
+extern "C" int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
+                                  int64_t T, int E, float eps, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "layernorm: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && w && y, "layernorm: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= E && ldy >= E, "layernorm: E/ld not multiples of 8");
+    ESME_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(w) && (!b || aligned16(b)), "layernorm: misaligned");
+    const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_LN(N)                                                                                            \
+    hipLaunchKernelGGL(layernorm_kernel<N>, grid, block, 0, s, (const u16*)x, ldx, (const u16*)w, (const u16*)b, \
+                       (u16*)y, ldy, T, E, eps)
+    if (E <= 512) ESME_LN(1);
+    else if (E <= 1024) ESME_LN(2);
+    else if (E <= 1536) ESME_LN(3);
+    else if (E <= 2560) ESME_LN(5);
+    else if (E <= 5120) ESME_LN(10);
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm: E > 5120 unsupported");
+#undef ESME_LN
+    return check_launch("layernorm");
+}
+
+extern "C" int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,
+                                      const int32_t* pos, int64_t T, int H, int d, int max_len, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && H > 0 && d > 0 && max_len > 0, "rotary: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(q && k && cosT && sinT && pos, "rotary: null pointer");
+    if (d % 16 != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "rotary: head dim must be a multiple of 16");
+    ESME_CHECK_ARG(ld % 8 == 0 && ld >= (int64_t)H * d, "rotary: bad row stride");
+    ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(cosT) && aligned16(sinT), "rotary: misaligned");
+    const int64_t items = T * 2 * H * (d / 16);
+    hipLaunchKernelGGL(rotary_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)q,
+                       (u16*)k, ld, (const u16*)cosT, (const u16*)sinT, pos, T, H, d, max_len);
+    return check_launch("rotary");
+}
+
+extern "C" int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t T, int V,
+                                     int log_flag, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && V > 0, "softmax_rows: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && y && ldx >= V && ldy >= V, "softmax_rows: null pointer or bad stride");
+    if (V > 64) ESME_FAIL(ESME_ERR_UNSUPPORTED, "softmax_rows: V > 64 unsupported");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned int)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)x, ldx, (u16*)y, ldy, T, V, log_flag);
+    return check_launch("softmax_rows");
+}
+
+static int gather_scatter(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream,
+                          int scatter) {
+    ESME_CHECK_ARG(n >= 0 && E > 0, "gather/scatter_rows: bad sizes");
+    if (n == 0) return ESME_OK;
+    ESME_CHECK_ARG(src && idx && dst, "gather/scatter_rows: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && aligned16(src) && aligned16(dst), "gather/scatter_rows: E %% 8 != 0 or misaligned");
+    const int chunks = E / 8;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * chunks, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)src, idx, (u32x4*)dst, n, chunks, scatter);
+    return check_launch(scatter ? "scatter_rows" : "gather_rows");
+}
+
+extern "C" int esme_hip_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream) {
+    return gather_scatter(src, idx, dst, n, E, stream, 0);
+}
+extern "C" int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream) {
+    return gather_scatter(src, idx, dst, n, E, stream, 1);
+}

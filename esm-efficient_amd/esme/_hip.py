@@ -1,0 +1,226 @@
+"""ctypes binding of libesme_hip.so (C ABI in include/esme_hip.h) for torch tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic
+op on the forward path is a HIP kernel behind the C ABI.  There is NO fallback:
+if the shared library is missing, or a tensor is not on a HIP device, the call
+raises -- the product never routes through torch ops or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+_LIB_NAME = 'libesme_hip.so'
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+ABI_VERSION = 1
+
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
+
+# name -> (restype, argtypes); must list every symbol include/esme_hip.h declares
+SIGNATURES = {
+    'esme_hip_abi_version': (c_int, []),
+    'esme_hip_last_error': (c_char_p, []),
+    'esme_hip_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_seq_positions': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    'esme_hip_layernorm': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                   c_float, c_void_p]),
+    'esme_hip_rotary_varlen': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                       c_int, c_int, c_void_p]),
+    'esme_hip_attn_varlen_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                                         c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_gemm_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and type the shared library.  Raises HipLibraryError loudly if
+    it has not been built (`python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_LIB_PATH):
+        raise HipLibraryError(
+            f'{_LIB_NAME} not found at {_LIB_PATH}: build it with '
+            f'`make -C esm-efficient_amd/csrc` (or __graft_entry__.build()). '
+            f'There is no CPU/torch fallback for the forward path.')
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.esme_hip_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f'{_LIB_NAME} ABI {lib.esme_hip_abi_version()} != binding {ABI_VERSION}')
+    try:
+        lib.esme_hip_debug_set_gemm_tile.restype = None
+        lib.esme_hip_debug_set_gemm_tile.argtypes = [c_int]
+    except AttributeError:
+        pass
+    _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load().esme_hip_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (code {code}): {msg}')
+
+
+def _dev(t: torch.Tensor, what: str, dtype=None) -> int:
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: tensor is on {t.device}; the forward path runs only on a HIP device '
+                           f'(no CPU fallback)')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'{what}: expected {dtype}, got {t.dtype}')
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows2d(t: torch.Tensor, what: str):
+    """(rows, cols) view with unit column stride; returns (ptr, ld)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f'{what}: need a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} '
+                         f'stride {t.stride()}')
+    return _dev(t, what, torch.bfloat16), t.stride(0)
+
+
+# ------------------------------------------------------------------ wrappers
+
+def embed(tokens: torch.Tensor, table: torch.Tensor, mask_idx: int = -1, pad_idx: int = -1) -> torch.Tensor:
+    tok = tokens.reshape(-1).contiguous()
+    V, E = table.shape
+    out = torch.empty(tok.numel(), E, dtype=torch.bfloat16, device=table.device)
+    _check(load().esme_hip_embed(_dev(tok, 'embed tokens', torch.int64), _dev(table.contiguous(), 'embed table', torch.bfloat16),
+                                 out.data_ptr(), tok.numel(), E, V, mask_idx, pad_idx, _stream()), 'esme_hip_embed')
+    return out.view(*tokens.shape, E)
+
+
+def seq_positions(cu_lens: torch.Tensor, total: int):
+    """(pos int32 (T,), seq_id int32 (T,)) for packed rows."""
+    cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
+    cu = cu.contiguous()
+    pos = torch.empty(total, dtype=torch.int32, device=cu.device)
+    seq = torch.empty(total, dtype=torch.int32, device=cu.device)
+    _check(load().esme_hip_seq_positions(_dev(cu, 'cu_lens', torch.int32), cu.numel() - 1, total,
+                                         pos.data_ptr(), seq.data_ptr(), _stream()), 'esme_hip_seq_positions')
+    return pos, seq
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    shape = x.shape
+    x2 = x if x.dim() == 2 else x.reshape(-1, shape[-1])
+    xp, ldx = _rows2d(x2, 'layernorm x')
+    T, E = x2.shape
+    if out is None:
+        out = torch.empty(T, E, dtype=torch.bfloat16, device=x.device)
+    yp, ldy = _rows2d(out, 'layernorm out')
+    _check(load().esme_hip_layernorm(xp, ldx, _dev(weight, 'layernorm weight', torch.bfloat16),
+                                     _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
+                                     yp, ldy, T, E, eps, _stream()), 'esme_hip_layernorm')
+    return out if x.dim() == 2 else out.view(shape)
+
+
+def rotary_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor,
+            heads: int) -> None:
+    """In-place rotary on q and k, each a (T, H*d) view (same row stride) of bf16."""
+    qp, ld = _rows2d(q, 'rotary q')
+    kp, ldk = _rows2d(k, 'rotary k')
+    if ld != ldk:
+        raise ValueError('rotary: q and k must share a row stride')
+    T, E = q.shape
+    d = E // heads
+    _check(load().esme_hip_rotary_varlen(qp, kp, ld, _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16),
+                                         _dev(pos, 'pos', torch.int32), T, heads, d, cos.shape[0], _stream()),
+           'esme_hip_rotary_varlen')
+
+
+def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
+                heads: int, softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k, v: (T, H*d) views sharing one row stride; returns (T, H*d)."""
+    qp, ld = _rows2d(q, 'attn q')
+    kp, ld2 = _rows2d(k, 'attn k')
+    vp, ld3 = _rows2d(v, 'attn v')
+    if not (ld == ld2 == ld3):
+        raise ValueError('attn: q, k, v must share a row stride')
+    T, E = q.shape
+    d = E // heads
+    if out is None:
+        out = torch.empty(T, E, dtype=torch.bfloat16, device=q.device)
+    op, ldo = _rows2d(out, 'attn out')
+    cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
+    scale = softmax_scale if softmax_scale is not None else d ** -0.5
+    _check(load().esme_hip_attn_varlen_fwd(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
+                                           cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()),
+           'esme_hip_attn_varlen_fwd')
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+         resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(a @ w.T + bias); a (M,K), w (N,K) contiguous; see include/esme_hip.h."""
+    ap, lda = _rows2d(a, 'gemm a')
+    if not w.is_contiguous():
+        raise ValueError('gemm: weight must be contiguous (N, K)')
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f'gemm: K mismatch {a.shape} x {w.shape}')
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
+    cp, ldc = _rows2d(out, 'gemm out')
+    rp, ldr = (None, 0)
+    if epilogue == EPI_RESIDUAL:
+        rp, ldr = _rows2d(resid, 'gemm resid')
+    _check(load().esme_hip_gemm_bf16(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+                                     _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
+                                     rp, ldr, cp, ldc, M, N, K, epilogue, alpha, _stream()), 'esme_hip_gemm_bf16')
+    return out
+
+
+def softmax_rows(x: torch.Tensor, log: bool) -> torch.Tensor:
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    xp, ldx = _rows2d(x2, 'softmax x')
+    out = torch.empty_like(x2, memory_format=torch.contiguous_format)
+    _check(load().esme_hip_softmax_rows(xp, ldx, out.data_ptr(), out.stride(0), x2.shape[0], x2.shape[1],
+                                        1 if log else 0, _stream()), 'esme_hip_softmax_rows')
+    return out.view(shape)
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """src (R, E) contiguous bf16, idx int64 (n) -> (n, E)."""
+    src = src.contiguous()
+    out = torch.empty(idx.numel(), src.shape[1], dtype=torch.bfloat16, device=src.device)
+    _check(load().esme_hip_gather_rows(_dev(src, 'gather src', torch.bfloat16), _dev(idx.contiguous(), 'gather idx', torch.int64),
+                                       out.data_ptr(), idx.numel(), src.shape[1], _stream()), 'esme_hip_gather_rows')
+    return out
+
+
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, rows: int) -> torch.Tensor:
+    """zeros (rows, E) with out[idx[i]] = src[i]  (the contract of pad_input)."""
+    src = src.contiguous()
+    out = torch.zeros(rows, src.shape[1], dtype=torch.bfloat16, device=src.device)
+    _check(load().esme_hip_scatter_rows(_dev(src, 'scatter src', torch.bfloat16), _dev(idx.contiguous(), 'scatter idx', torch.int64),
+                                        out.data_ptr(), idx.numel(), src.shape[1], _stream()), 'esme_hip_scatter_rows')
+    return out

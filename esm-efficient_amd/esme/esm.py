@@ -1,0 +1,230 @@
+"""ESM-2 / ESM-C model assembly and checkpoint loading for the MI355X hot path.
+
+Public surface mirrors the reference (`esme/esm.py`): `ESM.from_pretrained`
+(:28-69), `ESM2` (:72-374: embedding, forward_representation, forward,
+predict_log_prob, predict_prob, create_model, from_pretrained) and `ESMC`
+(:738-913) with the same argument order, defaults, return shapes/dtypes and
+assertion/ValueError behaviour, so callers of
+`model(tokens, (cu_lens, max_len))` / `predict_log_prob` switch packages without
+edits.  Everything arithmetic runs in HIP kernels behind `esme._hip`; a tensor
+that is not on a HIP device raises (there is no CPU fallback).
+
+Out of scope here: ESM-1b/1v, LoRA management, 8-bit loaders,
+activation checkpointing (training only), hub download (no network).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from esme import _hip
+from esme.alphabet import Alphabet, Alphabet3
+from esme.attention import FlashTransformerLayer, ForwardContext
+from esme.head import RobertaLMHead
+from esme.nn import LayerNorm
+
+model_names = ['esm2_8m', 'esm2_35m', 'esm2_150m', 'esm2_650m', 'esm2_3b', 'esm2_15b',
+               'esmc_300m', 'esmc_600m']
+
+
+def _read_metadata(path: str) -> dict:
+    from safetensors import safe_open
+    with safe_open(path, framework='pt', device='cpu') as f:
+        return dict(f.metadata() or {})
+
+
+class ESM(nn.Module):
+    """Dispatcher: picks the model class from the checkpoint's `name` metadata."""
+
+    @staticmethod
+    def from_pretrained(path, quantization=None, checkpointing=False, device='cpu'):
+        if not os.path.isfile(path):
+            # the reference would try the HF hub here (esm.py:42-48); there is no network
+            raise ValueError(f'Invalid model name: {path}. Must be a local safetensors file '
+                             f'(hub names {model_names} need a download step that is out of scope)')
+        name = _read_metadata(path)['name'].split('_')[0]
+        if name == 'esm2':
+            return ESM2.from_pretrained(path, quantization, checkpointing, device)
+        if name == 'esmc':
+            return ESMC.from_pretrained(path, quantization, checkpointing, device)
+        if name in ('esm1b', 'esm1v'):
+            raise NotImplementedError(f'{name} (learned positions) is not on the MI355X hot path yet')
+        raise ValueError(f'Invalid model name: {name}. Must be one of {model_names}')
+
+
+class ESM2(nn.Module):
+    alphabet = Alphabet
+    vocab_size = 33
+    zero_mask_rows = True          # `<mask>` embedding rows are zeroed (esm.py:189)
+
+    def __init__(self, num_layers: int = 33, embed_dim: int = 1280, attention_heads: int = 20,
+                 checkpointing: bool = False, rotary_embedding: bool = True, dropout: float = 0.,
+                 dtype=torch.bfloat16):
+        super().__init__()
+        if dtype != torch.bfloat16:
+            raise NotImplementedError('the HIP path computes in bf16 (fp32 accumulate) only')
+        if checkpointing:
+            raise NotImplementedError('activation checkpointing is a training feature (out of scope)')
+        self.num_layers, self.embed_dim, self.attention_heads = num_layers, embed_dim, attention_heads
+        self.checkpointing = False
+        self.embed_scale = 1
+        self.embed_tokens = nn.Embedding(self.vocab_size, embed_dim, dtype=dtype,
+                                         padding_idx=self.alphabet.padding_idx)
+        self.embed_tokens.weight.requires_grad_(False)
+        self.layers = nn.ModuleList(self._make_layer(rotary_embedding, dropout, dtype)
+                                    for _ in range(num_layers))
+        self.emb_layer_norm_after = self._make_final_norm(dtype)
+        self.lm_head = RobertaLMHead(embed_dim, self.vocab_size, dtype=dtype)
+
+    # -- construction hooks (ESMC overrides) ---------------------------------
+    def _make_layer(self, rotary_embedding, dropout, dtype):
+        return FlashTransformerLayer(self.embed_dim, 4, self.attention_heads, rotary_embedding=rotary_embedding,
+                                     pre_layernorm=False, bias=True, final_activation='gelu',
+                                     dropout=dropout, dtype=dtype)
+
+    def _make_final_norm(self, dtype):
+        return LayerNorm(self.embed_dim, dtype=dtype)
+
+    # -- embedding -----------------------------------------------------------
+    def embedding(self, tokens, pad_args=None):
+        """Embedding rows; `<mask>` rows zeroed without rescale (esm.py:188-189); for 2-D
+        tokens `<pad>` rows are zeroed too (esm.py:191-193)."""
+        if tokens.ndim not in (1, 2):
+            raise ValueError('tokens must be 1D or 2D')
+        return _hip.embed(tokens, self.embed_tokens.weight,
+                          mask_idx=self.alphabet.mask_idx if self.zero_mask_rows else -1,
+                          pad_idx=self.alphabet.padding_idx if (tokens.ndim == 2 and self.zero_mask_rows) else -1)
+
+    # -- helpers ---------------------------------------------------------------
+    def _context(self, cu_lens, max_len, total, device) -> ForwardContext:
+        pos, _ = _hip.seq_positions(cu_lens, total)
+        rot = self.layers[0].self_attn.rot_emb if len(self.layers) else None
+        cos = sin = None
+        if rot is not None:
+            cos, sin = rot.tables(int(max_len), device, torch.bfloat16)
+        return ForwardContext(pos, cos, sin)
+
+    def _unpad(self, x, tokens):
+        """Boolean-mask row gather: the `unpad_input` contract (esm.py:238)."""
+        keep = tokens.ne(self.alphabet.padding_idx)
+        lens = keep.sum(dim=1, dtype=torch.int32)
+        indices = torch.nonzero(keep.flatten(), as_tuple=False).flatten()
+        cu_lens = torch.zeros(tokens.shape[0] + 1, dtype=torch.int32, device=tokens.device)
+        cu_lens[1:] = torch.cumsum(lens, 0)
+        max_len = int(lens.max())
+        return _hip.gather_rows(x.view(-1, x.shape[-1]), indices), indices, cu_lens, max_len
+
+    @staticmethod
+    def _pad(x, indices, batch, seqlen):
+        """`pad_input`: scatter packed rows into zeros (B*S, E) -> (B, S, E) (esm.py:255)."""
+        return _hip.scatter_rows(x, indices, batch * seqlen).view(batch, seqlen, x.shape[-1])
+
+    def _check_layers_arg(self, layers):
+        assert all(i < len(self.layers) for i in layers), \
+            f'Invalid layer indices {layers}. The number of layers in the model is {len(self.layers)}.'
+
+    # -- forward -----------------------------------------------------------------
+    def forward_representation(self, tokens, pad_args=None, pad_output=False, pad_indices=None,
+                               lora_names=None, layers=None):
+        """Per-token representations: (T, E) for packed input, (B, S, E) when padded;
+        with `layers=[...]` the raw outputs of those layers are concatenated after the
+        final-LayerNorm output on the feature axis (esm.py:201-266)."""
+        assert lora_names is None, 'LoRA adapters are outside the inference hot path'
+        layers = list(layers) if layers else []
+        self._check_layers_arg(layers)
+
+        x = self.embedding(tokens, pad_args)
+        if pad_args is not None:
+            assert tokens.ndim == 1, 'tokens are expected to be unpadded with shape (batch * seq_len)'
+            cu_lens, max_len = pad_args
+        else:
+            assert tokens.ndim == 2, 'tokens are expected to be padded with shape (batch, seq_len, embed_dim)'
+            x, pad_indices, cu_lens, max_len = self._unpad(x, tokens)
+        if cu_lens.dtype != torch.int32:
+            cu_lens = cu_lens.to(torch.int32)
+        max_len = int(max_len)
+
+        ctx = self._context(cu_lens, max_len, x.shape[0], x.device)
+        taps = []
+        for i, layer in enumerate(self.layers):
+            x = layer(x, cu_lens, max_len, None, ctx, inplace=True)
+            if i in layers:
+                taps.append(x.clone())
+        x = self.emb_layer_norm_after(x, out=x)
+
+        if pad_output or (pad_args is None):
+            nseq = cu_lens.numel() - 1
+            x = self._pad(x, pad_indices, nseq, max_len)
+            taps = [self._pad(t, pad_indices, nseq, max_len) for t in taps]
+        return torch.concat((x, *taps), dim=-1) if taps else x
+
+    def forward(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
+        """Logits (T, V) / (B, S, V), bf16, on the model's device (esm.py:268-282)."""
+        return self.lm_head(self.forward_representation(tokens, pad_args, pad_output, pad_indices, lora_names))
+
+    def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
+        return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
+
+    def predict_prob(self, tokens, log=False, pad_args=None, pad_output=False, pad_indices=None,
+                     lora_names=None):
+        return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
+
+    # -- loading -------------------------------------------------------------------
+    @classmethod
+    def create_model(cls, path, checkpointing=False):
+        """Model skeleton (meta tensors) from the checkpoint's metadata strings
+        (esm.py:319-340)."""
+        md = _read_metadata(path)
+        name = md['name'].split('_')[0]
+        assert name == cls.__name__.lower(), \
+            f'Invalid weight for the {cls.__name__} model. ' \
+            f'You are trying to load a {name} model weights to a {cls.__name__} model.'
+        with torch.device('meta'):
+            return cls(num_layers=int(md['num_layers']), embed_dim=int(md['embed_dim']),
+                       attention_heads=int(md['attention_heads']), checkpointing=checkpointing)
+
+    @classmethod
+    def from_pretrained(cls, path, quantization=None, checkpointing=False, device='cpu'):
+        """Load a safetensors checkpoint in the reference layout.
+        The file's tensors become the parameters directly (no copy besides the H2D)."""
+        assert quantization in {None, '8bit', '4bit', '8bitexperimental'}, \
+            f'load_in must be one of [None, "8bit", "4bit"] but got {quantization}'
+        if quantization is not None:
+            assert device != 'cpu', 'Quantized model cannot be loaded on cpu provide CUDA gpu device'
+            raise NotImplementedError('weight quantisation is a later row of the scope table (SURVEY.md §8f)')
+        from safetensors.torch import load_file
+        model = cls.create_model(path, checkpointing=checkpointing)
+        dev = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
+        state = load_file(path, device=str(dev))
+        model.load_state_dict(state, strict=True, assign=True)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        return model.eval()
+
+
+class ESMC(ESM2):
+    alphabet = Alphabet3
+    vocab_size = 64
+    zero_mask_rows = False         # plain lookup (esm.py:876)
+
+    def __init__(self, num_layers: int = 30, embed_dim: int = 960, attention_heads: int = 15,
+                 checkpointing: bool = False, dropout: float = 0., dtype=torch.bfloat16):
+        super().__init__(num_layers=num_layers, embed_dim=embed_dim, attention_heads=attention_heads,
+                         checkpointing=checkpointing, rotary_embedding=True, dropout=dropout, dtype=dtype)
+
+    def _make_layer(self, rotary_embedding, dropout, dtype):
+        return FlashTransformerLayer(self.embed_dim, 8 / 3, self.attention_heads, rotary_embedding=True,
+                                     pre_layernorm=True, bias=False, final_activation='swiglu',
+                                     residue_scaling=math.sqrt(self.num_layers / 36), dropout=dropout, dtype=dtype)
+
+    def _make_final_norm(self, dtype):
+        return LayerNorm(self.embed_dim, bias=False, dtype=dtype)
+
+    def _check_layers_arg(self, layers):
+        # the reference compares against the *argument* list here (esm.py:873) -- reproduced as is
+        assert all(i < len(layers) for i in layers), \
+            f'Invalid layer indices {layers}. The number of layers in the model is {len(self.layers)}.'

@@ -1,0 +1,69 @@
+"""Varlen rotary position embedding on the HIP path.
+
+Mirrors the reference's `RotaryEmbedding` (esme/rotary.py:81-165): fp32
+inv_freq = base^(-2j/d), cos/sin tables of shape (max_len, d) (halves duplicated)
+cached while max_len does not grow, cast to the activation dtype (bf16) -- but the
+~10 ATen launches + host sync per call are one fused in-place kernel here, and
+the row -> position map is computed once per forward instead of twice per layer.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from esme import _hip
+
+
+def culen_indices(cu_lens: torch.Tensor) -> torch.Tensor:
+    """Position of each packed row inside its sequence (reference rotary.py:5-14),
+    int64 like the reference; computed by the HIP kernel (no host sync beyond the
+    total length)."""
+    total = int(cu_lens[-1])
+    if cu_lens.is_cuda:
+        return _hip.seq_positions(cu_lens, total)[0].to(torch.int64)
+    cu = cu_lens.to(torch.int64)
+    lengths = cu[1:] - cu[:-1]
+    return torch.arange(total) - torch.repeat_interleave(cu[:-1], lengths)
+
+
+class RotaryEmbedding(nn.Module):
+    def __init__(self, dim: int, base: float = 10000.0, pos_idx_in_fp32: bool = True, device=None):
+        super().__init__()
+        self.dim, self.base = dim, float(base)
+        self._seq_len_cached = 0
+        self._cos_cached: Optional[torch.Tensor] = None
+        self._sin_cached: Optional[torch.Tensor] = None
+
+    def _compute_inv_freq(self) -> torch.Tensor:
+        return 1.0 / (self.base ** (torch.arange(0, self.dim, 2, dtype=torch.float32) / self.dim))
+
+    def _update_cos_sin_cache(self, seqlen: int, device=None, dtype=torch.bfloat16) -> None:
+        """Tables are built on the host in fp32 and rounded to `dtype` exactly as the
+        reference does on its device (rotary.py:116-149), then uploaded once."""
+        if (seqlen > self._seq_len_cached or self._cos_cached is None
+                or self._cos_cached.device != torch.device(device) or self._cos_cached.dtype != dtype):
+            seqlen = max(seqlen, self._seq_len_cached)
+            t = torch.arange(seqlen, dtype=torch.float32)
+            ang = torch.outer(t, self._compute_inv_freq())
+            ang = torch.cat((ang, ang), dim=-1)
+            self._cos_cached = ang.cos().to(dtype).to(device)
+            self._sin_cached = ang.sin().to(dtype).to(device)
+            self._seq_len_cached = seqlen
+
+    def tables(self, max_len: int, device, dtype=torch.bfloat16) -> Tuple[torch.Tensor, torch.Tensor]:
+        self._update_cos_sin_cache(max_len, device, dtype)
+        return self._cos_cached, self._sin_cached
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
+                pos: Optional[torch.Tensor] = None):
+        """q, k: (T, H, d) bf16 (views allowed if rows are contiguous).  Rotates both
+        IN PLACE and returns them (the reference returns new tensors; callers on the
+        path never reuse the unrotated ones)."""
+        T, H, d = q.shape
+        cos, sin = self.tables(max_len, q.device, q.dtype)
+        if pos is None:
+            pos, _ = _hip.seq_positions(cu_lens, T)
+        _hip.rotary_(q.view(T, H * d), k.view(T, H * d), cos, sin, pos, H)
+        return q, k

@@ -1,0 +1,119 @@
+/* libesme_hip -- C ABI of the MI355X (gfx950) kernels behind the packed ESM-2 / ESM-C
+ * forward pass.  This is the drop-in boundary: plain pointers and sizes, no torch
+ * types.  A binding (ctypes here) needs nothing but this file.
+ *
+ * The reference (uci-cbcl/esm-efficient) has no FFI of its own: its native seam is the
+ * Python signature of flash_attn_varlen_func plus the torch ops its nn.Modules call.
+ * Each entry point below cites the reference call site(s) it replaces (paths relative
+ * to the reference repo root).
+ *
+ * Conventions
+ *  - bf16 tensors are passed as `const void*` to raw 16-bit storage, row-major, with an
+ *    explicit leading dimension in ELEMENTS (ld*), so q/k/v can live in one fused
+ *    (T, 3E) buffer.  All base pointers and row strides must be 16-byte aligned.
+ *  - Packed layout: residues of sequence i occupy rows cu_lens[i] .. cu_lens[i+1]-1;
+ *    cu_lens is int32 (B+1) on the device.
+ *  - The caller owns every buffer (including workspace); the library never allocates,
+ *    frees, synchronises or retains a pointer beyond the call.  All work is enqueued on
+ *    the hipStream_t passed as `stream` (a void* here so the header needs no HIP).
+ *  - Every function returns 0 on success or a negative ESME_ERR_* code;
+ *    esme_hip_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef ESME_HIP_H
+#define ESME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESME_HIP_ABI_VERSION 1
+
+enum {
+    ESME_OK = 0,
+    ESME_ERR_ARG = -1,          /* null / misaligned pointer, negative size, bad enum   */
+    ESME_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels implement             */
+    ESME_ERR_LAUNCH = -3        /* hipGetLastError() != hipSuccess after the launch     */
+};
+
+/* GEMM epilogues: C = epi(A W^T + bias) */
+enum {
+    ESME_EPI_NONE = 0,      /* C = acc (+bias)                                           */
+    ESME_EPI_GELU = 1,      /* C = gelu_erf(acc + bias)          attention.py:231-233    */
+    ESME_EPI_RESIDUAL = 2,  /* C = resid + alpha*(acc + bias)    attention.py:253-255    */
+    ESME_EPI_SWIGLU = 3     /* C[:, f] = silu(acc[:, gate f]) * acc[:, fc f]; W rows are
+                               interleaved in 32-row blocks [gate 0-31 | fc 0-31 | gate
+                               32-63 | ...]; C has N/2 columns   attention.py:258-281    */
+};
+
+int esme_hip_abi_version(void);
+const char* esme_hip_last_error(void);
+
+/* Row gather from the (V, E) embedding table; rows whose token == mask_idx or == pad_idx
+ * are written as zeros (pass -1 to disable either).  tokens: int64 (T).
+ * Replaces: ESM2.embedding esme/esm.py:176-199 (mask zeroing :189, pad zeroing
+ * :191-193) and the ESM-C lookup esme/esm.py:876. */
+int esme_hip_embed(const int64_t* tokens, const void* table, void* out, int64_t T, int E,
+                   int V, int mask_idx, int pad_idx, void* stream);
+
+/* pos[t] = t - cu_lens[seq(t)], seq_id[t] = seq(t) for every packed row (either output
+ * may be NULL).  Replaces: culen_indices esme/rotary.py:5-14 (recomputed twice per layer
+ * there, with a host sync; computed once per forward here). */
+int esme_hip_seq_positions(const int32_t* cu_lens, int B, int64_t T, int32_t* pos,
+                           int32_t* seq_id, void* stream);
+
+/* y = LayerNorm(x) over the last dim E (fp32 statistics, biased variance, eps inside the
+ * sqrt), affine weight w and optional bias b (NULL = none).  x and y may alias.
+ * Replaces: nn.LayerNorm at esme/attention.py:75,88-89,222,230; esme/esm.py:172,847;
+ * esme/head.py:22. */
+int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y,
+                       int64_t ldy, int64_t T, int E, float eps, void* stream);
+
+/* In-place rotary embedding of q and k, both (T, H, d) views with row stride ld:
+ * x[j] <- x[j]*cos[p][j] - x[j+d/2]*sin[p][j];  x[j+d/2] <- x[j+d/2]*cos[p][j] + x[j]*sin[p][j]
+ * with p = pos[t].  cos/sin: bf16 tables (max_len, d) as the reference caches them
+ * (duplicated halves; only the first d/2 columns are read).
+ * Replaces: RotaryEmbedding.forward / apply_rotary / rotate_half esme/rotary.py:17-43,151-165. */
+int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cos, const void* sin,
+                           const int32_t* pos, int64_t T, int H, int d, int max_len,
+                           void* stream);
+
+/* Varlen (block-diagonal) multi-head self-attention, non-causal, no dropout:
+ * per sequence i and head h, O = softmax(Q K^T * softmax_scale) V over that sequence's
+ * rows only.  q, k, v: (T, H, d) views with row stride ld_qkv; o: (T, H*d) with row
+ * stride ld_o.  bf16 operands, fp32 scores / softmax / accumulators, P rounded to bf16
+ * before the PV product (flash-attention-2 convention).  d in {16, 32, 64, 128}.
+ * Replaces: flash_attn_varlen_func at esme/attention.py:115-123 (third-party CUDA). */
+int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
+                             void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
+                             int H, int d, int max_len, float softmax_scale, void* stream);
+
+/* C (M, N') = epilogue(A (M, K) @ W (N, K)^T + bias (N)), bf16 in/out, fp32 accumulate on
+ * MFMA.  bias may be NULL.  resid (M, N) is read only for ESME_EPI_RESIDUAL and may alias C.
+ * N' = N/2 for ESME_EPI_SWIGLU, else N.  K must be a multiple of 64.
+ * Replaces: every nn.Linear on the path -- esme/attention.py:76-79 (q,k,v,out),
+ * :225,231,234,269-271 (FFN), esme/head.py:21,23 -- with the GELU (attention.py:233,
+ * head.py:26), SiLU*mul (attention.py:281) and residual/scale (attention.py:253-255)
+ * passes fused into the epilogue. */
+int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias,
+                       const void* resid, int64_t ldr, void* C, int64_t ldc, int64_t M, int N,
+                       int K, int epilogue, float alpha, void* stream);
+
+/* y = softmax(x) or log_softmax(x) over the last dim V <= 64 (fp32 inside, bf16 out).
+ * Replaces: torch.log_softmax / torch.softmax at esme/esm.py:297-298,315-317. */
+int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t T, int V,
+                          int log_flag, void* stream);
+
+/* dst[i, :] = src[idx[i], :]  (unpad_input's row gather, esme/esm.py:238) and
+ * dst[idx[i], :] = src[i, :] (pad_input's scatter into a zeroed buffer, esme/esm.py:255).
+ * idx: int64 (n).  E elements per row, multiple of 8. */
+int esme_hip_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E,
+                         void* stream);
+int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESME_HIP_H */

@@ -1,0 +1,265 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (esme._hip -> libesme_hip.so).
+
+Each HIP kernel is compared with the CPU oracle (oracle/esm_oracle.py, fp32 math on
+the same bf16-rounded inputs).  Tolerances (stated per test) are in units of the bf16
+output rounding: a correctly rounded bf16 result is within 2^-9 relative of the fp32
+value; we allow 2^-7 relative plus an absolute floor tied to the output scale for
+entries that are the result of cancellation.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rel_fro
+from oracle import esm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16_RTOL = 2.0 ** -7
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def rnd(shape, seed, scale=1.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (torch.from_numpy(rng.standard_normal(shape, dtype=np.float32)) * scale).to(torch.bfloat16)
+
+
+def check(got, ref, rtol=BF16_RTOL, atol_scale=2.0 ** -7, what=''):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f'{what}: non-finite output'
+    atol = atol_scale * float(ref.pow(2).mean().sqrt())
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bad.any(), (f'{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.4g} '
+                           f'at {np.unravel_index(int(err.argmax()), err.shape)}, rel_fro {rel_fro(got, ref):.3g}')
+
+
+def test_library_loads_on_gpu():
+    from esme import _hip
+    assert _hip.load().esme_hip_abi_version() == _hip.ABI_VERSION
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('T,E,V,mask,pad', [(54, 320, 33, 32, -1), (1000, 1280, 33, 32, 1), (7, 64, 64, -1, -1)])
+def test_embed(T, E, V, mask, pad):
+    from esme import _hip
+    table = rnd((V, E), 1)
+    rng = np.random.Generator(np.random.PCG64(2))
+    tok = torch.from_numpy(rng.integers(0, V, size=T, dtype=np.int64))
+    tok[::5] = 32 % V
+    tok[1::7] = 1
+    out = _hip.embed(tok.to(dev()), table.to(dev()), mask, pad).cpu()
+    ref = table[tok].clone()
+    if mask >= 0:
+        ref[tok == mask] = 0
+    if pad >= 0:
+        ref[tok == pad] = 0
+    assert torch.equal(out, ref)                 # pure copy: bit-exact
+
+
+def test_seq_positions():
+    from esme import _hip
+    for lengths in ([5, 26, 61], [1, 1, 1, 300, 2], [1000], [3] * 700):
+        cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+        pos, seq = _hip.seq_positions(cu.to(dev()), int(cu[-1]))
+        assert torch.equal(pos.cpu().long(), O.culen_positions(cu))      # integer: bit-exact
+        assert torch.equal(seq.cpu().long(), torch.repeat_interleave(torch.arange(len(lengths)), torch.tensor(lengths)))
+
+
+@pytest.mark.parametrize('T,E,bias', [(37, 64, True), (300, 320, True), (123, 640, True), (1001, 1280, True),
+                                      (77, 1152, False), (50, 2560, True), (9, 5120, True)])
+def test_layernorm(T, E, bias):
+    from esme import _hip
+    x = rnd((T, E), 3, 2.0) + 0.5
+    w = (1 + 0.1 * rnd((E,), 4).float()).to(torch.bfloat16)
+    b = rnd((E,), 5, 0.1) if bias else None
+    ref = torch.nn.functional.layer_norm(x.float(), (E,), w.float(), b.float() if bias else None, 1e-5)
+    got = _hip.layernorm(x.to(dev()), w.to(dev()), b.to(dev()) if bias else None)
+    check(got, ref, what=f'layernorm {T}x{E}')
+    # strided in-place variant (the ESM-C q/k LayerNorm inside the fused qkv buffer)
+    buf = torch.zeros(T, 3 * E, dtype=torch.bfloat16)
+    buf[:, E:2 * E] = x
+    g = buf.to(dev())
+    _hip.layernorm(g[:, E:2 * E], w.to(dev()), b.to(dev()) if bias else None, out=g[:, E:2 * E])
+    check(g[:, E:2 * E], ref, what='layernorm strided in-place')
+    assert torch.equal(g[:, :E].cpu(), buf[:, :E]) and torch.equal(g[:, 2 * E:].cpu(), buf[:, 2 * E:])
+
+
+@pytest.mark.parametrize('lengths,H,d', [([60, 40, 180], 4, 32), ([5, 26, 61], 4, 16), ([37, 70, 193], 20, 64),
+                                         ([513], 2, 128)])
+def test_rotary(lengths, H, d):
+    from esme import _hip
+    T, E = sum(lengths), H * d
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    max_len = max(lengths)
+    qkv = rnd((T, 3 * E), 6)
+    cos, sin = O.rotary_tables(max_len, d, torch.bfloat16)
+    pos = O.culen_positions(cu)
+    # fp32 math on the bf16 tables (what the kernel computes before its single rounding)
+    ref_q = O.apply_rotary(qkv[:, :E].float().view(T, H, d), cos.float(), sin.float(), pos).view(T, E)
+    ref_k = O.apply_rotary(qkv[:, E:2 * E].float().view(T, H, d), cos.float(), sin.float(), pos).view(T, E)
+    g = qkv.to(dev())
+    p, _ = _hip.seq_positions(cu.to(dev()), T)
+    _hip.rotary_(g[:, :E], g[:, E:2 * E], cos.to(dev()), sin.to(dev()), p, H)
+    check(g[:, :E], ref_q, what='rotary q')
+    check(g[:, E:2 * E], ref_k, what='rotary k')
+    assert torch.equal(g[:, 2 * E:].cpu(), qkv[:, 2 * E:])      # v untouched
+    # and against the reference's own bf16 arithmetic (3 roundings): within 2 bf16 ulps
+    ref_bf = O.apply_rotary(qkv[:, :E].view(T, H, d), cos, sin, pos).view(T, E)
+    check(g[:, :E], ref_bf.float(), rtol=2.0 ** -6, what='rotary q vs bf16 reference arithmetic')
+
+
+GEMM_SHAPES = [
+    # M, N, K
+    (54, 320, 320), (54, 960, 320), (54, 1280, 320), (54, 320, 1280),      # ESM2-8M widths, tiny M
+    (300, 3840, 1280), (300, 1280, 5120), (1000, 5120, 1280),              # 650M widths
+    (257, 1920, 640), (129, 33, 1280), (200, 64, 1152), (513, 3456, 1152),
+    (5000, 1280, 1280),
+]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_bias(M, N, K, tile):
+    from esme import _hip
+    _hip.load().esme_hip_debug_set_gemm_tile(tile)
+    try:
+        a, w, b = rnd((M, K), 7), rnd((N, K), 8, 1 / math.sqrt(K)), rnd((N,), 9, 0.1)
+        ref = a.float() @ w.float().T + b.float()
+        got = _hip.gemm(a.to(dev()), w.to(dev()), b.to(dev()))
+        check(got, ref, what=f'gemm {M}x{N}x{K} tile{tile}')
+        got = _hip.gemm(a.to(dev()), w.to(dev()), None)
+        check(got, ref - b.float(), what=f'gemm nobias {M}x{N}x{K} tile{tile}')
+    finally:
+        _hip.load().esme_hip_debug_set_gemm_tile(0)
+
+
+def test_gemm_transpose_detecting():
+    """A = I (padded) with an asymmetric W: catches swapped output indices."""
+    from esme import _hip
+    M = N = K = 128
+    a = torch.eye(M, K, dtype=torch.bfloat16)
+    w = (torch.arange(N).view(N, 1) * 0.25 + torch.arange(K).view(1, K) * 2.0).to(torch.bfloat16)
+    got = _hip.gemm(a.to(dev()), w.to(dev())).cpu()
+    assert torch.equal(got, w.T.contiguous())
+
+
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_epilogues(tile):
+    from esme import _hip
+    _hip.load().esme_hip_debug_set_gemm_tile(tile)
+    try:
+        M, N, K = 333, 1280, 640
+        a, w, b = rnd((M, K), 10), rnd((N, K), 11, 1 / math.sqrt(K)), rnd((N,), 12, 0.1)
+        r = rnd((M, N), 13)
+        lin = a.float() @ w.float().T + b.float()
+        got = _hip.gemm(a.to(dev()), w.to(dev()), b.to(dev()), _hip.EPI_GELU)
+        check(got, torch.nn.functional.gelu(lin), what='gemm+gelu')
+        got = _hip.gemm(a.to(dev()), w.to(dev()), b.to(dev()), _hip.EPI_RESIDUAL, resid=r.to(dev()), alpha=0.75)
+        check(got, r.float() + 0.75 * lin, what='gemm+residual')
+        # in place: out aliases resid
+        rg = r.to(dev())
+        _hip.gemm(a.to(dev()), w.to(dev()), b.to(dev()), _hip.EPI_RESIDUAL, resid=rg, alpha=1.0, out=rg)
+        check(rg, r.float() + lin, what='gemm+residual in place')
+        # SwiGLU over the interleaved weight
+        F = 768
+        wa, wf = rnd((F, K), 14, 1 / math.sqrt(K)), rnd((F, K), 15, 1 / math.sqrt(K))
+        packed = torch.cat((wa.view(F // 32, 1, 32, K), wf.view(F // 32, 1, 32, K)), 1).reshape(2 * F, K).contiguous()
+        got = _hip.gemm(a.to(dev()), packed.to(dev()), None, _hip.EPI_SWIGLU)
+        ref = torch.nn.functional.silu(a.float() @ wa.float().T) * (a.float() @ wf.float().T)
+        check(got, ref, what='gemm+swiglu')
+    finally:
+        _hip.load().esme_hip_debug_set_gemm_tile(0)
+
+
+def _attn_case(lengths, H, d, seed, qscale=1.0, spike=False):
+    from esme import _hip
+    T, E = sum(lengths), H * d
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    qkv = rnd((T, 3 * E), seed)
+    qkv[:, :2 * E] *= qscale
+    if spike:
+        # force the online-softmax rescale branch late in a long sequence: one key row
+        # strongly aligned with one query row far into the key range
+        a = int(cu[-2])
+        s_len = lengths[-1]
+        qi, ki = a + 3, a + s_len - 5
+        qkv[ki, E:2 * E] = qkv[qi, :E] * 4.0
+    q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    ref = O.varlen_attention(q, k, v, cu).view(T, E)
+    g = qkv.to(dev())
+    got = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H)
+    return got, ref
+
+
+@pytest.mark.parametrize('lengths,H,d', [
+    ([5, 26, 61], 4, 16), ([1, 2, 64, 65, 128, 129], 3, 16),
+    ([130, 9, 61], 20, 32), ([37, 70, 193], 20, 64), ([500, 500], 20, 64), ([1, 300, 63, 64], 5, 64),
+    ([700], 2, 128), ([1253], 4, 64),
+])
+def test_attention(lengths, H, d):
+    got, ref = _attn_case(lengths, H, d, seed=20)
+    # P is rounded to bf16 before PV (FA-2 convention): allow 2^-6 relative + 2^-6 of the rms
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention {lengths} H{H} d{d}')
+
+
+def test_attention_sharp_softmax_and_rescale():
+    got, ref = _attn_case([40, 900], 4, 64, seed=21, qscale=3.0, spike=True)
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='attention sharp/spiked')
+
+
+def test_attention_sequence_independence():
+    """A sequence's output must not depend on what it is packed with
+    (the property the reference checks in tests/test_esm.py:31-42)."""
+    from esme import _hip
+    H, d = 20, 64
+    E = H * d
+    a = rnd((150, 3 * E), 30)
+    other = rnd((333, 3 * E), 31)
+    def run(parts):
+        x = torch.cat(parts).to(dev())
+        cu = torch.tensor(np.cumsum([0] + [p.shape[0] for p in parts]), dtype=torch.int32).to(dev())
+        return _hip.attn_varlen(x[:, :E], x[:, E:2 * E], x[:, 2 * E:], cu, max(p.shape[0] for p in parts), H).cpu()
+    alone = run([a])
+    packed = run([other, a, other[:7]])
+    assert torch.equal(alone, packed[333:483])          # bit-exact: same tiles, same order
+
+
+@pytest.mark.parametrize('V', [33, 64])
+def test_softmax_rows(V):
+    from esme import _hip
+    x = rnd((1000, V), 40, 3.0)
+    g = x.to(dev())
+    check(_hip.softmax_rows(g, log=True), torch.log_softmax(x.float(), -1), what='log_softmax')
+    check(_hip.softmax_rows(g, log=False), torch.softmax(x.float(), -1), what='softmax')
+    padded = torch.zeros(1000, 64, dtype=torch.bfloat16)
+    padded[:, :V] = x
+    check(_hip.softmax_rows(padded.to(dev())[:, :V], log=True), torch.log_softmax(x.float(), -1), what='log_softmax strided')
+
+
+def test_gather_scatter_rows():
+    from esme import _hip
+    src = rnd((50, 64), 41)
+    idx = torch.tensor([3, 0, 49, 7, 7, 20], dtype=torch.int64)
+    assert torch.equal(_hip.gather_rows(src.to(dev()), idx.to(dev())).cpu(), src[idx])
+    idx2 = torch.tensor([5, 1, 30, 2], dtype=torch.int64)
+    out = _hip.scatter_rows(src[:4].to(dev()), idx2.to(dev()), 40).cpu()
+    ref = torch.zeros(40, 64, dtype=torch.bfloat16)
+    ref[idx2] = src[:4]
+    assert torch.equal(out, ref)
+
+
+def test_error_reporting():
+    from esme import _hip
+    a = rnd((8, 100), 1).to(dev())          # K = 100 is not a multiple of 64
+    w = rnd((64, 100), 2).to(dev())
+    with pytest.raises(RuntimeError, match='multiple of 64'):
+        _hip.gemm(a, w)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _hip.layernorm(rnd((4, 64), 1), rnd((64,), 2))

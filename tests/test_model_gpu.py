@@ -1,0 +1,170 @@
+"""End-to-end GPU parity: the HIP forward (ESM2 / ESMC behind the reference's API) vs
+(a) the committed golden outputs of the reference itself and (b) the CPU oracle.
+
+Tolerance (floating point, stated as the task requires): the reference computes in
+bf16; its own bf16 forward differs from its fp32-math forward on the same weights by
+6.5-7.5e-3 Frobenius-relative.  The HIP path keeps bf16 storage at
+the same points but does all arithmetic in fp32 with a single rounding per fused
+stage, so it must be at least as close to the fp32 forward as the reference's bf16
+forward is:   rel_fro(hip, ref_fp32) <= max(1.25 * rel_fro(ref_bf16, ref_fp32), 4e-3)
+and           rel_fro(hip, ref_bf16) <= 2e-2,  per-row cosine >= 0.999.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import load_golden, rel_fro
+from oracle import esm_oracle as O
+from esme import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def build(kind, L, E, H, seed):
+    from esme import ESM
+    with tempfile.TemporaryDirectory() as td:
+        name = f'{kind}_test'
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), name, L, E, H, seed=seed)
+        return ESM.from_pretrained(path, device=DEV)
+
+
+def assert_parity(got, ref32, refbf, what):
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), what
+    e_hip = rel_fro(got, ref32)
+    e_ref = rel_fro(refbf.float(), ref32)
+    e_bf = rel_fro(got, refbf.float())
+    cos = F.cosine_similarity(got.reshape(-1, got.shape[-1]), ref32.reshape(-1, ref32.shape[-1]), dim=-1).min()
+    print(f'\n[parity] {what}: hip-vs-fp32 {e_hip:.3e} | ref_bf16-vs-fp32 {e_ref:.3e} | hip-vs-ref_bf16 {e_bf:.3e} '
+          f'| min row cosine {float(cos):.6f}')
+    assert e_hip <= max(1.25 * e_ref, 4e-3), (what, e_hip, e_ref)
+    assert e_bf <= 2e-2, (what, e_bf)
+    assert cos >= 0.999, (what, float(cos))
+
+
+@pytest.mark.parametrize('fname', ['g1_esm2_tiny.npz', 'g4_esmc_tiny.npz', 'g3_esm2_650m_layer.npz',
+                                   'g3b_esm2_150m_layer.npz', 'g4b_esmc_300m_layer.npz'])
+def test_forward_vs_golden(fname):
+    g = load_golden(fname)
+    model = build(g['kind'], g['L'], g['E'], g['H'], g['seed'])
+    tokens, cu, max_len = g['tokens'].to(DEV), g['cu_lens'].to(DEV), g['max_len']
+    logits = model(tokens, (cu, max_len))
+    assert logits.dtype == torch.bfloat16 and logits.shape == g['logits_f32'].shape and logits.is_contiguous()
+    assert_parity(logits, g['logits_f32'], g['logits_bf16'], f'{fname} logits')
+    lp = model.predict_log_prob(tokens, (cu, max_len))
+    assert_parity(lp, g['logprob_f32'], g['logprob_bf16'], f'{fname} log_prob')
+    prob = model.predict_prob(tokens, pad_args=(cu, max_len)).float().cpu()
+    assert torch.allclose(prob.sum(-1), torch.ones(prob.shape[0]), atol=2e-2)
+    rep = model.forward_representation(tokens, (cu, max_len))
+    assert rep.shape == (tokens.numel(), g['E'])
+    assert_parity(rep.cpu()[g['tap_rows']], g['rep_f32'], g['rep_bf16'], f'{fname} representation')
+
+
+@pytest.mark.parametrize('fname', ['g1_esm2_tiny.npz', 'g3_esm2_650m_layer.npz', 'g4b_esmc_300m_layer.npz'])
+def test_layer_stage_taps(fname):
+    """Stage-by-stage comparison of layer 0 against the reference's taps."""
+    from esme import _hip
+    g = load_golden(fname)
+    model = build(g['kind'], g['L'], g['E'], g['H'], g['seed'])
+    rows = g['tap_rows']
+    tokens, cu, max_len = g['tokens'].to(DEV), g['cu_lens'].to(DEV), g['max_len']
+    x0 = model.embedding(tokens)
+    assert torch.equal(x0.cpu()[rows], g['emb_bf16'])
+    layer = model.layers[0]
+    att = layer.self_attn
+    T, E = x0.shape
+    taps = {'ln1': att.norm(x0)}
+    q, k, v = att._qkv(x0)
+    taps.update(q=q.reshape(T, E).clone(), k=k.reshape(T, E).clone(), v=v.reshape(T, E).clone())
+    q, k = att.rot_emb(q, k, cu, max_len)
+    taps.update(q_rot=q.reshape(T, E).clone(), k_rot=k.reshape(T, E).clone())
+    a = att._attn(q, k, v, cu, max_len)
+    taps['attn'] = a
+    taps['attn_out'] = att.out(a)
+    out = layer(x0, cu, max_len)
+    taps['x_out'] = out
+    for name, t in taps.items():
+        assert_parity(t.cpu()[rows], g[f'l0_{name}_f32'], g[f'l0_{name}_bf16'], f'{fname} l0.{name}')
+    assert torch.equal(model.embedding(tokens), x0), 'layer() without inplace must not modify its input'
+
+
+@pytest.mark.parametrize('fname', ['g1_esm2_tiny.npz', 'g4_esmc_tiny.npz'])
+def test_padded_path_and_layers_arg(fname):
+    g = load_golden(fname)
+    model = build(g['kind'], g['L'], g['E'], g['H'], g['seed'])
+    tok2d = g['tokens2d'].to(DEV)
+    logits = model(tok2d)
+    assert logits.shape == g['logits2d_f32'].shape
+    assert_parity(logits, g['logits2d_f32'], g['logits2d_bf16'], f'{fname} padded logits')
+    if 'layers_arg' in g:
+        tokens, cu = g['tokens'].to(DEV), g['cu_lens'].to(DEV)
+        rep = model.forward_representation(tokens, (cu, g['max_len']), layers=g['layers_arg'].tolist())
+        assert rep.shape == g['rep_layers_f32'].shape
+        assert_parity(rep, g['rep_layers_f32'], g['rep_layers_bf16'], f'{fname} layers= taps')
+
+
+def test_readme_example_8m():
+    """BASELINE config 1 on the GPU: README sequences through tokenize / tokenize_unpad."""
+    from esme import ESM2
+    from esme.alphabet import Alphabet, tokenize, tokenize_unpad
+    g = load_golden('g2_esm2_8m_readme.npz')
+    model = build('esm2', 6, 320, 20, g['seed'])
+    assert isinstance(model, ESM2)
+    seqs = ['MEEPQSDPSVEPPLSQESTFSLDLWK', 'MADQLTEEQIAEFKEAFSLFDKDG']
+    tokens, _, cu, max_len = tokenize_unpad(seqs, alphabet=Alphabet)
+    assert torch.equal(tokens, g['tokens'])
+    lp = model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), max_len))
+    assert lp.shape == (54, 33)
+    assert_parity(lp, g['logprob_f32'], g['logprob_bf16'], 'README packed log_prob')
+    lp2 = model.predict_log_prob(tokenize(seqs, alphabet=Alphabet).to(DEV))
+    assert lp2.shape == (2, 28, 33)
+    assert_parity(lp2, g['logprob2d_f32'], g['logprob2d_bf16'], 'README padded log_prob')
+
+
+def test_api_errors():
+    model = build('esm2', 1, 64, 4, 1)
+    t1 = torch.zeros(5, dtype=torch.int64, device=DEV)
+    with pytest.raises(AssertionError):
+        model(t1)                                   # 1-D tokens without pad_args
+    with pytest.raises(AssertionError):
+        model(t1.view(1, 5), (torch.tensor([0, 5], dtype=torch.int32, device=DEV), 5))
+    with pytest.raises(AssertionError):
+        model.forward_representation(t1, (torch.tensor([0, 5], dtype=torch.int32, device=DEV), 5), layers=[3])
+    from esme import ESM
+    with pytest.raises(ValueError):
+        ESM.from_pretrained('not_a_model_name')
+
+
+def test_sequence_independence_end_to_end():
+    """Packed [a, b] rows of `a` == `a` alone (reference tests/test_esm.py:31-42)."""
+    model = build('esm2', 2, 320, 20, 5)
+    a = syn.random_tokens([120], seed=1).to(DEV)
+    b = syn.random_tokens([300], seed=2).to(DEV)
+    cu1 = torch.tensor([0, 120], dtype=torch.int32, device=DEV)
+    cu2 = torch.tensor([0, 300, 420], dtype=torch.int32, device=DEV)
+    alone = model(a, (cu1, 120))
+    packed = model(torch.cat((b, a)), (cu2, 300))
+    assert torch.equal(alone, packed[300:])
+
+
+def test_large_batch_properties():
+    """ESM2-150M width at 8 192 packed residues (BASELINE config 2), varlen: finite output,
+    permutation of the sequences permutes the logits, prob rows sum to 1."""
+    model = build('esm2', 2, 640, 20, 6)
+    lengths = syn.proteome_lengths(8192, seed=1)
+    tokens = syn.random_tokens(lengths, seed=1)
+    cu = syn.cu_lens_of(lengths)
+    out = model(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    assert out.shape == (8192, 33) and torch.isfinite(out.float()).all()
+    order = list(reversed(range(len(lengths))))
+    parts = [tokens[cu[i]:cu[i + 1]] for i in order]
+    l2 = [lengths[i] for i in order]
+    out2 = model(torch.cat(parts).to(DEV), (syn.cu_lens_of(l2).to(DEV), max(l2)))
+    back = torch.cat([out2[syn.cu_lens_of(l2)[j]:syn.cu_lens_of(l2)[j + 1]] for j in
+                      sorted(range(len(order)), key=lambda j: order[j])])
+    assert torch.equal(back, out)
