@@ -41,6 +41,31 @@ SIGNATURES = {
 
 _lib = None
 
+# Optional per-launch timing hook (bench.py's roofline leg): when set to a list, every
+# wrapper below brackets its launch with two events on the current stream and appends
+# (op, meta, start_event, end_event).  None (default) = zero overhead.
+TRACE = None
+
+
+class _Traced:
+    __slots__ = ('op', 'meta', 'start')
+
+    def __init__(self, op, meta):
+        self.op, self.meta = op, meta
+
+    def __enter__(self):
+        if TRACE is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TRACE is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            TRACE.append((self.op, self.meta, self.start, end))
+        return False
+
 
 class HipLibraryError(RuntimeError):
     pass
@@ -134,9 +159,10 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     if out is None:
         out = torch.empty(T, E, dtype=torch.bfloat16, device=x.device)
     yp, ldy = _rows2d(out, 'layernorm out')
-    _check(load().esme_hip_layernorm(xp, ldx, _dev(weight, 'layernorm weight', torch.bfloat16),
-                                     _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
-                                     yp, ldy, T, E, eps, _stream()), 'esme_hip_layernorm')
+    with _Traced('layernorm', (T, E)):
+        _check(load().esme_hip_layernorm(xp, ldx, _dev(weight, 'layernorm weight', torch.bfloat16),
+                                         _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
+                                         yp, ldy, T, E, eps, _stream()), 'esme_hip_layernorm')
     return out if x.dim() == 2 else out.view(shape)
 
 
@@ -149,9 +175,10 @@ def rotary_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
         raise ValueError('rotary: q and k must share a row stride')
     T, E = q.shape
     d = E // heads
-    _check(load().esme_hip_rotary_varlen(qp, kp, ld, _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16),
-                                         _dev(pos, 'pos', torch.int32), T, heads, d, cos.shape[0], _stream()),
-           'esme_hip_rotary_varlen')
+    with _Traced('rotary', (T, E)):
+        _check(load().esme_hip_rotary_varlen(qp, kp, ld, _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16),
+                                             _dev(pos, 'pos', torch.int32), T, heads, d, cos.shape[0], _stream()),
+               'esme_hip_rotary_varlen')
 
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
@@ -169,9 +196,10 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     op, ldo = _rows2d(out, 'attn out')
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
-    _check(load().esme_hip_attn_varlen_fwd(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
-                                           cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()),
-           'esme_hip_attn_varlen_fwd')
+    with _Traced('attn', (T, heads, d)):
+        _check(load().esme_hip_attn_varlen_fwd(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
+                                               cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()),
+               'esme_hip_attn_varlen_fwd')
     return out
 
 
@@ -192,9 +220,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     rp, ldr = (None, 0)
     if epilogue == EPI_RESIDUAL:
         rp, ldr = _rows2d(resid, 'gemm resid')
-    _check(load().esme_hip_gemm_bf16(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
-                                     _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
-                                     rp, ldr, cp, ldc, M, N, K, epilogue, alpha, _stream()), 'esme_hip_gemm_bf16')
+    with _Traced('gemm', (M, N, K, epilogue)):
+        _check(load().esme_hip_gemm_bf16(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+                                         _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
+                                         rp, ldr, cp, ldc, M, N, K, epilogue, alpha, _stream()), 'esme_hip_gemm_bf16')
     return out
 
 
