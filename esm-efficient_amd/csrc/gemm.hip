@@ -30,7 +30,7 @@ struct GemmArgs {
     int64_t M; int N; int K;
     float alpha;
     int tiles_n;
-    int vec_ok;                  // C/resid rows allow 8-byte accesses (ld % 4 == 0, 8-B aligned base)
+    int vec_ok;                  // C rows allow 16-byte stores (ldc % 8 == 0, 16-B aligned) and resid rows 8-byte loads
 };
 
 static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
@@ -135,38 +135,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         __syncthreads();                      // next stage landed; everyone done with this one
     }
 
-    // ---- epilogue: lane owns token row m, accumulator quad g = 4 consecutive columns
-    if constexpr (EPI == ESME_EPI_SWIGLU) {
-        const int NO = a.N >> 1;
+    // ---- epilogue.  Lane owns token row m; accumulator quad g = 4 consecutive output columns.
+    // Fast path: bias / activation / residual are applied in the accumulator layout, the bf16
+    // results go through a wave-private LDS slab (XOR-swizzled 16-B chunks) and leave as
+    // 16 B/lane row-contiguous stores -- whole 128-B lines instead of 8-B fragments scattered
+    // over 32 rows (the direct store path measured 1.5x slower end to end).
+    constexpr int OUTC = (EPI == ESME_EPI_SWIGLU) ? WTN / 2 : WTN;     // output columns per wave
+    constexpr int CH = OUTC / 8;                                       // 16-B chunks per slab row
+    constexpr int ROWB = OUTC * 2;
+    constexpr int RPI = 64 / CH;                                       // rows per store instruction
+    char* slab = smem + wave * (WTM * ROWB);
+    const int n_out = (EPI == ESME_EPI_SWIGLU) ? (a.N >> 1) : a.N;
+    const int nw0 = (EPI == ESME_EPI_SWIGLU) ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN);   // first output column of the wave
+    const int64_t mw0 = m0 + wm * WTM;
+
+    if (a.vec_ok) {
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const int64_t m = m0 + wm * WTM + j * 32 + l31;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = ((n0 + wn * WTN) >> 1) + 8 * g + 4 * hi;
-                if (f >= NO) continue;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gate = acc[0][j][4 * g + e], fc = acc[1][j][4 * g + e];
-                    o[e] = gate / (1.0f + __expf(-gate)) * fc;
-                }
-                u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
-                *reinterpret_cast<u32x2*>(a.C + m * a.ldc + f) = pk;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
+        for (int i = 0; i < (EPI == ESME_EPI_SWIGLU ? 1 : FN); ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi;
-                if (n >= a.N) continue;
-                const bool full = a.vec_ok && n + 3 < a.N;
+                const int cl = i * 32 + 8 * g + 4 * hi;                 // column inside the wave slab
+                const int n = nw0 + cl;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias) {
-                    if (full) {
+                if (EPI != ESME_EPI_SWIGLU && a.bias) {
+                    if (n + 3 < a.N) {
                         const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + n);
                         bv[0] = bf_lo(bw[0]); bv[1] = bf_hi(bw[0]); bv[2] = bf_lo(bw[1]); bv[3] = bf_hi(bw[1]);
                     } else {
@@ -177,32 +169,82 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
-                    const int64_t m = m0 + wm * WTM + j * 32 + l31;
-                    if (m >= a.M) continue;
+                    const int r = j * 32 + l31;
                     float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] + bv[e];
-                    if constexpr (EPI == ESME_EPI_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
-                    }
-                    u16* cp = a.C + m * a.ldc + n;
-                    if (full) {
-                        if constexpr (EPI == ESME_EPI_RESIDUAL) {
-                            const u32x2 rw = *reinterpret_cast<const u32x2*>(a.resid + m * a.ldr + n);
-                            o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
-                            o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
-                        }
-                        u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
-                        *reinterpret_cast<u32x2*>(cp) = pk;
-                    } else {
+                    if constexpr (EPI == ESME_EPI_SWIGLU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (n + e < a.N) {
-                                float v = o[e];
-                                if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
-                                cp[e] = f2bf(v);
+                            const float gate = acc[0][j][4 * g + e], fc = acc[1][j][4 * g + e];
+                            o[e] = gate / (1.0f + __expf(-gate)) * fc;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] + bv[e];
+                        if constexpr (EPI == ESME_EPI_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+                        }
+                        if constexpr (EPI == ESME_EPI_RESIDUAL) {
+                            const int64_t m = mw0 + r;
+                            if (m < a.M && n + 3 < a.N) {
+                                const u32x2 rw = *reinterpret_cast<const u32x2*>(a.resid + m * a.ldr + n);
+                                o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
+                                o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
+                            } else if (m < a.M) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (n + e < a.N) o[e] = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * o[e];
                             }
+                        }
+                    }
+                    u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                    *reinterpret_cast<u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3)) = pk;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int rl = lane / CH, ch = lane % CH;
+        const int n = nw0 + ch * 8;
+        if (n + 7 < n_out) {
+#pragma unroll
+            for (int it = 0; it < WTM / RPI; ++it) {
+                const int r = it * RPI + rl;
+                const int64_t m = mw0 + r;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
+                if (m < a.M) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+            }
+        } else if (n < n_out) {                      // ragged right edge (n_out % 8 != 0): 2-byte stores
+            for (int it = 0; it < WTM / RPI; ++it) {
+                const int r = it * RPI + rl;
+                const int64_t m = mw0 + r;
+                const u16* sp = reinterpret_cast<const u16*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
+                if (m < a.M)
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < n_out) a.C[m * a.ldc + n + e] = sp[e];
+            }
+        }
+        return;
+    }
+
+    // Slow path (C or resid rows not 16-byte addressable, e.g. the (T, 33) vocab logits):
+    // direct 2-byte stores from the accumulator layout.
+    if constexpr (EPI != ESME_EPI_SWIGLU) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nw0 + i * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const int64_t m = mw0 + j * 32 + l31;
+                    if (m >= a.M) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < a.N) {
+                            float v = acc[i][j][4 * g + e] + (a.bias ? bf2f(a.bias[n + e]) : 0.f);
+                            if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
+                            if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
+                            a.C[m * a.ldc + n + e] = f2bf(v);
                         }
                     }
                 }
@@ -264,14 +306,14 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
     ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= n_out, "gemm: bad lda/ldc");
     ESME_CHECK_ARG(aligned16(A) && aligned16(W), "gemm: A and W must be 16-byte aligned");
     ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm: misaligned bias");
-    // 8-byte row-segment stores need ld % 4 == 0 and 8-B aligned bases; otherwise (e.g. the
-    // (T, 33) vocab projection) the epilogue falls back to 2-byte accesses.
-    int vec_ok = (ldc % 4 == 0) && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
+    // The coalesced epilogue stores 16 B per lane: it needs ldc % 8 == 0 and a 16-B aligned C;
+    // otherwise (e.g. the (T, 33) vocab projection) the epilogue falls back to 2-byte accesses.
+    int vec_ok = (ldc % 8 == 0) && aligned16(C);
     if (epilogue == ESME_EPI_RESIDUAL) {
         ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
         vec_ok = vec_ok && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(resid) & 7u) == 0;
     }
-    if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 4 == 0 and an 8-byte aligned C");
+    if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok};
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
