@@ -1,0 +1,182 @@
+"""CPU-side tests (run with -m "not gpu"): the C-ABI library loads and exports every
+symbol include/esme_hip.h declares, host-side logic (tokenizer shapes, synthetic
+checkpoints, packing, loader, API errors, fail-loudly behaviour), and the N>1 sharding
+path on the gloo backend with world_size 2.  No compute is launched on a GPU here."""
+import ctypes
+import os
+import re
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported_and_bound():
+    from esme import _hip
+    header = open(os.path.join(ROOT, 'include', 'esme_hip.h')).read()
+    declared = set(re.findall(r'\b(esme_hip_\w+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    lib = ctypes.CDLL(_hip.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/esme_hip.h but not exported'
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    assert _hip.load().esme_hip_abi_version() == _hip.ABI_VERSION
+    m = re.search(r'#define\s+ESME_HIP_ABI_VERSION\s+(\d+)', header)
+    assert int(m.group(1)) == _hip.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    """Host-side checks of the C entry points reject bad arguments before any launch."""
+    from esme import _hip
+    lib = _hip.load()
+    assert lib.esme_hip_gemm_bf16(None, 64, None, None, None, 0, None, 64, 8, 64, 64, 0, 1.0, None) == -1
+    assert b'null' in lib.esme_hip_last_error()
+    assert lib.esme_hip_gemm_bf16(16, 100, 16, None, None, 0, 16, 64, 8, 64, 100, 0, 1.0, None) == -2
+    assert b'multiple of 64' in lib.esme_hip_last_error()
+    assert lib.esme_hip_gemm_bf16(16, 64, 16, None, None, 0, 16, 64, 8, 64, 64, 9, 1.0, None) == -1
+    assert lib.esme_hip_attn_varlen_fwd(16, 16, 16, 64, 16, 64, 16, 1, 8, 1, 24, 8, 0.2, None) == -2
+    assert b'head dim' in lib.esme_hip_last_error()
+    assert lib.esme_hip_layernorm(16, 8, 16, None, 16, 8, 4, 12, 1e-5, None) == -1      # E % 8 != 0
+    assert lib.esme_hip_rotary_varlen(16, 16, 64, 16, 16, 16, 4, 2, 24, 8, None) == -2   # d % 16 != 0
+    assert lib.esme_hip_gemm_bf16(None, 0, None, None, None, 0, None, 0, 0, 64, 64, 0, 1.0, None) == 0   # M = 0: no-op
+
+
+def test_no_cpu_fallback_and_missing_library(monkeypatch):
+    from esme import _hip, ESM2
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _hip.layernorm(x, torch.ones(64, dtype=torch.bfloat16))
+    model = ESM2(num_layers=1, embed_dim=64, attention_heads=4)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(5, dtype=torch.int64), (torch.tensor([0, 5], dtype=torch.int32), 5))
+    monkeypatch.setattr(_hip, '_lib', None)
+    monkeypatch.setattr(_hip, '_LIB_PATH', '/nonexistent/libesme_hip.so')
+    with pytest.raises(_hip.HipLibraryError, match='no CPU/torch fallback'):
+        _hip.load()
+
+
+def test_checkpoint_roundtrip_and_dispatch():
+    from esme import ESM, ESM2, ESMC, synthetic as syn
+    with tempfile.TemporaryDirectory() as td:
+        p = syn.write_checkpoint(os.path.join(td, 'a.safetensors'), 'esm2_tiny', 2, 64, 4, seed=3)
+        m = ESM.from_pretrained(p)
+        assert isinstance(m, ESM2) and not isinstance(m, ESMC)
+        sd, ref = m.state_dict(), syn.synthetic_state_dict('esm2', 2, 64, 3)
+        assert list(sd) == list(ref) or set(sd) == set(ref)
+        assert all(torch.equal(sd[k], ref[k]) for k in ref)
+        assert all(v.dtype == torch.bfloat16 for v in sd.values())
+        p = syn.write_checkpoint(os.path.join(td, 'c.safetensors'), 'esmc_tiny', 2, 128, 2, seed=4)
+        m = ESM.from_pretrained(p)
+        assert isinstance(m, ESMC) and m.lm_head.final.weight.shape == (64, 128)
+        assert m.layers[0].residue_scaling == pytest.approx((2 / 36) ** 0.5)
+        assert m.layers[0].final[1].activation.weight.shape == (512, 128)       # 8/3*128 -> 512
+        with pytest.raises(AssertionError):
+            ESM2.from_pretrained(p)                       # esmc weights into an ESM2
+        with pytest.raises(AssertionError):
+            ESM2.from_pretrained(p, quantization='2bit')
+        with pytest.raises(AssertionError):
+            ESM.from_pretrained(os.path.join(td, 'a.safetensors'), quantization='4bit', device='cpu')
+    with pytest.raises(ValueError):
+        ESM.from_pretrained('esm2_8m')                    # hub names need a download: out of scope
+
+
+def test_qkv_packing_keeps_state_dict():
+    from esme import ESM2
+    torch.manual_seed(0)
+    m = ESM2(num_layers=1, embed_dim=64, attention_heads=4)
+    att = m.layers[0].self_attn
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    att._pack()
+    after = m.state_dict()
+    assert set(before) == set(after) and all(torch.equal(before[k], after[k]) for k in before)
+    assert att._qkv_w.shape == (192, 64) and att.q.weight.data_ptr() == att._qkv_w.data_ptr()
+    assert att.k.weight.data_ptr() == att._qkv_w[64:].data_ptr()
+    key = att._pack_key
+    att._pack()
+    assert att._pack_key == key                            # idempotent
+
+
+def test_synthetic_batches_and_flops():
+    from esme import synthetic as syn
+    tok, cu, ml, lens = syn.uniform_batch(50000, 500, seed=0)
+    assert tok.numel() == 50000 and len(lens) == 100 and ml == 500 and cu[-1] == 50000
+    assert int(tok[0]) == 0 and int(tok[499]) == 2 and tok[1:499].min() >= 4 and tok.max() <= 23
+    lens = syn.proteome_lengths(50000, seed=0)
+    assert sum(lens) == 50000 and min(lens) >= 3 and max(lens) <= 3502
+    assert lens == syn.proteome_lengths(50000, seed=0)
+    f = syn.algorithmic_flops('esm2', 33, 1280, [500] * 100)
+    assert abs(f / 50000 / 1e6 - 1385.45) < 0.01           # 1 385.45 MFLOP / residue
+    assert syn.swiglu_width(1152) == 3072 and syn.swiglu_width(960) == 2560
+
+
+def test_partition_is_balanced_and_complete():
+    from esme import shard, synthetic as syn
+    lens = syn.proteome_lengths(50000, seed=3)
+    for world in (1, 2, 3, 8):
+        plan = shard.partition_sequences(lens, world)
+        assert sorted(i for p in plan for i in p) == list(range(len(lens)))
+        loads = [sum(lens[i] for i in p) for p in plan]
+        assert max(loads) - min(loads) <= max(lens)
+    assert shard.partition_sequences([5, 5], 4) == [[0], [1], [], []]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, lengths, out_path):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'esm-efficient_amd'))
+    from esme import shard, synthetic as syn
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    table = torch.arange(33 * 8, dtype=torch.float32).view(33, 8).to(torch.bfloat16)
+
+    def fake_forward(tok, pad_args):
+        cu_r, max_len = pad_args
+        assert tok.numel() == int(cu_r[-1]) and max_len == int((cu_r[1:] - cu_r[:-1]).max())
+        pos = torch.arange(tok.numel()) - torch.repeat_interleave(cu_r[:-1].long(), (cu_r[1:] - cu_r[:-1]).long())
+        out = table[tok].clone()
+        out[:, 0] = pos.to(torch.bfloat16)             # position inside its own sequence
+        return out
+
+    full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu')
+    if rank == 0:
+        torch.save(full, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('lengths', [[7, 3, 12, 5, 9], [4], [6, 6, 6]])
+def test_sharded_forward_gloo_world2(lengths):
+    """N>1 path on CPU: 2 ranks, gloo.  The gathered result must equal the single-rank
+    result in input order (rows carry their token id and in-sequence position)."""
+    from esme import synthetic as syn
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'full.pt')
+        mp.spawn(_worker, args=(2, _free_port(), lengths, out), nprocs=2, join=True)
+        full = torch.load(out)
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    table = torch.arange(33 * 8, dtype=torch.float32).view(33, 8).to(torch.bfloat16)
+    ref = table[tokens].clone()
+    pos = torch.arange(tokens.numel()) - torch.repeat_interleave(cu[:-1].long(), (cu[1:] - cu[:-1]).long())
+    ref[:, 0] = pos.to(torch.bfloat16)
+    assert torch.equal(full, ref)
+
+
+def test_feedforward_head_module():
+    from esme.layer import FeedForward
+    ff = FeedForward(16, 32)
+    assert ff(torch.randn(5, 16)).shape == (5, 1)
+    assert [n for n, _ in ff.named_parameters()] == ['linear1.weight', 'linear1.bias', 'linear2.weight', 'linear2.bias']
