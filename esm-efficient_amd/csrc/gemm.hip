@@ -31,15 +31,20 @@ struct GemmArgs {
     float alpha;
     int tiles_n;
     int vec_ok;                  // C rows allow 16-byte stores (ldc % 8 == 0, 16-B aligned) and resid rows 8-byte loads
+    // fused rotary (QKV projection): columns < rot_cols are rotated with position pos[m]
+    const u16* cosT; const u16* sinT; const int32_t* pos; int max_len; int rot_cols;
 };
 
 static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
+constexpr bool WTN_OK(int bn, int wn) { return bn / wn == 64; }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+    static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
+                  "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
     constexpr int NW = WM * WN;               // waves per block
     constexpr int NT = NW * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -149,6 +154,53 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int nw0 = (EPI == ESME_EPI_SWIGLU) ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN);   // first output column of the wave
     const int64_t mw0 = m0 + wm * WTM;
 
+    // ---- fused rotary (QKV projection, head dim ROTD | 64): a head never straddles a wave's
+    // 64 output columns and column c pairs with c + ROTD/2, a multiple of 8 away -- i.e. the
+    // SAME lane, another accumulator quad.  Bias is added first, then q/k columns are rotated
+    // in the accumulators (fp32, bf16 tables), so rotary costs no HBM pass of its own.
+    if constexpr (ROTD > 0) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (!a.bias) continue;
+                const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + nw0 + i * 32 + 8 * g + 4 * hi);
+                const float b0 = bf_lo(bw[0]), b1 = bf_hi(bw[0]), b2 = bf_lo(bw[1]), b3 = bf_hi(bw[1]);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    acc[i][j][4 * g] += b0; acc[i][j][4 * g + 1] += b1; acc[i][j][4 * g + 2] += b2; acc[i][j][4 * g + 3] += b3;
+                }
+            }
+        if (nw0 < a.rot_cols) {                               // wave-uniform: whole heads of q or k
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                int64_t m = mw0 + j * 32 + l31;
+                m = m < a.M ? m : a.M - 1;
+                int p = a.pos[m];
+                p = p < a.max_len ? p : a.max_len - 1;
+                const u16* ct = a.cosT + (int64_t)p * ROTD + 4 * hi;
+                const u16* st = a.sinT + (int64_t)p * ROTD + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {                 // q = quad index i*4+g over the 64 columns
+                    constexpr int HALF = ROTD / 2;
+                    const int c0 = q * 8;                     // first column of the quad pair (per hi: +4)
+                    if ((c0 % ROTD) >= HALF) continue;        // upper half of a head: handled with its partner
+                    const int q2 = (c0 + HALF) / 8;           // partner quad
+                    const u32x2 cw = *reinterpret_cast<const u32x2*>(ct + (c0 % ROTD));
+                    const u32x2 sw = *reinterpret_cast<const u32x2*>(st + (c0 % ROTD));
+                    const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
+                    const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = acc[q >> 2][j][4 * (q & 3) + e], up = acc[q2 >> 2][j][4 * (q2 & 3) + e];
+                        acc[q >> 2][j][4 * (q & 3) + e] = lo * cv[e] - up * sv[e];
+                        acc[q2 >> 2][j][4 * (q2 & 3) + e] = up * cv[e] + lo * sv[e];
+                    }
+                }
+            }
+        }
+    }
+
     if (a.vec_ok) {
 #pragma unroll
         for (int i = 0; i < (EPI == ESME_EPI_SWIGLU ? 1 : FN); ++i) {
@@ -157,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int cl = i * 32 + 8 * g + 4 * hi;                 // column inside the wave slab
                 const int n = nw0 + cl;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (EPI != ESME_EPI_SWIGLU && a.bias) {
+                if (EPI != ESME_EPI_SWIGLU && ROTD == 0 && a.bias) {
                     if (n + 3 < a.N) {
                         const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + n);
                         bv[0] = bf_lo(bw[0]); bv[1] = bf_hi(bw[0]); bv[2] = bf_lo(bw[1]); bv[3] = bf_hi(bw[1]);
@@ -241,7 +293,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (n + e < a.N) {
-                            float v = acc[i][j][4 * g + e] + (a.bias ? bf2f(a.bias[n + e]) : 0.f);
+                            float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0) ? bf2f(a.bias[n + e]) : 0.f);
                             if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
                             if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
                             a.C[m * a.ldc + n + e] = f2bf(v);
@@ -251,6 +303,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int ROTD>
+static int launch_gemm_rot(GemmArgs& a, hipStream_t s) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    const int64_t blocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, ESME_EPI_NONE, ROTD>;
+    if (smem > 64 * 1024) {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); once = true; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(WM * WN * 64), smem, s, a);
+    return check_launch("gemm_qkv_rotary");
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -314,7 +381,8 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
         vec_ok = vec_ok && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(resid) & 7u) == 0;
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
-    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok};
+    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
+               nullptr, nullptr, nullptr, 0, 0};
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
     if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
@@ -325,4 +393,36 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
         case 3: return launch_gemm<256, 256, 2, 4>(a, epilogue, s);
         default: ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
     }
+}
+
+extern "C" int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const void* bias, void* C,
+                                        int64_t ldc, int64_t M, int N, int K, const void* cosT, const void* sinT,
+                                        const int32_t* pos, int head_dim, int max_len, int rot_cols, void* stream) {
+    ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0 && max_len > 0, "gemm_qkv_rotary: bad sizes");
+    if (M == 0) return ESME_OK;
+    ESME_CHECK_ARG(A && W && C && cosT && sinT && pos, "gemm_qkv_rotary: null pointer");
+    if (K % BK != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: K must be a multiple of 64");
+    if (head_dim != 16 && head_dim != 32 && head_dim != 64)
+        ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: head dim must be 16, 32 or 64 (use esme_hip_rotary_varlen otherwise)");
+    if (N % 64 != 0 || rot_cols % 64 != 0 || rot_cols < 0 || rot_cols > N)
+        ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: N and rot_cols must be multiples of 64, rot_cols <= N");
+    ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm_qkv_rotary: bad lda/ldc");
+    ESME_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(cosT) && aligned16(sinT),
+                   "gemm_qkv_rotary: misaligned pointer");
+    ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm_qkv_rotary: misaligned bias");
+    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, nullptr, 0, (u16*)C, ldc, M, N, K, 1.0f, 0, 1,
+               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols};
+    const hipStream_t s = (hipStream_t)stream;
+    int tile = g_force_tile;
+    if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
+#define ESME_ROT(D)                                                      \
+    case D:                                                               \
+        return tile == 1 ? launch_gemm_rot<128, 128, 2, 2, D>(a, s) : launch_gemm_rot<256, 256, 2, 4, D>(a, s);
+    switch (head_dim) {
+        ESME_ROT(16)
+        ESME_ROT(32)
+        ESME_ROT(64)
+    }
+#undef ESME_ROT
+    return ESME_ERR_UNSUPPORTED;
 }

@@ -34,6 +34,8 @@ SIGNATURES = {
                                          c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_gemm_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_gemm_qkv_rotary': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
@@ -224,6 +226,27 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _check(load().esme_hip_gemm_bf16(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
                                          _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
                                          rp, ldr, cp, ldc, M, N, K, epilogue, alpha, _stream()), 'esme_hip_gemm_bf16')
+    return out
+
+
+def gemm_qkv_rotary(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], cos: torch.Tensor,
+                    sin: torch.Tensor, pos: torch.Tensor, head_dim: int, rot_cols: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a @ w.T + bias with rotary applied to the heads in columns [0, rot_cols)
+    inside the GEMM epilogue (fused QKV projection; head_dim in {16, 32, 64})."""
+    ap, lda = _rows2d(a, 'gemm_qkv_rotary a')
+    if not w.is_contiguous():
+        raise ValueError('gemm_qkv_rotary: weight must be contiguous (N, K)')
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    cp, ldc = _rows2d(out, 'gemm_qkv_rotary out')
+    with _Traced('gemm', (M, N, K, 'qkv_rotary')):
+        _check(load().esme_hip_gemm_qkv_rotary(
+            ap, lda, _dev(w, 'w', torch.bfloat16), _dev(bias, 'bias', torch.bfloat16) if bias is not None else None,
+            cp, ldc, M, N, K, _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16),
+            _dev(pos, 'pos', torch.int32), head_dim, cos.shape[0], rot_cols, _stream()), 'esme_hip_gemm_qkv_rotary')
     return out
 
 

@@ -113,13 +113,23 @@ class FlashMultiheadAttention(nn.Module):
                 resid=None, alpha: float = 1.0, out=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
         resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid)."""
-        q, k, v = self._qkv(x, lora_names)
-        if self.rot_emb is not None:
-            if ctx is not None:
-                T, E = x.shape
-                _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, self.num_heads)
-            else:
-                q, k = self.rot_emb(q, k, cu_lens, max_len)
+        T, E = x.shape
+        fuse = (self.rot_emb is not None and ctx is not None and not self.pre_layernorm
+                and self.head_dim in (16, 32, 64) and E % 32 == 0)
+        if fuse:
+            # LN -> ONE GEMM that also adds the bias and rotates the q/k heads in its epilogue
+            assert lora_names is None, 'LoRA adapters are outside the inference hot path'
+            self._pack()
+            qkv = _hip.gemm_qkv_rotary(self.norm(x), self._qkv_w, self._qkv_b, ctx.cos, ctx.sin, ctx.pos,
+                                       self.head_dim, 2 * E)
+            q, k, v = (qkv[:, i * E:(i + 1) * E].view(T, self.num_heads, self.head_dim) for i in range(3))
+        else:
+            q, k, v = self._qkv(x, lora_names)
+            if self.rot_emb is not None:
+                if ctx is not None:
+                    _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, self.num_heads)
+                else:
+                    q, k = self.rot_emb(q, k, cu_lens, max_len)
         a = self._attn(q, k, v, cu_lens, max_len)
         if resid is not None:
             return self.out(a, _hip.EPI_RESIDUAL, resid, alpha, out)

@@ -100,6 +100,17 @@ int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bi
                        const void* resid, int64_t ldr, void* C, int64_t ldc, int64_t M, int N,
                        int K, int epilogue, float alpha, void* stream);
 
+/* Fused QKV projection + rotary: C (M, N) = A (M, K) @ W (N, K)^T + bias, then every head in
+ * columns [0, rot_cols) (the q and k column blocks of a fused (T, 3E) projection) is rotated
+ * with position pos[m] exactly as esme_hip_rotary_varlen does -- in the GEMM epilogue, so
+ * rotary costs no HBM pass.  head_dim in {16, 32, 64}; N and rot_cols multiples of 64.
+ * Replaces: q/k/v nn.Linear (esme/attention.py:76-78,94-102) followed by
+ * RotaryEmbedding.forward (esme/rotary.py:151-165) for models without q/k LayerNorm. */
+int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const void* bias, void* C,
+                             int64_t ldc, int64_t M, int N, int K, const void* cos,
+                             const void* sin, const int32_t* pos, int head_dim, int max_len,
+                             int rot_cols, void* stream);
+
 /* y = softmax(x) or log_softmax(x) over the last dim V <= 64 (fp32 inside, bf16 out).
  * Replaces: torch.log_softmax / torch.softmax at esme/esm.py:297-298,315-317. */
 int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t T, int V,

@@ -178,6 +178,33 @@ def test_gemm_epilogues(tile):
         _hip.load().esme_hip_debug_set_gemm_tile(0)
 
 
+@pytest.mark.parametrize('lengths,H,d', [([60, 40, 180], 4, 32), ([5, 26, 61], 20, 16), ([37, 70, 193], 20, 64),
+                                         ([300, 211], 10, 64)])
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_qkv_rotary_fused(lengths, H, d, tile):
+    """Fused QKV GEMM + rotary epilogue == plain GEMM followed by the rotary kernel's math."""
+    from esme import _hip
+    T, E = sum(lengths), H * d
+    K = E
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    a, w, b = rnd((T, K), 50), rnd((3 * E, K), 51, 1 / math.sqrt(K)), rnd((3 * E,), 52, 0.1)
+    cos, sin = O.rotary_tables(max(lengths), d, torch.bfloat16)
+    pos = O.culen_positions(cu)
+    lin = a.float() @ w.float().T + b.float()
+    ref = lin.clone()
+    for blk in range(2):
+        x = lin[:, blk * E:(blk + 1) * E].view(T, H, d)
+        ref[:, blk * E:(blk + 1) * E] = O.apply_rotary(x, cos.float(), sin.float(), pos).view(T, E)
+    _hip.load().esme_hip_debug_set_gemm_tile(tile)
+    try:
+        p, _ = _hip.seq_positions(cu.to(dev()), T)
+        got = _hip.gemm_qkv_rotary(a.to(dev()), w.to(dev()), b.to(dev()), cos.to(dev()), sin.to(dev()), p, d, 2 * E)
+    finally:
+        _hip.load().esme_hip_debug_set_gemm_tile(0)
+    check(got[:, :2 * E], ref[:, :2 * E], what='fused rotary q,k')
+    check(got[:, 2 * E:], ref[:, 2 * E:], what='fused rotary v (untouched)')
+
+
 def _attn_case(lengths, H, d, seed, qscale=1.0, spike=False):
     from esme import _hip
     T, E = sum(lengths), H * d
