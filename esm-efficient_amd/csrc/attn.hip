@@ -14,10 +14,13 @@
 // 8 scores a lane holds per 16-key step are 8 CONSECUTIVE keys, i.e. exactly the B-operand
 // layout of the second MFMA, with V^T read as one ds_read_b128 per fragment.
 //
-// LDS: K tile [64 keys][D] (16-B chunks XOR-swizzled against the row index, conflict-free
-// for the 32-row fragment reads) and V^T tile [D][64 keys] (each thread transposes a 4x4
-// bf16 block in registers while staging).  Global loads for tile t+1 are issued before the
-// MFMAs of tile t (register-staged, written to LDS after the barrier).
+// LDS (double-buffered, one barrier per tile): K tile [64 keys][D] (16-B chunks XOR-swizzled
+// against the row index, conflict-free for the 32-row fragment reads) and V^T tile [D][64 keys]
+// (each thread transposes a 4x4 bf16 block in registers while staging; the lane->block map
+// makes the 8-byte transposed writes conflict-free too).  Global loads for tile t+2 are issued
+// while tile t+1 is written to LDS and tile t is in the MFMAs.  Online softmax uses exp2 with
+// the scale folded in and a defer-max threshold (rescale O only when a row max grew by more
+// than 2^8), so the common tile does no O-wide VALU pass.
 #include "common.h"
 #include "launch.h"
 
@@ -49,13 +52,14 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(const AttnArgs a) {
     constexpr int CPR = D / 8;                   // 16-B chunks per K row
     constexpr int KCH = KT * CPR;                // chunks in a K tile
     constexpr int KI = (KCH + 255) / 256;        // K chunks per thread
-    constexpr int VB = (KT / 4) * (D / 4);       // 4x4 blocks in a V tile
-    constexpr int VI = (VB + 255) / 256;
+    constexpr int DQ = D / 4;                    // 4-wide column groups of V
+    constexpr int DQ_HI_BITS = (D == 16 ? 0 : D == 32 ? 1 : D == 64 ? 2 : 3);
+    constexpr int VI = (16 * DQ + 255) / 256;    // 4x4 V blocks per thread
     constexpr int K_BYTES = KT * D * 2;
+    constexpr int BUF = K_BYTES + D * 128;       // one K tile + one V^T tile
+    constexpr float THR = 8.0f;                  // defer-max threshold (log2 units)
 
-    __shared__ __attribute__((aligned(16))) char smem[K_BYTES + D * 128];
-    char* const Ks = smem;
-    char* const Vt = smem + K_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -64,83 +68,98 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(const AttnArgs a) {
     const int q0 = blockIdx.x * QT;
     if (q0 >= S) return;
 
-    const int64_t ld = a.ld;
-    const u16* qb = a.q + (int64_t)s0 * ld + h * D;
-    const u16* kb = a.k + (int64_t)s0 * ld + h * D;
-    const u16* vb = a.v + (int64_t)s0 * ld + h * D;
+    const unsigned int ld = (unsigned int)a.ld;
+    const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
+    const u16* kb = a.k + (int64_t)s0 * a.ld + h * D;
+    const u16* vb = a.v + (int64_t)s0 * a.ld + h * D;
 
     // ---- Q fragments (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 .. +7]
     const int qrow = q0 + wave * 32 + l31;
     const bool wave_active = (q0 + wave * 32) < S;       // wave-uniform
-    const int qrow_c = qrow < S ? qrow : S - 1;
+    const unsigned int qrow_c = qrow < S ? qrow : S - 1;
     bf16x8 qf[DS];
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds)
-        qf[ds] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qrow_c * ld + ds * 16 + hi * 8);
+        qf[ds] = *reinterpret_cast<const bf16x8*>(qb + (qrow_c * ld + ds * 16 + hi * 8));
 
-    // ---- staging assignments
+    // ---- staging assignments.  K: chunk c -> (row c / CPR, chunk c % CPR).
+    // V: each thread owns 4x4 (key x d) blocks; lane bits are laid out so that the 16
+    // lanes of a ds_write_b64 group cover 4 column groups x 4 key groups = 16 distinct
+    // 8-byte positions of the swizzled 128-B V^T rows (conflict-free), while a wave's
+    // global load still reads whole 128-B lines.
+    unsigned int koff[KI];
+    int krow[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+        const int c = i * 256 + tid;
+        krow[i] = c / CPR;
+        koff[i] = (unsigned int)(c % CPR) * 8u;
+    }
+    int v_dq[VI], v_kq[VI];
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int rest = (lane >> 4) | (wave << 2) | (i << 4);
+        v_dq[i] = (lane & 3) | ((rest & ((1 << DQ_HI_BITS) - 1)) << 2);
+        v_kq[i] = ((lane >> 2) & 3) | ((rest >> DQ_HI_BITS) << 2);
+    }
     u32x4 kreg[KI];
     u32x2 vreg[VI][4];
     auto load_tile = [&](int kv0) {
+        const bool full = kv0 + KT <= S;
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
-            const int c = i * 256 + tid;
-            if (KCH >= 256 || c < KCH) {
-                int row = kv0 + c / CPR;
-                row = row < S ? row : S - 1;
-                kreg[i] = *reinterpret_cast<const u32x4*>(kb + (int64_t)row * ld + (c % CPR) * 8);
+            if (KCH >= 256 * KI || krow[i] < KT) {
+                unsigned int row = kv0 + krow[i];
+                if (!full) row = row < (unsigned int)S ? row : S - 1;
+                kreg[i] = *reinterpret_cast<const u32x4*>(kb + (row * ld + koff[i]));
             }
         }
 #pragma unroll
         for (int i = 0; i < VI; ++i) {
-            const int blk = i * 256 + tid;
-            if (VB >= 256 || blk < VB) {
-                const int dq = blk % (D / 4), kq = blk / (D / 4);
+            if (v_kq[i] < 16) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    int row = kv0 + kq * 4 + kk;
-                    row = row < S ? row : S - 1;
-                    vreg[i][kk] = *reinterpret_cast<const u32x2*>(vb + (int64_t)row * ld + dq * 4);
+                    unsigned int row = kv0 + v_kq[i] * 4 + kk;
+                    if (!full) row = row < (unsigned int)S ? row : S - 1;
+                    vreg[i][kk] = *reinterpret_cast<const u32x2*>(vb + (row * ld + v_dq[i] * 4));
                 }
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](char* Ks, char* Vt) {
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
-            const int c = i * 256 + tid;
-            if (KCH >= 256 || c < KCH) {
-                const int row = c / CPR, ch = c % CPR;
+            if (KCH >= 256 * KI || krow[i] < KT) {
+                const int row = krow[i], ch = (int)(koff[i] >> 3);
                 *reinterpret_cast<u32x4*>(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4)) = kreg[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < VI; ++i) {
-            const int blk = i * 256 + tid;
-            if (VB >= 256 || blk < VB) {
-                const int dq = blk % (D / 4), kq = blk / (D / 4);
+            if (v_kq[i] < 16) {
+                const int dq = v_dq[i], kq = v_kq[i];
                 // 4x4 transpose of 16-bit elements: in[kk] = {d0d1, d2d3} of key kk
 #pragma unroll
                 for (int dd = 0; dd < 4; ++dd) {
                     const int w = dd >> 1;
-                    unsigned int e0, e1, e2, e3;
+                    unsigned int e0, e1;
                     if (dd & 1) {
-                        e0 = vreg[i][0][w] >> 16; e1 = vreg[i][1][w] & 0xffff0000u;
-                        e2 = vreg[i][2][w] >> 16; e3 = vreg[i][3][w] & 0xffff0000u;
+                        e0 = __builtin_amdgcn_perm(vreg[i][1][w], vreg[i][0][w], 0x07060302u);
+                        e1 = __builtin_amdgcn_perm(vreg[i][3][w], vreg[i][2][w], 0x07060302u);
                     } else {
-                        e0 = vreg[i][0][w] & 0xffffu; e1 = vreg[i][1][w] << 16;
-                        e2 = vreg[i][2][w] & 0xffffu; e3 = vreg[i][3][w] << 16;
+                        e0 = __builtin_amdgcn_perm(vreg[i][1][w], vreg[i][0][w], 0x05040100u);
+                        e1 = __builtin_amdgcn_perm(vreg[i][3][w], vreg[i][2][w], 0x05040100u);
                     }
                     const int drow = dq * 4 + dd;
                     const int ch = kq >> 1;                         // 16-B chunk (8 keys) of the V^T row
-                    u32x2 out = {e0 | e1, e2 | e3};
+                    u32x2 out = {e0, e1};
                     *reinterpret_cast<u32x2*>(Vt + drow * 128 + ((ch ^ ((drow >> 1) & 7)) << 4) + (kq & 1) * 8) = out;
                 }
             }
         }
     };
 
-    // K row fed to MFMA row i of key block kbk: bits 2 and 3 of i swapped
+    // K row fed to MFMA row i of a key block: bits 2 and 3 of i swapped
     const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
 
     f32x16 oacc[DB];
@@ -148,88 +167,105 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(const AttnArgs a) {
     for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
     const float c = a.scale_log2;
+    float mc = -1e30f;                 // running max, already multiplied by c (log2 units)
+    float l_run = 0.f;
 
     const int ntiles = (S + KT - 1) / KT;
     load_tile(0);
+    store_tile(smem, smem + K_BYTES);
+    if (ntiles > 1) load_tile(KT);
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
-        __syncthreads();                      // all waves done reading the previous tile
-        store_tile();
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(kv0 + KT);
-        if (!wave_active) continue;
-
-        // ---- S^T = K . Q^T for two 32-key blocks
-        f32x16 sacc[2];
+        const char* Ks = smem + (t & 1) * BUF;
+        const char* Vt = Ks + K_BYTES;
+        if (wave_active) {
+            // ---- S^T = K . Q^T for two 32-key blocks
+            f32x16 sacc[2];
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
+            for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
-            const int row = kbk * 32 + krow_perm;
-            const char* rp = Ks + row * (D * 2);
-            const int sw = kswz<D>(row);
+                for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
+                const int row = kbk * 32 + krow_perm;
+                const char* rp = Ks + row * (D * 2);
+                const int sw = kswz<D>(row);
 #pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
-                sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[kbk], 0, 0, 0);
-            }
-        }
-        // register r of block kbk holds key kv0 + kbk*32 + 16*(r>>3) + 8*hi + (r&7)
-        const bool tail = kv0 + KT > S;
-        float tmax = -1e30f;
-#pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (tail) {
-                    const int key = kv0 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= S) sacc[kbk][r] = -1e30f;
+                for (int ds = 0; ds < DS; ++ds) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
+                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[kbk], 0, 0, 0);
                 }
-                tmax = fmaxf(tmax, sacc[kbk][r]);
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pf[2][2];
+            // register r of block kbk holds key kv0 + kbk*32 + 16*(r>>3) + 8*hi + (r&7)
+            if (kv0 + KT > S) {
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
+                for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float p[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p[j] = exp2f(fmaf(sacc[kbk][8 * s + j], c, -mc));
-                    psum += p[j];
-                }
-                u32x4 pk = pack8(p);
-                pf[kbk][s] = __builtin_bit_cast(bf16x8, pk);
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) >= S) sacc[kbk][r] = -1e30f;
             }
-        l_run = l_run * alpha + psum;
+            float tmax = sacc[0][0];
 #pragma unroll
-        for (int i = 0; i < DB; ++i)
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[0][r]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-
-        // ---- O^T += V^T . P^T
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[1][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float tmc = tmax * c;
+            // defer-max: rescale only when some row's max grew by more than THR (in log2 units);
+            // otherwise keep the old reference max -- P is then bounded by 2^THR, which fp32 sums
+            // and the bf16 P (same relative precision at any scale) absorb.  Wave-uniform branch.
+            if (__any(tmc > mc + THR)) {
+                const float mn = fmaxf(mc, tmc);
+                const float alpha = __builtin_amdgcn_exp2f(mc - mn);
+                mc = mn;
+                l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < DB; ++i) {
-            int drow = i * 32 + l31;
-            if (D < 32) drow &= (D - 1);          // D = 16: upper lanes re-read valid rows, results discarded
-            const char* rp = Vt + drow * 128;
-            const int sw = (drow >> 1) & 7;
+                for (int i = 0; i < DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+            float psum = 0.f;
+            bf16x8 pf[2][2];
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
-                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kbk][s], oacc[i], 0, 0, 0);
+                    float p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p[j] = __builtin_amdgcn_exp2f(fmaf(sacc[kbk][8 * s + j], c, -mc));
+                        psum += p[j];
+                    }
+                    u32x4 pk = pack8(p);
+                    pf[kbk][s] = __builtin_bit_cast(bf16x8, pk);
                 }
+            l_run += psum;
+
+            // ---- O^T += V^T . P^T
+#pragma unroll
+            for (int i = 0; i < DB; ++i) {
+                int drow = i * 32 + l31;
+                if (D < 32) drow &= (D - 1);          // D = 16: upper lanes re-read valid rows, results discarded
+                const char* rp = Vt + drow * 128;
+                const int sw = (drow >> 1) & 7;
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
+                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kbk][s], oacc[i], 0, 0, 0);
+                    }
+            }
         }
+        // stage tile t+1 (loaded into registers while tile t was computed) into the other buffer;
+        // that buffer was last read for tile t-1, which every wave finished before the barrier
+        // that ended iteration t-1.
+        if (t + 1 < ntiles) {
+            char* Kn = smem + ((t + 1) & 1) * BUF;
+            store_tile(Kn, Kn + K_BYTES);
+            if (t + 2 < ntiles) load_tile(kv0 + 2 * KT);
+        }
+        __syncthreads();
     }
 
     if (!wave_active) return;
