@@ -33,6 +33,9 @@ struct GemmArgs {
     int vec_ok;                  // C rows allow 16-byte stores (ldc % 8 == 0, 16-B aligned) and resid rows 8-byte loads
     // fused rotary (QKV projection): columns < rot_cols are rotated with position pos[m]
     const u16* cosT; const u16* sinT; const int32_t* pos; int max_len; int rot_cols;
+    // tile rasterisation: bands of gm tile-rows, inside a band groups of gn tile-columns walked
+    // column-major (gm = 1, gn = tiles_n is plain row-major)
+    int tiles_m, gm, gn;
 };
 
 static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
@@ -63,9 +66,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
+    // XCD-aware, L2-friendly tile order: each XCD (own 4 MB L2) walks a contiguous range of ids;
+    // ids sweep gm x gn groups of tiles so the ~32 workgroups resident on an XCD share gm
+    // activation slabs and gn weight slabs instead of 1-2 and all of them.
     const unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = pid % a.tiles_n;
-    const int64_t tile_m = pid / a.tiles_n;
+    const int per_band = a.gm * a.tiles_n;
+    const int band = pid / per_band, lb = pid - band * per_band;
+    const int rows = min(a.gm, a.tiles_m - band * a.gm);
+    const int grp = rows * a.gn;
+    const int ng = lb / grp, rg = lb - ng * grp;
+    const int tile_n = ng * a.gn + rg / rows;
+    const int64_t tile_m = (int64_t)band * a.gm + rg % rows;
     const int64_t m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -305,11 +316,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     }
 }
 
+static int g_raster_gm = 0, g_raster_gn = 0;      // test/tuning hook (0 = heuristic)
+
+// Choose the tile walk.  If the whole weight matrix fits an XCD's L2 (4 MB) next to the
+// streaming activations, plain row-major order is already optimal (W stays resident, every
+// activation slab is fetched once).  Otherwise walk 8 x 4 groups (1 workgroup/CU, 32 CUs per
+// XCD): per group the XCD fetches 8 activation + 4 weight slabs instead of ~2 + all.
+template <int BM, int BN>
+static void set_raster(GemmArgs& a) {
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.tiles_m = (int)((a.M + BM - 1) / BM);
+    const double w_bytes = 2.0 * a.N * a.K;
+    if (g_raster_gm > 0) { a.gm = g_raster_gm; a.gn = g_raster_gn > 0 ? g_raster_gn : a.tiles_n; }
+    else if (w_bytes <= 3.5e6 || a.tiles_n <= 6) { a.gm = 1; a.gn = a.tiles_n; }   // few columns: a row-major
+                                                                                     // wavefront is already a g x tiles_n group
+    else { a.gm = 8; a.gn = 4; }
+    if (a.gn > a.tiles_n) a.gn = a.tiles_n;
+    if (a.gm > a.tiles_m) a.gm = a.tiles_m;
+    if (a.gm < 1) a.gm = 1;
+    if (a.gn < 1) a.gn = 1;
+}
+
 template <int BM, int BN, int WM, int WN, int ROTD>
 static int launch_gemm_rot(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    a.tiles_n = (a.N + BN - 1) / BN;
-    const int64_t blocks = ((a.M + BM - 1) / BM) * a.tiles_n;
+    set_raster<BM, BN>(a);
+    const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, ESME_EPI_NONE, ROTD>;
     if (smem > 64 * 1024) {
@@ -323,9 +355,8 @@ static int launch_gemm_rot(GemmArgs& a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(GemmArgs& a, int epi, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    a.tiles_n = (a.N + BN - 1) / BN;
-    const int64_t tiles_m = (a.M + BM - 1) / BM;
-    const int64_t blocks = tiles_m * a.tiles_n;
+    set_raster<BM, BN>(a);
+    const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
     const dim3 grid((unsigned int)blocks), block(WM * WN * 64);
 #define ESME_GEMM_CASE(E)                                                                         \
@@ -359,6 +390,7 @@ using namespace esme;
 // test hook: force a tile configuration (0 = heuristic).  Not part of the documented ABI.
 static int g_force_tile = 0;
 extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
+extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
 
 extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
                                   int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
@@ -382,7 +414,7 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
-               nullptr, nullptr, nullptr, 0, 0};
+               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1};
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
     if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
@@ -411,7 +443,7 @@ extern "C" int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* 
                    "gemm_qkv_rotary: misaligned pointer");
     ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm_qkv_rotary: misaligned bias");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, nullptr, 0, (u16*)C, ldc, M, N, K, 1.0f, 0, 1,
-               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols};
+               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols, 0, 1, 1};
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
     if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;

@@ -13,6 +13,9 @@ cases = [('qkv  none', T, 3 * E, E, _hip.EPI_NONE), ('out  resid', T, E, E, _hip
          ('ffn1 none', T, 4 * E, E, _hip.EPI_NONE), ('swiglu', T, 2 * 3072, 1152, _hip.EPI_SWIGLU),
          ('vocab 33', T, 33, E, _hip.EPI_NONE)]
 tiles = [int(t) for t in os.environ.get('TILES', '0').split(',')]
+rasters = [tuple(int(v) for v in r.split('x')) for r in os.environ.get('RASTERS', '0x0').split(',')]
+ITERS = int(os.environ.get('ITERS', 30))
+_hip.load().esme_hip_debug_set_gemm_raster.restype = None
 torch.manual_seed(0)
 for name, M, N, K, epi in cases:
     a = torch.randn(M, K, device='cuda').to(torch.bfloat16)
@@ -21,16 +24,18 @@ for name, M, N, K, epi in cases:
     n_out = N // 2 if epi == _hip.EPI_SWIGLU else N
     r = torch.randn(M, n_out, device='cuda').to(torch.bfloat16) if epi == _hip.EPI_RESIDUAL else None
     out = torch.empty(M, n_out, device='cuda', dtype=torch.bfloat16)
-    for tile in tiles:
+    for tile, (gm, gn) in [(t, r) for t in tiles for r in rasters]:
         _hip.load().esme_hip_debug_set_gemm_tile(tile)
-        for _ in range(3):
+        _hip.load().esme_hip_debug_set_gemm_raster(gm, gn)
+        for _ in range(5):
             _hip.gemm(a, w, b, epi, r, 1.0, out)
         torch.cuda.synchronize()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()
-        for _ in range(10):
+        for _ in range(ITERS):
             _hip.gemm(a, w, b, epi, r, 1.0, out)
         en.record(); torch.cuda.synchronize()
-        ms = st.elapsed_time(en) / 10
-        print(f'{name:11s} M={M} N={N} K={K} tile={tile}  {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TF', flush=True)
+        ms = st.elapsed_time(en) / ITERS
+        print(f'{name:11s} M={M} N={N} K={K} tile={tile} raster={gm}x{gn} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TF', flush=True)
     _hip.load().esme_hip_debug_set_gemm_tile(0)
+    _hip.load().esme_hip_debug_set_gemm_raster(0, 0)
