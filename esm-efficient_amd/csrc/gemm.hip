@@ -36,6 +36,8 @@ struct GemmArgs {
     // tile rasterisation: bands of gm tile-rows, inside a band groups of gn tile-columns walked
     // column-major (gm = 1, gn = tiles_n is plain row-major)
     int tiles_m, gm, gn;
+    int nt_store;                // (unused; kept for the tuning hook)
+    int stagger;                 // first-wave start skew (units of ~1024 cycles across the 256 first blocks)
 };
 
 static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
@@ -66,6 +68,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
+    // Optional start skew for the first wave of workgroups: de-synchronises the CUs so that the
+    // epilogue store bursts (and the prologue fetch bursts) of different CUs do not coincide.
+    if (a.stagger > 0 && blockIdx.x < 256) {
+        const int n = (blockIdx.x * a.stagger) >> 8;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);       // 16 x 64 cycles
+    }
     // XCD-aware, L2-friendly tile order: each XCD (own 4 MB L2) walks a contiguous range of ids;
     // ids sweep gm x gn groups of tiles so the ~32 workgroups resident on an XCD share gm
     // activation slabs and gn weight slabs instead of 1-2 and all of them.
@@ -213,22 +221,53 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     }
 
     if (a.vec_ok) {
+        // Branch-free: every load of the epilogue (bias quads, residual quads) is issued up front
+        // with clamped addresses (overhanging rows/columns are computed but never stored), so the
+        // wave pays ONE memory latency, not one per quad.
+        constexpr int FNE = (EPI == ESME_EPI_SWIGLU) ? 1 : FN;
+        u32x2 bq[FNE][4];
+        if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0) {
+            if (a.bias) {
 #pragma unroll
-        for (int i = 0; i < (EPI == ESME_EPI_SWIGLU ? 1 : FN); ++i) {
+                for (int i = 0; i < FNE; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int n = nw0 + i * 32 + 8 * g + 4 * hi;
+                        n = n < a.N - 4 ? n : a.N - 4;
+                        bq[i][g] = *reinterpret_cast<const u32x2*>(a.bias + n);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < FNE; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[i][g] = u32x2{0u, 0u};
+            }
+        }
+        u32x2 rq[EPI == ESME_EPI_RESIDUAL ? FN : 1][EPI == ESME_EPI_RESIDUAL ? 4 : 1][EPI == ESME_EPI_RESIDUAL ? FM : 1];
+        if constexpr (EPI == ESME_EPI_RESIDUAL) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                int64_t m = mw0 + j * 32 + l31;
+                m = m < a.M ? m : a.M - 1;
+                const u16* rrow = a.resid + m * a.ldr;
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int n = nw0 + i * 32 + 8 * g + 4 * hi;
+                        n = n < a.N - 4 ? n : a.N - 4;
+                        rq[i][g][j] = *reinterpret_cast<const u32x2*>(rrow + n);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FNE; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = i * 32 + 8 * g + 4 * hi;                 // column inside the wave slab
-                const int n = nw0 + cl;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (EPI != ESME_EPI_SWIGLU && ROTD == 0 && a.bias) {
-                    if (n + 3 < a.N) {
-                        const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + n);
-                        bv[0] = bf_lo(bw[0]); bv[1] = bf_hi(bw[0]); bv[2] = bf_lo(bw[1]); bv[3] = bf_hi(bw[1]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < a.N) bv[e] = bf2f(a.bias[n + e]);
-                    }
+                if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0) {
+                    bv[0] = bf_lo(bq[i][g][0]); bv[1] = bf_hi(bq[i][g][0]); bv[2] = bf_lo(bq[i][g][1]); bv[3] = bf_hi(bq[i][g][1]);
                 }
 #pragma unroll
                 for (int j = 0; j < FM; ++j) {
@@ -238,7 +277,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float gate = acc[0][j][4 * g + e], fc = acc[1][j][4 * g + e];
-                            o[e] = gate / (1.0f + __expf(-gate)) * fc;
+                            o[e] = gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gate)) * fc;
                         }
                     } else {
 #pragma unroll
@@ -248,16 +287,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                             for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
                         }
                         if constexpr (EPI == ESME_EPI_RESIDUAL) {
-                            const int64_t m = mw0 + r;
-                            if (m < a.M && n + 3 < a.N) {
-                                const u32x2 rw = *reinterpret_cast<const u32x2*>(a.resid + m * a.ldr + n);
-                                o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
-                                o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
-                            } else if (m < a.M) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (n + e < a.N) o[e] = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * o[e];
-                            }
+                            const u32x2 rw = rq[i][g][j];
+                            o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
+                            o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
                         }
                     }
                     u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
@@ -268,22 +300,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         __builtin_amdgcn_wave_barrier();
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
-        if (n + 7 < n_out) {
+        if (n < n_out) {                              // n_out % 8 == 0 on this path
 #pragma unroll
             for (int it = 0; it < WTM / RPI; ++it) {
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (m < a.M) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
-            }
-        } else if (n < n_out) {                      // ragged right edge (n_out % 8 != 0): 2-byte stores
-            for (int it = 0; it < WTM / RPI; ++it) {
-                const int r = it * RPI + rl;
-                const int64_t m = mw0 + r;
-                const u16* sp = reinterpret_cast<const u16*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
-                if (m < a.M)
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < n_out) a.C[m * a.ldc + n + e] = sp[e];
             }
         }
         return;
@@ -317,6 +340,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 }
 
 static int g_raster_gm = 0, g_raster_gn = 0;      // test/tuning hook (0 = heuristic)
+static int g_nt_store = 0;
+static int g_stagger = 0;
 
 // Choose the tile walk.  If the whole weight matrix fits an XCD's L2 (4 MB) next to the
 // streaming activations, plain row-major order is already optimal (W stays resident, every
@@ -391,6 +416,8 @@ using namespace esme;
 static int g_force_tile = 0;
 extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
 extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
+extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
+extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
 
 extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
                                   int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
@@ -407,14 +434,14 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
     ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm: misaligned bias");
     // The coalesced epilogue stores 16 B per lane: it needs ldc % 8 == 0 and a 16-B aligned C;
     // otherwise (e.g. the (T, 33) vocab projection) the epilogue falls back to 2-byte accesses.
-    int vec_ok = (ldc % 8 == 0) && aligned16(C);
+    int vec_ok = (ldc % 8 == 0) && aligned16(C) && (n_out % 8 == 0) && N >= 8;
     if (epilogue == ESME_EPI_RESIDUAL) {
         ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
         vec_ok = vec_ok && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(resid) & 7u) == 0;
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
-               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1};
+               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger};
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
     if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
@@ -443,7 +470,7 @@ extern "C" int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* 
                    "gemm_qkv_rotary: misaligned pointer");
     ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm_qkv_rotary: misaligned bias");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, nullptr, 0, (u16*)C, ldc, M, N, K, 1.0f, 0, 1,
-               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols, 0, 1, 1};
+               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols, 0, 1, 1, g_nt_store, g_stagger};
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
     if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;

@@ -16,6 +16,8 @@ tiles = [int(t) for t in os.environ.get('TILES', '0').split(',')]
 rasters = [tuple(int(v) for v in r.split('x')) for r in os.environ.get('RASTERS', '0x0').split(',')]
 ITERS = int(os.environ.get('ITERS', 30))
 _hip.load().esme_hip_debug_set_gemm_raster.restype = None
+NT = [int(v) for v in os.environ.get('NT', '0').split(',')]
+STAG = [int(v) for v in os.environ.get('STAG', '0').split(',')]
 torch.manual_seed(0)
 for name, M, N, K, epi in cases:
     a = torch.randn(M, K, device='cuda').to(torch.bfloat16)
@@ -24,7 +26,9 @@ for name, M, N, K, epi in cases:
     n_out = N // 2 if epi == _hip.EPI_SWIGLU else N
     r = torch.randn(M, n_out, device='cuda').to(torch.bfloat16) if epi == _hip.EPI_RESIDUAL else None
     out = torch.empty(M, n_out, device='cuda', dtype=torch.bfloat16)
-    for tile, (gm, gn) in [(t, r) for t in tiles for r in rasters]:
+    for tile, (gm, gn), nt, stg in [(t, r, n, sg) for t in tiles for r in rasters for n in NT for sg in STAG]:
+        _hip.load().esme_hip_debug_set_gemm_nt(nt)
+        _hip.load().esme_hip_debug_set_gemm_stagger(stg)
         _hip.load().esme_hip_debug_set_gemm_tile(tile)
         _hip.load().esme_hip_debug_set_gemm_raster(gm, gn)
         for _ in range(5):
@@ -36,6 +40,6 @@ for name, M, N, K, epi in cases:
             _hip.gemm(a, w, b, epi, r, 1.0, out)
         en.record(); torch.cuda.synchronize()
         ms = st.elapsed_time(en) / ITERS
-        print(f'{name:11s} M={M} N={N} K={K} tile={tile} raster={gm}x{gn} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TF', flush=True)
+        print(f'{name:11s} M={M} N={N} K={K} tile={tile} raster={gm}x{gn} nt={nt} stag={stg} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TF', flush=True)
     _hip.load().esme_hip_debug_set_gemm_tile(0)
     _hip.load().esme_hip_debug_set_gemm_raster(0, 0)
