@@ -137,27 +137,66 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = a.K / BK;
+    // Main loop.  MFMA fragments are double-buffered in registers: the ds_read_b128s of k-step
+    // s+1 are in flight while the 8 MFMAs of k-step s issue, the LDS-DMA of K-tile t+1 is
+    // spread over k-steps 0/1 of tile t, and the ONE barrier per K-tile sits between the MFMAs
+    // of k-steps 2 and 3 (so the pipe has work queued across it).  sched_barrier pins the order.
+    struct Frag { bf16x8 w[FN], a[FM]; };
+    auto rd = [&](Frag& f, const char* base, int ks) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 32 * 128 + coff[ks]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 32 * 128 + coff[ks]);
+    };
+    auto mm = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
+    };
+    auto stage_half = [&](int kt, int buf, int h) {            // half of the LDS-DMA of one K-tile
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = h * (IA / 2); i < (h + 1) * (IA / 2); ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(base + (i * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = h * (IW / 2); i < (h + 1) * (IW / 2); ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0),
+                                             (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    static_assert(IA % 2 == 0 && IW % 2 == 0, "stage_half splits the per-thread chunks in two");
     stage(0, 0);
     __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier
+    Frag f0, f1;
+    rd(f0, smem, 0);
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
         const char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fw[FN], fa[FM];
-#pragma unroll
-            for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 32 * 128 + coff[ks]);
-#pragma unroll
-            for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 32 * 128 + coff[ks]);
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();                      // next stage landed; everyone done with this one
+        const bool more = kt + 1 < KT;
+        rd(f1, base, 1);
+        if (more) stage_half(kt + 1, buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(f0, base, 2);
+        if (more) stage_half(kt + 1, buf ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(f1, base, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                      // K-tile t+1 landed; every wave's reads of tile t are done
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) rd(f0, smem + (buf ^ 1) * STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();                          // all waves past their last LDS fragment use before the slab overwrites it
 
     // ---- epilogue.  Lane owns token row m; accumulator quad g = 4 consecutive output columns.
     // Fast path: bias / activation / residual are applied in the accumulator layout, the bf16

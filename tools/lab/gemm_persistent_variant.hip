@@ -1,0 +1,558 @@
+// EXPERIMENT (not built): persistent-tile variant of csrc/gemm.hip with cross-tile prefetch, 2-pass
+// epilogue through one LDS stage, unconditional buffer stores + counted vmcnt.  Measured on MI355X:
+// +1.5 % where it does not spill (SwiGLU), slower elsewhere (256 VGPRs, 54 spilled).  Kept for later rounds.
+// bf16 MFMA GEMM for the packed forward pass:  C = epilogue(A (M,K) @ W (N,K)^T + bias).
+//
+// Both operands are K-contiguous ("NT" GEMM: activations (T,E) row-major, nn.Linear
+// weights (out,in) row-major), which is exactly what v_mfma_f32_32x32x16_bf16 wants: each
+// lane feeds 8 consecutive k of one row.  The product is computed TRANSPOSED -- the MFMA
+// A operand is a 32-row slab of W, the B operand a 32-row slab of activations -- so a lane
+// ends up holding 4 consecutive output columns of one token row per accumulator quad and
+// the epilogue (bias, erf-GELU, SiLU*mul, rotary, residual add + scale, bf16 rounding)
+// needs no cross-lane traffic.
+//
+// Data path per K-tile (BK = 64):  HBM --global_load_lds (16 B/lane, no VGPR round trip)-->
+// LDS [rows][64] bf16, two stages --ds_read_b128--> MFMA fragments.  LDS rows are 128 B, so
+// a 32-row fragment read would hit one 16-B slot 16 ways; the 16-B chunk index is XORed
+// with (row>>1)&7, applied on the per-lane GLOBAL source address (the LDS-DMA destination is
+// lane-linear) and again on the read: conflict-free for both ds_read_b128 lane groupings.
+//
+// The big configuration (256x256x64, 8 waves, 128 KB LDS, one workgroup per CU) is
+// PERSISTENT: one workgroup per CU walks a list of output tiles.  Between two tiles the first
+// K-tile of the next one is already on its way into LDS (issued before the epilogue's stores),
+// the epilogue runs through the other LDS stage, and no workgroup launch sits between tiles.
+// Tile ids are handed out XCD-aware (block b lives on XCD b % 8 and walks a contiguous id
+// range) in gm x gn groups so the ~32 workgroups sharing an XCD's 4 MB L2 touch few distinct
+// activation/weight slabs at a time.
+//
+// Epilogue: results go through a wave-private LDS slab (XOR-swizzled 16-B chunks) and leave
+// as 16 B/lane row-contiguous stores (whole 128-B lines); all epilogue loads (bias, residual,
+// rotary positions) are issued up front with clamped addresses: one memory latency per tile.
+// M/N edges: loads clamp the row index, stores are guarded; only K % 64 == 0 is required.
+#include "common.h"
+#include "launch.h"
+
+namespace esme {
+
+struct GemmArgs {
+    const u16* A; int64_t lda;
+    const u16* W;
+    const u16* bias;
+    const u16* resid; int64_t ldr;
+    u16* C; int64_t ldc;
+    int64_t M; int N; int K;
+    float alpha;
+    int tiles_n;
+    int vec_ok;                  // C rows allow 16-byte stores (ldc % 8 == 0, 16-B aligned, N % 8 == 0), resid 8-byte loads
+    // fused rotary (QKV projection): columns < rot_cols are rotated with position pos[m]
+    const u16* cosT; const u16* sinT; const int32_t* pos; int max_len; int rot_cols;
+    // tile rasterisation: bands of gm tile-rows, inside a band groups of gn tile-columns walked
+    // column-major (gm = 1, gn = tiles_n is plain row-major)
+    int tiles_m, gm, gn;
+    int ntiles;                  // tiles_m * tiles_n
+};
+
+static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
+constexpr bool WTN_OK(int bn, int wn) { return bn / wn == 64; }
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool PERSIST = false>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+    static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
+                  "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
+    constexpr int NW = WM * WN;               // waves per block
+    constexpr int NT = NW * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    constexpr int A_ROWS_BYTES = BM * 128, W_ROWS_BYTES = BN * 128;
+    constexpr int STAGE = A_ROWS_BYTES + W_ROWS_BYTES;
+    constexpr int IA = BM * 8 / NT, IW = BN * 8 / NT;      // 16-B chunks per thread per tile
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+    static_assert(EPI != ESME_EPI_SWIGLU || WTN == 64, "swiglu needs 64-wide wave tiles");
+    static_assert(FM % 2 == 0, "epilogue works in passes of 64 rows");
+    // epilogue slab: one pass = 64 rows x OUTC columns per wave; all waves fit one LDS stage
+    constexpr int OUTC = (EPI == ESME_EPI_SWIGLU) ? WTN / 2 : WTN;     // output columns per wave
+    constexpr int CH = OUTC / 8;                                       // 16-B chunks per slab row
+    constexpr int ROWB = OUTC * 2;
+    constexpr int RPI = 64 / CH;                                       // rows per store instruction
+    static_assert(NW * 64 * ROWB <= STAGE, "epilogue slab must fit one LDS stage");
+    constexpr int FNE = (EPI == ESME_EPI_SWIGLU) ? 1 : FN;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- tile schedule.  Non-persistent: one tile per block, id = xcd_remap(blockIdx).
+    // Persistent: block b (XCD x = b & 7, slot s = b >> 3) takes ids start(x) + round*nb(x) + s
+    // from XCD x's contiguous chunk [start(x), start(x) + len(x)).
+    unsigned int sched_start, sched_len, sched_step, sched_pos;
+    if constexpr (PERSIST) {
+        const unsigned int nblk = gridDim.x, x = blockIdx.x & 7u, s = blockIdx.x >> 3;
+        const unsigned int q = (unsigned int)a.ntiles >> 3, r = (unsigned int)a.ntiles & 7u;
+        sched_start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        sched_len = q + (x < r ? 1u : 0u);
+        sched_step = (nblk - x + 7u) >> 3;          // blocks living on XCD x
+        sched_pos = s;
+    } else {
+        sched_start = xcd_remap(blockIdx.x, gridDim.x);
+        sched_len = 1; sched_step = 1; sched_pos = 0;
+    }
+
+    int64_t m0 = 0; int n0 = 0;
+    auto tile_of = [&](unsigned int pid, int64_t& tm0, int& tn0) {
+        const int per_band = a.gm * a.tiles_n;
+        const int band = pid / per_band, lb = pid - band * per_band;
+        const int rows = min(a.gm, a.tiles_m - band * a.gm);
+        const int grp = rows * a.gn;
+        const int ng = lb / grp, rg = lb - ng * grp;
+        tn0 = (ng * a.gn + rg / rows) * BN;
+        tm0 = ((int64_t)band * a.gm + rg % rows) * BM;
+    };
+
+    // ---- per-thread staging sources (k0 = 0); chunk swizzle folded into the address
+    const u16* srcA[IA];
+    const u16* srcW[IW];
+    auto set_sources = [&](int64_t tm0, int tn0) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int q = (i * NW + wave) * 64 + lane;
+            const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+            int64_t gr = tm0 + row;
+            gr = gr < a.M ? gr : a.M - 1;
+            srcA[i] = a.A + gr * a.lda + c * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < IW; ++i) {
+            const int q = (i * NW + wave) * 64 + lane;
+            const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+            int gr = tn0 + row;
+            gr = gr < a.N ? gr : a.N - 1;
+            srcW[i] = a.W + (int64_t)gr * a.K + c * 8;
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(base + (i * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IW; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0),
+                                             (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets: row*128 + ((chunk ^ swz) << 4); swz depends on lane only
+    const int swz = (l31 >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + hi) ^ swz) << 4;
+    const int rowA = (wm * WTM + l31) * 128;                     // activation slab rows (MFMA B operand)
+    const int rowW = A_ROWS_BYTES + (wn * WTN + l31) * 128;      // weight slab rows (MFMA A operand)
+
+    const int KT = a.K / BK;
+    const int n_out = (EPI == ESME_EPI_SWIGLU) ? (a.N >> 1) : a.N;
+    int par = 0;                                              // LDS stage holding K-tile 0 of the current tile
+    bool first_tile = true;
+    constexpr int NST = (FM / 2) * (64 / RPI);               // epilogue store instructions per wave per tile
+
+    if (sched_pos >= sched_len) return;
+    tile_of(sched_start + sched_pos, m0, n0);
+    set_sources(m0, n0);
+    stage(0, 0);
+
+    for (;;) {
+        f32x16 acc[FN][FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // K-tile 0 landed + previous tile's slab reads done.  After the first tile the youngest
+        // VM operations of this wave are exactly NST epilogue stores (unconditional buffer
+        // stores, see below) issued AFTER the LDS-DMA of this K-tile 0: a counted wait lets the
+        // stores drain in the background instead of stalling the next tile on their acks.
+        if (first_tile || !a.vec_ok) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        __builtin_amdgcn_s_barrier();
+        first_tile = false;
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = (kt & 1) ^ par;
+            if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+            const char* base = smem + buf * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fw[FN], fa[FM];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 32 * 128 + coff[ks]);
+#pragma unroll
+                for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 32 * 128 + coff[ks]);
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();                  // next stage landed; everyone done with this one
+        }
+        // both stages are free now.  Next tile's K-tile 0 goes to stage `nxt`, the slab to the other.
+        const int nxt = par ^ (KT & 1);
+        char* slab = smem + (nxt ^ 1) * STAGE + wave * (64 * ROWB);
+        const int nw0 = (EPI == ESME_EPI_SWIGLU) ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN);   // first output column of the wave
+        const int64_t mw0 = m0 + wm * WTM;
+
+        // ---- epilogue loads first (bias quads, residual quads, rotary positions), clamped
+        u32x2 bq[FNE][4];
+        if constexpr (EPI != ESME_EPI_SWIGLU) {
+            if (a.bias) {
+#pragma unroll
+                for (int i = 0; i < FNE; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int n = nw0 + i * 32 + 8 * g + 4 * hi;
+                        n = n < a.N - 4 ? n : a.N - 4;
+                        n = n > 0 ? n : 0;
+                        bq[i][g] = *reinterpret_cast<const u32x2*>(a.bias + n);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < FNE; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[i][g] = u32x2{0u, 0u};
+            }
+        }
+        u32x2 rq[EPI == ESME_EPI_RESIDUAL ? FN : 1][EPI == ESME_EPI_RESIDUAL ? 4 : 1][EPI == ESME_EPI_RESIDUAL ? FM : 1];
+        if constexpr (EPI == ESME_EPI_RESIDUAL) {
+            if (a.vec_ok) {
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    int64_t m = mw0 + j * 32 + l31;
+                    m = m < a.M ? m : a.M - 1;
+                    const u16* rrow = a.resid + m * a.ldr;
+#pragma unroll
+                    for (int i = 0; i < FN; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            int n = nw0 + i * 32 + 8 * g + 4 * hi;
+                            n = n < a.N - 4 ? n : a.N - 4;
+                            rq[i][g][j] = *reinterpret_cast<const u32x2*>(rrow + n);
+                        }
+                }
+            }
+        }
+        int rpos[ROTD > 0 ? FM : 1];
+        if constexpr (ROTD > 0) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                int64_t m = mw0 + j * 32 + l31;
+                m = m < a.M ? m : a.M - 1;
+                rpos[j] = a.pos[m];
+            }
+        }
+
+        // ---- next tile: its first K-tile is issued BEFORE this tile's stores
+        sched_pos += sched_step;
+        const bool has_next = PERSIST && sched_pos < sched_len;
+        int64_t nm0 = 0; int nn0 = 0;
+        if (has_next) {
+            tile_of(sched_start + sched_pos, nm0, nn0);
+            set_sources(nm0, nn0);
+            stage(0, nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keep the LDS-DMA ahead of every epilogue store (counted vmcnt)
+
+        // ---- fused rotary (QKV projection, head dim ROTD | 64): a head never straddles a wave's
+        // 64 output columns and column c pairs with c + ROTD/2, a multiple of 8 away -- the SAME
+        // lane, another accumulator quad.  Bias first, then q/k columns rotate in the accumulators.
+        if constexpr (ROTD > 0) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float b0 = bf_lo(bq[i][g][0]), b1 = bf_hi(bq[i][g][0]), b2 = bf_lo(bq[i][g][1]), b3 = bf_hi(bq[i][g][1]);
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        acc[i][j][4 * g] += b0; acc[i][j][4 * g + 1] += b1; acc[i][j][4 * g + 2] += b2; acc[i][j][4 * g + 3] += b3;
+                    }
+                }
+            if (nw0 < a.rot_cols) {                               // wave-uniform: whole heads of q or k
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    int p = rpos[j];
+                    p = p < a.max_len ? p : a.max_len - 1;
+                    const u16* ct = a.cosT + (int64_t)p * ROTD + 4 * hi;
+                    const u16* st = a.sinT + (int64_t)p * ROTD + 4 * hi;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {                 // q = quad index i*4+g over the 64 columns
+                        constexpr int HALF = ROTD / 2;
+                        const int c0 = q * 8;
+                        if ((c0 % ROTD) >= HALF) continue;        // upper half of a head: handled with its partner
+                        const int q2 = (c0 + HALF) / 8;           // partner quad
+                        const u32x2 cw = *reinterpret_cast<const u32x2*>(ct + (c0 % ROTD));
+                        const u32x2 sw = *reinterpret_cast<const u32x2*>(st + (c0 % ROTD));
+                        const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
+                        const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = acc[q >> 2][j][4 * (q & 3) + e], up = acc[q2 >> 2][j][4 * (q2 & 3) + e];
+                            acc[q >> 2][j][4 * (q & 3) + e] = lo * cv[e] - up * sv[e];
+                            acc[q2 >> 2][j][4 * (q2 & 3) + e] = up * cv[e] + lo * sv[e];
+                        }
+                    }
+                }
+            }
+        }
+
+        if (a.vec_ok) {
+            // ---- fast path, in passes of 64 rows: accumulator layout -> slab -> 16-B row stores
+            u16* cwave = a.C + mw0 * a.ldc + nw0;
+            {   // wave-uniform by construction; tell the compiler so (descriptor must live in SGPRs)
+                const unsigned int lo32 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)cwave);
+                const unsigned int hi32 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((uintptr_t)cwave >> 32));
+                cwave = reinterpret_cast<u16*>(((uintptr_t)hi32 << 32) | (uintptr_t)lo32);
+            }
+            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(cwave, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int ph = 0; ph < FM / 2; ++ph) {
+#pragma unroll
+                for (int i = 0; i < FNE; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cl = i * 32 + 8 * g + 4 * hi;             // column inside the wave slab
+                        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0) {
+                            bv[0] = bf_lo(bq[i][g][0]); bv[1] = bf_hi(bq[i][g][0]); bv[2] = bf_lo(bq[i][g][1]); bv[3] = bf_hi(bq[i][g][1]);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = ph * 2 + jj;
+                            const int r = jj * 32 + l31;
+                            float o[4];
+                            if constexpr (EPI == ESME_EPI_SWIGLU) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float gate = acc[0][j][4 * g + e], fc = acc[1][j][4 * g + e];
+                                    o[e] = gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gate)) * fc;
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] + bv[e];
+                                if constexpr (EPI == ESME_EPI_GELU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+                                }
+                                if constexpr (EPI == ESME_EPI_RESIDUAL) {
+                                    const u32x2 rw = rq[i][g][j];
+                                    o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
+                                    o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
+                                }
+                            }
+                            u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                            *reinterpret_cast<u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3)) = pk;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // Row-contiguous 16-B stores through a buffer descriptor based at the wave's first
+                // output element: lanes outside M x n_out get an out-of-range offset, which the
+                // hardware drops -- no branch, so every wave issues exactly NST stores per tile.
+                const int rl = lane / CH, ch = lane % CH;
+                const bool col_ok = nw0 + ch * 8 < n_out;     // n_out % 8 == 0 on this path
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int r = it * RPI + rl;
+                    const int rt = ph * 64 + r;               // row inside the wave tile
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
+                    const unsigned int off = (col_ok && mw0 + rt < a.M) ? (unsigned int)(rt * (int)a.ldc + ch * 8) * 2u : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, crsrc, off, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if constexpr (EPI != ESME_EPI_SWIGLU) {
+            // Slow path (C or resid rows not 16-byte addressable, e.g. the (T, 33) vocab logits):
+            // direct 2-byte stores from the accumulator layout.
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw0 + i * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        const int64_t m = mw0 + j * 32 + l31;
+                        if (m >= a.M) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < a.N) {
+                                float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0) ? bf2f(a.bias[n + e]) : 0.f);
+                                if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
+                                if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
+                                a.C[m * a.ldc + n + e] = f2bf(v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (!has_next) break;
+        m0 = nm0; n0 = nn0; par = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+
+static int g_raster_gm = 0, g_raster_gn = 0;      // test/tuning hooks (0 = heuristic)
+static int g_force_tile = 0;
+static int g_persist = 1;
+
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// Choose the tile walk.  If the whole weight matrix fits an XCD's L2 (4 MB) next to the
+// streaming activations, or there are only a few tile columns, plain row-major order is already
+// a g x tiles_n group (W stays resident / every activation slab is fetched once).  Otherwise walk
+// 8 x 4 groups (1 workgroup/CU, 32 CUs per XCD): per group the XCD fetches 8 activation + 4
+// weight slabs instead of ~2 + all (measured: QKV +7 %, FFN-up +3 %).
+template <int BM, int BN>
+static void set_raster(GemmArgs& a) {
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.tiles_m = (int)((a.M + BM - 1) / BM);
+    const double w_bytes = 2.0 * a.N * a.K;
+    if (g_raster_gm > 0) { a.gm = g_raster_gm; a.gn = g_raster_gn > 0 ? g_raster_gn : a.tiles_n; }
+    else if (w_bytes <= 3.5e6 || a.tiles_n <= 6) { a.gm = 1; a.gn = a.tiles_n; }
+    else { a.gm = 8; a.gn = 4; }
+    if (a.gn > a.tiles_n) a.gn = a.tiles_n;
+    if (a.gm > a.tiles_m) a.gm = a.tiles_m;
+    if (a.gm < 1) a.gm = 1;
+    if (a.gn < 1) a.gn = 1;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD>
+static int launch_one(GemmArgs& a, hipStream_t s, const char* what) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr bool BIG = (BM == 256);
+    set_raster<BM, BN>(a);
+    const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
+    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
+    a.ntiles = (int)blocks;
+    const int cus = num_cus();
+    const bool persist = BIG && g_persist && blocks > cus && cus % 8 == 0;
+    if (persist) {
+        auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, BIG>;
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); once = true; }
+        hipLaunchKernelGGL(kern, dim3((unsigned int)cus), dim3(WM * WN * 64), smem, s, a);
+    } else {
+        auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, false>;
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); once = true; }
+        hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(WM * WN * 64), smem, s, a);
+    }
+    return check_launch(what);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(GemmArgs& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case ESME_EPI_NONE: return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 0>(a, s, "gemm_bf16");
+        case ESME_EPI_GELU: return launch_one<BM, BN, WM, WN, ESME_EPI_GELU, 0>(a, s, "gemm_bf16");
+        case ESME_EPI_RESIDUAL: return launch_one<BM, BN, WM, WN, ESME_EPI_RESIDUAL, 0>(a, s, "gemm_bf16");
+        case ESME_EPI_SWIGLU: return launch_one<BM, BN, WM, WN, ESME_EPI_SWIGLU, 0>(a, s, "gemm_bf16");
+        default: return fail(ESME_ERR_ARG, "gemm: unknown epilogue");
+    }
+}
+
+}  // namespace esme
+
+using namespace esme;
+
+// test / tuning hooks.  Not part of the documented ABI.
+extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
+extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
+extern "C" void esme_hip_debug_set_gemm_persist(int v) { g_persist = v; }
+extern "C" void esme_hip_debug_set_gemm_nt(int) {}
+extern "C" void esme_hip_debug_set_gemm_stagger(int) {}
+
+static int pick_tile(int64_t M, int N) {
+    if (g_force_tile) return g_force_tile;
+    return (M >= 4096 && N >= 256) ? 2 : 1;
+}
+
+extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
+                                  int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                                  float alpha, void* stream) {
+    ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad sizes");
+    ESME_CHECK_ARG(epilogue >= ESME_EPI_NONE && epilogue <= ESME_EPI_SWIGLU, "gemm: unknown epilogue");
+    if (M == 0) return ESME_OK;
+    ESME_CHECK_ARG(A && W && C, "gemm: null pointer");
+    if (K % BK != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: K must be a multiple of 64");
+    const int n_out = epilogue == ESME_EPI_SWIGLU ? N / 2 : N;
+    if (epilogue == ESME_EPI_SWIGLU && N % 64 != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs N % 64 == 0");
+    ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= n_out, "gemm: bad lda/ldc");
+    ESME_CHECK_ARG(aligned16(A) && aligned16(W), "gemm: A and W must be 16-byte aligned");
+    ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm: misaligned bias");
+    // The coalesced epilogue stores 16 B per lane: it needs ldc % 8 == 0, a 16-B aligned C and
+    // N % 8 == 0; otherwise (e.g. the (T, 33) vocab projection) it falls back to 2-byte accesses.
+    int vec_ok = (ldc % 8 == 0) && aligned16(C) && (n_out % 8 == 0) && N >= 8;
+    if (epilogue == ESME_EPI_RESIDUAL) {
+        ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
+        vec_ok = vec_ok && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(resid) & 7u) == 0;
+    }
+    if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
+    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
+               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, 0};
+    const hipStream_t s = (hipStream_t)stream;
+    switch (pick_tile(M, N)) {
+        case 1: return launch_gemm<128, 128, 2, 2>(a, epilogue, s);
+        case 2: return launch_gemm<256, 256, 2, 4>(a, epilogue, s);      // wave tile 128(m) x 64(n)
+        default: ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
+    }
+}
+
+extern "C" int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const void* bias, void* C,
+                                        int64_t ldc, int64_t M, int N, int K, const void* cosT, const void* sinT,
+                                        const int32_t* pos, int head_dim, int max_len, int rot_cols, void* stream) {
+    ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0 && max_len > 0, "gemm_qkv_rotary: bad sizes");
+    if (M == 0) return ESME_OK;
+    ESME_CHECK_ARG(A && W && C && cosT && sinT && pos, "gemm_qkv_rotary: null pointer");
+    if (K % BK != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: K must be a multiple of 64");
+    if (head_dim != 16 && head_dim != 32 && head_dim != 64)
+        ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: head dim must be 16, 32 or 64 (use esme_hip_rotary_varlen otherwise)");
+    if (N % 64 != 0 || rot_cols % 64 != 0 || rot_cols < 0 || rot_cols > N)
+        ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: N and rot_cols must be multiples of 64, rot_cols <= N");
+    ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm_qkv_rotary: bad lda/ldc");
+    ESME_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(cosT) && aligned16(sinT),
+                   "gemm_qkv_rotary: misaligned pointer");
+    ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm_qkv_rotary: misaligned bias");
+    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, nullptr, 0, (u16*)C, ldc, M, N, K, 1.0f, 0, 1,
+               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols, 0, 1, 1, 0};
+    const hipStream_t s = (hipStream_t)stream;
+    const int tile = pick_tile(M, N);
+#define ESME_ROT(D)                                                                                    \
+    case D:                                                                                             \
+        return tile == 1 ? launch_one<128, 128, 2, 2, ESME_EPI_NONE, D>(a, s, "gemm_qkv_rotary")       \
+                         : launch_one<256, 256, 2, 4, ESME_EPI_NONE, D>(a, s, "gemm_qkv_rotary");
+    switch (head_dim) {
+        ESME_ROT(16)
+        ESME_ROT(32)
+        ESME_ROT(64)
+    }
+#undef ESME_ROT
+    return ESME_ERR_UNSUPPORTED;
+}
