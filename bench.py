@@ -49,9 +49,22 @@ def parse():
     ap.add_argument('--seq-len', type=int, default=500)
     ap.add_argument('--batch', choices=['uniform', 'proteome'], default='uniform')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-tokens', type=int, default=2000)
+    ap.add_argument('--cpu-sample-tokens', type=int, default=8000)
     ap.add_argument('--no-gather', action='store_true', help='skip the logits all-gather when N>1')
     return ap.parse_args()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).
+    Counters cannot be read from inside the process, so this is the last profiled value, valid
+    for the default workload only; None otherwise."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    try:
+        with open(path) as f:
+            return int(json.load(f)['traffic_bytes_per_launch'])
+    except Exception:
+        return None
 
 
 def cpu_baseline(weights, heads, kind, L, E, seq_len, sample_tokens):
@@ -181,7 +194,7 @@ def main():
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': f'gemm_bf16_kernel M={key[1][0]} N={key[1][1]} K={key[1][2]} (FFN up, fused epilogue)',
                 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic() if (args.model == 'esm2_650m' and T == 50000) else None,
                 'avg_launch_ms': round(ms, 4), 'launches_timed': len(per_op[key]),
                 'all_gemms': {'achieved': round(g_fl / (g_ms * 1e-3) / 1e12, 1),
                               'frac': round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
