@@ -46,7 +46,7 @@ __device__ __forceinline__ int kswz(int row) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_varlen_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     constexpr int DS = D / 16;                   // k-steps of the QK^T contraction
     constexpr int DB = (D + 31) / 32;            // 32-row blocks of O^T
     constexpr int CPR = D / 8;                   // 16-B chunks per K row
