@@ -38,6 +38,12 @@ struct GemmArgs {
     int tiles_m, gm, gn;
     int nt_store;                // (unused; kept for the tuning hook)
     int stagger;                 // first-wave start skew (units of ~1024 cycles across the 256 first blocks)
+    // LayerNorm folded into the consumer GEMM (W already scaled by gamma):
+    //   y = rstd[m]*acc - (rstd*mean)[m]*c1[n] + c2[n],  ln_stats = (rstd, rstd*mean) per row
+    const float* ln_stats; const float* ln_c1; const float* ln_c2;
+    // residual epilogue also emits per-row partial (sum, sum of squares) of the ROUNDED output
+    // over each 64-column block: stats_out[(n/64) * M + m] (float2) -> next LayerNorm's statistics
+    float* stats_out;
 };
 
 static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
@@ -46,8 +52,10 @@ constexpr bool WTN_OK(int bn, int wn) { return bn / wn == 64; }
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+    static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
+    static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN)), "row statistics are emitted by the residual epilogue");
     static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
                   "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
     constexpr int NW = WM * WN;               // waves per block
@@ -212,6 +220,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int nw0 = (EPI == ESME_EPI_SWIGLU) ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN);   // first output column of the wave
     const int64_t mw0 = m0 + wm * WTM;
 
+    // ---- folded LayerNorm: the GEMM ran on the RAW residual stream with gamma-scaled weights;
+    // finish LN(x) W^T + b algebraically per element (fp32), so no normalised copy of x is ever
+    // written or read:  y = rstd*(x.W') - rstd*mean*sum_k W'[n,k] + (sum_k beta_k W[n,k] + b[n]).
+    if constexpr (LNF) {
+        const int nrow0 = n0 + wn * WTN;                          // packed weight row of the wave's first column
+        f32x2 st[FM];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            int64_t m = mw0 + j * 32 + l31;
+            m = m < a.M ? m : a.M - 1;
+            st[j] = *reinterpret_cast<const f32x2*>(a.ln_stats + 2 * m);
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int n = nrow0 + i * 32 + 8 * g + 4 * hi;
+                n = n < a.N - 4 ? n : a.N - 4;
+                const f32x4 c1q = *reinterpret_cast<const f32x4*>(a.ln_c1 + n);
+                const f32x4 c2q = *reinterpret_cast<const f32x4*>(a.ln_c2 + n);
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][4 * g + e] = fmaf(st[j][0], acc[i][j][4 * g + e], fmaf(-st[j][1], c1q[e], c2q[e]));
+            }
+    }
+
     // ---- fused rotary (QKV projection, head dim ROTD | 64): a head never straddles a wave's
     // 64 output columns and column c pairs with c + ROTD/2, a multiple of 8 away -- i.e. the
     // SAME lane, another accumulator quad.  Bias is added first, then q/k columns are rotated
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (!a.bias) continue;
+                if (LNF || !a.bias) continue;
                 const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + nw0 + i * 32 + 8 * g + 4 * hi);
                 const float b0 = bf_lo(bw[0]), b1 = bf_hi(bw[0]), b2 = bf_lo(bw[1]), b3 = bf_hi(bw[1]);
 #pragma unroll
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // wave pays ONE memory latency, not one per quad.
         constexpr int FNE = (EPI == ESME_EPI_SWIGLU) ? 1 : FN;
         u32x2 bq[FNE][4];
-        if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0) {
+        if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0 && !LNF) {
             if (a.bias) {
 #pragma unroll
                 for (int i = 0; i < FNE; ++i)
@@ -299,13 +335,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
             }
         }
+        float s1[STATS ? FM : 1], s2[STATS ? FM : 1];
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        }
 #pragma unroll
         for (int i = 0; i < FNE; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = i * 32 + 8 * g + 4 * hi;                 // column inside the wave slab
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0) {
+                if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0 && !LNF) {
                     bv[0] = bf_lo(bq[i][g][0]); bv[1] = bf_hi(bq[i][g][0]); bv[2] = bf_lo(bq[i][g][1]); bv[3] = bf_hi(bq[i][g][1]);
                 }
 #pragma unroll
@@ -333,6 +374,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
                     u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
                     *reinterpret_cast<u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3)) = pk;
+                    if constexpr (STATS) {                      // statistics of what the next LayerNorm will read
+                        const float v0 = bf_lo(pk[0]), v1 = bf_hi(pk[0]), v2 = bf_lo(pk[1]), v3 = bf_hi(pk[1]);
+                        s1[j] += (v0 + v1) + (v2 + v3);
+                        s2[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    }
+                }
+            }
+        }
+        if constexpr (STATS) {
+            const int cwb = (n0 + wn * WTN) >> 6;                   // 64-column block index of this wave
+            if (n0 + wn * WTN < a.N) {
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+                    const int64_t m = mw0 + j * 32 + l31;
+                    if (hi == 0 && m < a.M) *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)cwb * a.M + m)) = f32x2{t1, t2};
                 }
             }
         }
@@ -366,7 +423,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (n + e < a.N) {
-                            float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0) ? bf2f(a.bias[n + e]) : 0.f);
+                            float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
                             if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
                             if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
                             a.C[m * a.ldc + n + e] = f2bf(v);
@@ -401,66 +458,56 @@ static void set_raster(GemmArgs& a) {
     if (a.gn < 1) a.gn = 1;
 }
 
-template <int BM, int BN, int WM, int WN, int ROTD>
-static int launch_gemm_rot(GemmArgs& a, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
+static int launch_one(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, ESME_EPI_NONE, ROTD>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS>;
     if (smem > 64 * 1024) {
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); once = true; }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(WM * WN * 64), smem, s, a);
-    return check_launch("gemm_qkv_rotary");
+    return check_launch("gemm_bf16");
 }
 
+// epilogue x rotary-head-dim x LN-fold x row-stats dispatch for one tile configuration
 template <int BM, int BN, int WM, int WN>
-static int launch_gemm(GemmArgs& a, int epi, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128;
-    set_raster<BM, BN>(a);
-    const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
-    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
-    const dim3 grid((unsigned int)blocks), block(WM * WN * 64);
-#define ESME_GEMM_CASE(E)                                                                         \
-    case E: {                                                                                     \
-        auto kern = gemm_bf16_kernel<BM, BN, WM, WN, E>;                                          \
-        if (smem > 64 * 1024) {                                                                   \
-            static bool once = false;                                                             \
-            if (!once) {                                                                          \
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-                once = true;                                                                      \
-            }                                                                                     \
-        }                                                                                         \
-        hipLaunchKernelGGL(kern, grid, block, smem, s, a);                                        \
-        break;                                                                                    \
-    }
+static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hipStream_t s) {
+#define ESME_L(E, R, L, S) launch_one<BM, BN, WM, WN, E, R, L, S>(a, s)
     switch (epi) {
-        ESME_GEMM_CASE(ESME_EPI_NONE)
-        ESME_GEMM_CASE(ESME_EPI_GELU)
-        ESME_GEMM_CASE(ESME_EPI_RESIDUAL)
-        ESME_GEMM_CASE(ESME_EPI_SWIGLU)
+        case ESME_EPI_NONE:
+            switch (rotd) {
+                case 0: return lnf ? ESME_L(ESME_EPI_NONE, 0, true, false) : ESME_L(ESME_EPI_NONE, 0, false, false);
+                case 16: return lnf ? ESME_L(ESME_EPI_NONE, 16, true, false) : ESME_L(ESME_EPI_NONE, 16, false, false);
+                case 32: return lnf ? ESME_L(ESME_EPI_NONE, 32, true, false) : ESME_L(ESME_EPI_NONE, 32, false, false);
+                case 64: return lnf ? ESME_L(ESME_EPI_NONE, 64, true, false) : ESME_L(ESME_EPI_NONE, 64, false, false);
+                default: return fail(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs head dim 16, 32 or 64");
+            }
+        case ESME_EPI_GELU: return lnf ? ESME_L(ESME_EPI_GELU, 0, true, false) : ESME_L(ESME_EPI_GELU, 0, false, false);
+        case ESME_EPI_SWIGLU: return lnf ? ESME_L(ESME_EPI_SWIGLU, 0, true, false) : ESME_L(ESME_EPI_SWIGLU, 0, false, false);
+        case ESME_EPI_RESIDUAL: return stats ? ESME_L(ESME_EPI_RESIDUAL, 0, false, true) : ESME_L(ESME_EPI_RESIDUAL, 0, false, false);
         default: return fail(ESME_ERR_ARG, "gemm: unknown epilogue");
     }
-#undef ESME_GEMM_CASE
-    return check_launch("gemm_bf16");
+#undef ESME_L
 }
 
 }  // namespace esme
 
 using namespace esme;
 
-// test hook: force a tile configuration (0 = heuristic).  Not part of the documented ABI.
+// test / tuning hooks.  Not part of the documented ABI.
 static int g_force_tile = 0;
 extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
 extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
 extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
 extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
 
-extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
-                                  int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
-                                  float alpha, void* stream) {
+extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
+                                        int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                                        float alpha, const esme_gemm_fusion_t* fu, void* stream) {
     ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad sizes");
     ESME_CHECK_ARG(epilogue >= ESME_EPI_NONE && epilogue <= ESME_EPI_SWIGLU, "gemm: unknown epilogue");
     if (M == 0) return ESME_OK;
@@ -471,8 +518,8 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
     ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= n_out, "gemm: bad lda/ldc");
     ESME_CHECK_ARG(aligned16(A) && aligned16(W), "gemm: A and W must be 16-byte aligned");
     ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm: misaligned bias");
-    // The coalesced epilogue stores 16 B per lane: it needs ldc % 8 == 0 and a 16-B aligned C;
-    // otherwise (e.g. the (T, 33) vocab projection) the epilogue falls back to 2-byte accesses.
+    // The coalesced epilogue stores 16 B per lane: it needs ldc % 8 == 0, a 16-B aligned C and
+    // N % 8 == 0; otherwise (e.g. the (T, 33) vocab projection) it falls back to 2-byte accesses.
     int vec_ok = (ldc % 8 == 0) && aligned16(C) && (n_out % 8 == 0) && N >= 8;
     if (epilogue == ESME_EPI_RESIDUAL) {
         ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
@@ -480,47 +527,59 @@ extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, con
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
-               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger};
+               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger, nullptr, nullptr, nullptr, nullptr};
+    int rotd = 0;
+    bool lnf = false, stats = false;
+    if (fu) {
+        if (fu->head_dim != 0) {                                     // fused rotary
+            ESME_CHECK_ARG(epilogue == ESME_EPI_NONE, "gemm: fused rotary needs ESME_EPI_NONE");
+            ESME_CHECK_ARG(fu->cos && fu->sin && fu->pos && fu->max_len > 0, "gemm: fused rotary needs cos, sin, pos, max_len");
+            if (fu->head_dim != 16 && fu->head_dim != 32 && fu->head_dim != 64)
+                ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs head dim 16, 32 or 64 (use esme_hip_rotary_varlen otherwise)");
+            if (N % 64 != 0 || fu->rot_cols % 64 != 0 || fu->rot_cols < 0 || fu->rot_cols > N || !vec_ok)
+                ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs N, rot_cols multiples of 64, rot_cols <= N, 16-byte addressable C");
+            ESME_CHECK_ARG(aligned16(fu->cos) && aligned16(fu->sin), "gemm: misaligned rotary tables");
+            a.cosT = (const u16*)fu->cos; a.sinT = (const u16*)fu->sin; a.pos = fu->pos;
+            a.max_len = fu->max_len; a.rot_cols = fu->rot_cols;
+            rotd = fu->head_dim;
+        }
+        if (fu->ln_stats) {                                          // LayerNorm folded into this GEMM
+            ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL, "gemm: LN fold does not combine with the residual epilogue");
+            ESME_CHECK_ARG(fu->ln_c1 && fu->ln_c2 && aligned16(fu->ln_c1) && aligned16(fu->ln_c2) &&
+                           (reinterpret_cast<uintptr_t>(fu->ln_stats) & 7u) == 0, "gemm: LN fold needs 16-byte aligned c1, c2 and 8-byte aligned stats");
+            if (N % 4 != 0 || !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: LN fold needs N % 4 == 0 and 16-byte addressable C");
+            a.ln_stats = fu->ln_stats; a.ln_c1 = fu->ln_c1; a.ln_c2 = fu->ln_c2;
+            lnf = true;
+        }
+        if (fu->stats_out) {                                         // emit row statistics for the next LayerNorm
+            ESME_CHECK_ARG(epilogue == ESME_EPI_RESIDUAL, "gemm: row statistics are emitted by the residual epilogue");
+            if (N % 64 != 0 || !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: row statistics need N % 64 == 0 and 16-byte addressable C");
+            ESME_CHECK_ARG((reinterpret_cast<uintptr_t>(fu->stats_out) & 7u) == 0, "gemm: misaligned stats_out");
+            a.stats_out = fu->stats_out;
+            stats = true;
+        }
+    }
     const hipStream_t s = (hipStream_t)stream;
     int tile = g_force_tile;
     if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
-    if (epilogue == ESME_EPI_SWIGLU && tile == 2) tile = 3;
     switch (tile) {
-        case 1: return launch_gemm<128, 128, 2, 2>(a, epilogue, s);
-        case 2: return launch_gemm<256, 256, 2, 4>(a, epilogue, s);      // wave tile 128(m) x 64(n)
-        case 3: return launch_gemm<256, 256, 2, 4>(a, epilogue, s);
+        case 1: return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
+        case 2: return launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);      // wave tile 128(m) x 64(n)
         default: ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
     }
+}
+
+extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
+                                  int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                                  float alpha, void* stream) {
+    return esme_hip_gemm_bf16_fused(A, lda, W, bias, resid, ldr, C, ldc, M, N, K, epilogue, alpha, nullptr, stream);
 }
 
 extern "C" int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const void* bias, void* C,
                                         int64_t ldc, int64_t M, int N, int K, const void* cosT, const void* sinT,
                                         const int32_t* pos, int head_dim, int max_len, int rot_cols, void* stream) {
-    ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0 && max_len > 0, "gemm_qkv_rotary: bad sizes");
-    if (M == 0) return ESME_OK;
-    ESME_CHECK_ARG(A && W && C && cosT && sinT && pos, "gemm_qkv_rotary: null pointer");
-    if (K % BK != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: K must be a multiple of 64");
-    if (head_dim != 16 && head_dim != 32 && head_dim != 64)
-        ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: head dim must be 16, 32 or 64 (use esme_hip_rotary_varlen otherwise)");
-    if (N % 64 != 0 || rot_cols % 64 != 0 || rot_cols < 0 || rot_cols > N)
-        ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm_qkv_rotary: N and rot_cols must be multiples of 64, rot_cols <= N");
-    ESME_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm_qkv_rotary: bad lda/ldc");
-    ESME_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(cosT) && aligned16(sinT),
-                   "gemm_qkv_rotary: misaligned pointer");
-    ESME_CHECK_ARG(!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0, "gemm_qkv_rotary: misaligned bias");
-    GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, nullptr, 0, (u16*)C, ldc, M, N, K, 1.0f, 0, 1,
-               (const u16*)cosT, (const u16*)sinT, pos, max_len, rot_cols, 0, 1, 1, g_nt_store, g_stagger};
-    const hipStream_t s = (hipStream_t)stream;
-    int tile = g_force_tile;
-    if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
-#define ESME_ROT(D)                                                      \
-    case D:                                                               \
-        return tile == 1 ? launch_gemm_rot<128, 128, 2, 2, D>(a, s) : launch_gemm_rot<256, 256, 2, 4, D>(a, s);
-    switch (head_dim) {
-        ESME_ROT(16)
-        ESME_ROT(32)
-        ESME_ROT(64)
-    }
-#undef ESME_ROT
-    return ESME_ERR_UNSUPPORTED;
+    ESME_CHECK_ARG(head_dim != 0, "gemm_qkv_rotary: head_dim must be 16, 32 or 64");
+    esme_gemm_fusion_t fu{};
+    fu.cos = cosT; fu.sin = sinT; fu.pos = pos; fu.head_dim = head_dim; fu.max_len = max_len; fu.rot_cols = rot_cols;
+    return esme_hip_gemm_bf16_fused(A, lda, W, bias, nullptr, 0, C, ldc, M, N, K, ESME_EPI_NONE, 1.0f, &fu, stream);
 }

@@ -96,6 +96,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
     }
 }
 
+// ------------------------------------------------------- LayerNorm statistics
+// stats[row] = {rstd, rstd*mean}: one wave per row straight from x ...
+template <int NCH>
+__global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ x, int64_t ldx, int64_t T, int E,
+                                                        float eps, f32x2* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const u16* xr = x + row * ldx;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            float v[8];
+            unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 += v[j] * v[j]; }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float mean = s1 / (float)E;
+    const float var = fmaxf(s2 / (float)E - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) stats[row] = f32x2{rstd, rstd * mean};
+}
+// ... or from the per-64-column-block partial sums a residual-epilogue GEMM emitted
+__global__ __launch_bounds__(256) void ln_stats_reduce_kernel(const f32x2* __restrict__ partial, int nblk, int64_t T,
+                                                              int E, float eps, f32x2* __restrict__ stats) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= T) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const f32x2 p = partial[(int64_t)b * T + row];
+        s1 += p[0]; s2 += p[1];
+    }
+    const float mean = s1 / (float)E;
+    const float var = fmaxf(s2 / (float)E - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    stats[row] = f32x2{rstd, rstd * mean};
+}
+
 // ------------------------------------------------------------------- rotary
 // One lane per (row, tensor, head, 8-wide chunk of the first half of the head): it
 // rotates that chunk together with its partner chunk d/2 further on.  Tables are tiny
@@ -214,6 +256,35 @@ extern "C" int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, con
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm: E > 5120 unsupported");
 #undef ESME_LN
     return check_launch("layernorm");
+}
+
+extern "C" int esme_hip_row_stats(const void* x, int64_t ldx, int64_t T, int E, float eps, float* stats, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "row_stats: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && stats && E % 8 == 0 && ldx % 8 == 0 && ldx >= E && aligned16(x) &&
+                   (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "row_stats: null/misaligned pointer or E, ldx not multiples of 8");
+    const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_RS(N) hipLaunchKernelGGL(row_stats_kernel<N>, grid, block, 0, s, (const u16*)x, ldx, T, E, eps, (f32x2*)stats)
+    if (E <= 512) ESME_RS(1);
+    else if (E <= 1024) ESME_RS(2);
+    else if (E <= 1536) ESME_RS(3);
+    else if (E <= 2560) ESME_RS(5);
+    else if (E <= 5120) ESME_RS(10);
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "row_stats: E > 5120 unsupported");
+#undef ESME_RS
+    return check_launch("row_stats");
+}
+
+extern "C" int esme_hip_ln_stats_reduce(const float* partial, int nblk, int64_t T, int E, float eps, float* stats,
+                                        void* stream) {
+    ESME_CHECK_ARG(T >= 0 && nblk > 0 && E > 0, "ln_stats_reduce: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(partial && stats && (reinterpret_cast<uintptr_t>(partial) & 7u) == 0 &&
+                   (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "ln_stats_reduce: null/misaligned pointer");
+    hipLaunchKernelGGL(ln_stats_reduce_kernel, dim3((unsigned int)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x2*)partial, nblk, T, E, eps, (f32x2*)stats);
+    return check_launch("ln_stats_reduce");
 }
 
 extern "C" int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 from typing import Optional
 
 import torch
@@ -19,6 +19,14 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 ABI_VERSION = 1
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
+
+
+class GemmFusion(Structure):
+    """esme_gemm_fusion_t (include/esme_hip.h)."""
+    _fields_ = [('ln_stats', c_void_p), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
+                ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
+                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int)]
+
 
 # name -> (restype, argtypes); must list every symbol include/esme_hip.h declares
 SIGNATURES = {
@@ -36,6 +44,10 @@ SIGNATURES = {
                                    c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_gemm_qkv_rotary': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_gemm_bf16_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_int64, c_int, c_int, c_int, c_float, POINTER(GemmFusion), c_void_p]),
+    'esme_hip_row_stats': (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p]),
+    'esme_hip_ln_stats_reduce': (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
@@ -247,6 +259,73 @@ def gemm_qkv_rotary(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
             ap, lda, _dev(w, 'w', torch.bfloat16), _dev(bias, 'bias', torch.bfloat16) if bias is not None else None,
             cp, ldc, M, N, K, _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16),
             _dev(pos, 'pos', torch.int32), head_dim, cos.shape[0], rot_cols, _stream()), 'esme_hip_gemm_qkv_rotary')
+    return out
+
+
+def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+               resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
+               ln=None, stats_out: Optional[torch.Tensor] = None, rot=None) -> torch.Tensor:
+    """esme_hip_gemm_bf16_fused.  `ln` = (stats (M,2) f32, c1 (N,) f32, c2 (N,) f32) folds the
+    LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
+    `stats_out` (N/64, M, 2) f32 receives per-row partial sums of the rounded output (residual
+    epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue)."""
+    ap, lda = _rows2d(a, 'gemm a')
+    if not w.is_contiguous():
+        raise ValueError('gemm: weight must be contiguous (N, K)')
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f'gemm: K mismatch {a.shape} x {w.shape}')
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
+    cp, ldc = _rows2d(out, 'gemm out')
+    rp, ldr = (None, 0)
+    if epilogue == EPI_RESIDUAL:
+        rp, ldr = _rows2d(resid, 'gemm resid')
+    fu = GemmFusion()
+    tag = epilogue
+    if ln is not None:
+        st, c1, c2 = ln
+        if st.shape != (M, 2) or c1.numel() != N or c2.numel() != N:
+            raise ValueError('gemm: LN-fold tensors have the wrong shape')
+        fu.ln_stats, fu.ln_c1, fu.ln_c2 = (_dev(st, 'ln stats', torch.float32), _dev(c1, 'ln c1', torch.float32),
+                                           _dev(c2, 'ln c2', torch.float32))
+    if stats_out is not None:
+        if stats_out.numel() < (N // 64) * M * 2 or not stats_out.is_contiguous():
+            raise ValueError('gemm: stats_out must be a contiguous (N/64, M, 2) float32 buffer')
+        fu.stats_out = _dev(stats_out, 'stats_out', torch.float32)
+    if rot is not None:
+        cos, sin, pos, head_dim, rot_cols = rot
+        fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16), _dev(pos, 'pos', torch.int32)
+        fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
+        tag = 'qkv_rotary'
+    with _Traced('gemm', (M, N, K, tag)):
+        _check(load().esme_hip_gemm_bf16_fused(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+                                               _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
+                                               rp, ldr, cp, ldc, M, N, K, epilogue, alpha, ctypes.byref(fu), _stream()),
+               'esme_hip_gemm_bf16_fused')
+    return out
+
+
+def row_stats(x: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(T, 2) float32 {rstd, rstd*mean} of each row of a (T, E) bf16 tensor."""
+    xp, ldx = _rows2d(x, 'row_stats x')
+    T, E = x.shape
+    if out is None:
+        out = torch.empty(T, 2, dtype=torch.float32, device=x.device)
+    with _Traced('ln_stats', (T, E)):
+        _check(load().esme_hip_row_stats(xp, ldx, T, E, eps, _dev(out, 'stats', torch.float32), _stream()), 'esme_hip_row_stats')
+    return out
+
+
+def ln_stats_reduce(partial: torch.Tensor, T: int, E: int, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Reduce the (E/64, T, 2) partial sums a residual-epilogue GEMM emitted to (T, 2) {rstd, rstd*mean}."""
+    if out is None:
+        out = torch.empty(T, 2, dtype=torch.float32, device=partial.device)
+    with _Traced('ln_stats', (T, E)):
+        _check(load().esme_hip_ln_stats_reduce(_dev(partial, 'partial', torch.float32), E // 64, T, E, eps,
+                                               _dev(out, 'stats', torch.float32), _stream()), 'esme_hip_ln_stats_reduce')
     return out
 
 

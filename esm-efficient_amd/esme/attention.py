@@ -3,17 +3,23 @@
 Same public names, constructor arguments and parameter names as the reference
 (`esme/attention.py`: FlashMultiheadAttention :10-139, FlashTransformerLayer
 :142-255, SwiGLU :258-281) so its checkpoints load unchanged, but re-planned for
-MI355X:
+MI355X.  Per layer, on the model's fast path (6 GEMM/attention launches + 2 tiny
+statistics reductions, no elementwise pass over HBM):
 
-  LN -> ONE fused QKV GEMM (N = 3E, the three nn.Linear weights are re-pointed to
-  row slices of one (3E, E) buffer) -> [ESM-C: LayerNorm of the q and k column
-  blocks in place] -> rotary in place on the q/k column blocks -> varlen attention
-  reading q/k/v straight out of the (T, 3E) buffer -> out-projection GEMM whose
-  epilogue adds bias, scales by 1/residue_scaling and adds the residual ->
-  LN -> FFN GEMM with GELU (or SiLU*mul over an interleaved gate/fc weight) in the
-  epilogue -> down GEMM with the residual epilogue.
+  [row statistics of x: emitted by the previous residual GEMM's epilogue]
+  ONE fused QKV GEMM on the RAW residual stream with gamma-scaled weights (N = 3E); its
+      epilogue finishes the LayerNorm algebraically, adds the bias and rotates the q/k heads
+  varlen attention reading q/k/v straight out of the (T, 3E) buffer
+  out-projection GEMM: epilogue adds bias, scales by 1/residue_scaling, adds the residual,
+      and emits the row statistics the next LayerNorm needs
+  FFN-up GEMM on the raw stream (LN folded the same way) with GELU / SiLU*mul in the epilogue
+  FFN-down GEMM with the residual epilogue (+ statistics for the next layer)
 
-8 kernel launches per layer; no elementwise pass touches HBM on its own.
+The LayerNorm fold:  LN(x) W^T + b = rstd*(x W'^T) - rstd*mean*c1 + c2  with W' = W*diag(gamma),
+c1[n] = sum_k W'[n,k], c2[n] = sum_k beta[k] W[n,k] + b[n]; no normalised copy of x is written.
+ESM-C (q/k LayerNorm between projection and rotary) keeps separate LN / rotary kernels for
+those two steps.  The stage methods named like the reference's (`_qkv`, `_attn`) run the
+unfused kernels (LN kernel, plain GEMM, rotary kernel) and are what the stage-tap tests use.
 """
 from __future__ import annotations
 
@@ -29,16 +35,33 @@ from esme.rotary import RotaryEmbedding
 
 
 class ForwardContext:
-    """Per-forward shared state: row positions, rotary tables (computed once, not
-    per layer)."""
-    __slots__ = ('pos', 'cos', 'sin')
+    """Per-forward shared state: row positions, rotary tables (computed once, not per
+    layer) and the LayerNorm-statistics plumbing of the fused path."""
+    __slots__ = ('pos', 'cos', 'sin', 'stats', 'stats_next', 'partial', 'fold')
 
-    def __init__(self, pos, cos, sin):
+    def __init__(self, pos, cos, sin, fold=False):
         self.pos, self.cos, self.sin = pos, cos, sin
+        self.fold = fold            # run the LN-folded fast path
+        self.stats = None           # (T, 2) f32 {rstd, rstd*mean} of the current residual stream
+        self.stats_next = None      # spare (T, 2) buffer (ping-pong)
+        self.partial = None         # (E/64, T, 2) f32 partial sums written by the residual GEMMs
 
 
 def _version_key(*params):
     return tuple((p.data_ptr(), p._version) for p in params if p is not None)
+
+
+def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
+                    beta: Optional[torch.Tensor]):
+    """(W' = bf16(W*gamma), c1 = rowsum(W'), c2 = W beta + bias) for the LN-folded GEMM."""
+    wf = (w.float() * gamma.float().unsqueeze(0)).to(torch.bfloat16).contiguous()
+    c1 = wf.float().sum(dim=1).contiguous()
+    c2 = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+    if beta is not None:
+        c2 += w.float() @ beta.float()
+    if bias is not None:
+        c2 += bias.float()
+    return wf, c1, c2.contiguous()
 
 
 class FlashMultiheadAttention(nn.Module):
@@ -64,6 +87,8 @@ class FlashMultiheadAttention(nn.Module):
         self._qkv_w: Optional[torch.Tensor] = None
         self._qkv_b: Optional[torch.Tensor] = None
         self._pack_key = None
+        self._fold = None           # (W', c1, c2) of the LN-folded QKV projection
+        self._fold_key = None
 
     # -- weight layout ------------------------------------------------------
     def _pack(self):
@@ -89,6 +114,17 @@ class FlashMultiheadAttention(nn.Module):
         self._pack_key = _version_key(self.q.weight, self.k.weight, self.v.weight,
                                       self.q.bias, self.k.bias, self.v.bias)
 
+    def _pack_fold(self):
+        """LN-folded copy of the fused QKV weight (self.norm folded in)."""
+        self._pack()
+        key = (self._pack_key, _version_key(self.norm.weight, self.norm.bias))
+        if key != self._fold_key:
+            with torch.no_grad():
+                self._fold = _fold_layernorm(self._qkv_w, self._qkv_b, self.norm.weight.data,
+                                             self.norm.bias.data if self.norm.bias is not None else None)
+            self._fold_key = key
+        return self._fold
+
     # -- stages (names follow the reference) --------------------------------
     def _qkv(self, x, lora_names=None):
         """LN -> fused QKV (-> ESM-C q/k LayerNorm over the full E, attention.py:104-105).
@@ -98,6 +134,10 @@ class FlashMultiheadAttention(nn.Module):
         T, E = x.shape
         h = self.norm(x)
         qkv = _hip.gemm(h, self._qkv_w, self._qkv_b)
+        return self._split_qkv(qkv)
+
+    def _split_qkv(self, qkv):
+        T, E = qkv.shape[0], self.embed_dim
         if self.pre_layernorm:
             self.layernorm_q(qkv[:, :E], out=qkv[:, :E])
             self.layernorm_k(qkv[:, E:2 * E], out=qkv[:, E:2 * E])
@@ -110,29 +150,33 @@ class FlashMultiheadAttention(nn.Module):
         return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
-                resid=None, alpha: float = 1.0, out=None):
+                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
-        resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid)."""
+        resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid).
+        `x_stats` ((T, 2) f32 row statistics of x) selects the LN-folded projection;
+        `stats_out` makes the out-projection emit the statistics of its output."""
+        assert lora_names is None, 'LoRA adapters are outside the inference hot path'
         T, E = x.shape
-        fuse = (self.rot_emb is not None and ctx is not None and not self.pre_layernorm
-                and self.head_dim in (16, 32, 64) and E % 32 == 0)
-        if fuse:
-            # LN -> ONE GEMM that also adds the bias and rotates the q/k heads in its epilogue
-            assert lora_names is None, 'LoRA adapters are outside the inference hot path'
-            self._pack()
-            qkv = _hip.gemm_qkv_rotary(self.norm(x), self._qkv_w, self._qkv_b, ctx.cos, ctx.sin, ctx.pos,
-                                       self.head_dim, 2 * E)
-            q, k, v = (qkv[:, i * E:(i + 1) * E].view(T, self.num_heads, self.head_dim) for i in range(3))
+        H, d = self.num_heads, self.head_dim
+        rot_fusable = (self.rot_emb is not None and ctx is not None and not self.pre_layernorm
+                       and d in (16, 32, 64) and E % 32 == 0)
+        rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
+        if x_stats is not None:
+            wf, c1, c2 = self._pack_fold()
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, c1, c2), rot=rot)
         else:
-            q, k, v = self._qkv(x, lora_names)
-            if self.rot_emb is not None:
-                if ctx is not None:
-                    _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, self.num_heads)
-                else:
-                    q, k = self.rot_emb(q, k, cu_lens, max_len)
+            self._pack()
+            qkv = _hip.gemm_fused(self.norm(x), self._qkv_w, self._qkv_b, rot=rot)
+        q, k, v = self._split_qkv(qkv)                      # ESM-C: q/k LayerNorm in place
+        if self.rot_emb is not None and rot is None:
+            if ctx is not None:
+                _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
+            else:
+                q, k = self.rot_emb(q, k, cu_lens, max_len)
         a = self._attn(q, k, v, cu_lens, max_len)
         if resid is not None:
-            return self.out(a, _hip.EPI_RESIDUAL, resid, alpha, out)
+            return _hip.gemm_fused(a, self.out.weight, self.out.bias, _hip.EPI_RESIDUAL, resid, alpha, out,
+                                   stats_out=stats_out)
         return self.out(a, out=out)
 
 
@@ -163,9 +207,9 @@ class SwiGLU(nn.Module):
             self._packed = torch.cat((g, f), dim=1).reshape(2 * F, E).contiguous()
         self._pack_key = key
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, ln=None, packed=None):
         self._pack()
-        return _hip.gemm(x, self._packed, None, _hip.EPI_SWIGLU, out=out)
+        return _hip.gemm_fused(x, self._packed if packed is None else packed, None, _hip.EPI_SWIGLU, out=out, ln=ln)
 
 
 class FlashTransformerLayer(nn.Module):
@@ -189,20 +233,64 @@ class FlashTransformerLayer(nn.Module):
         else:
             raise ValueError('Invalid final activation function. Must be "swiglu" or "gelu".')
         self.final_activation = final_activation
+        self._fold = None
+        self._fold_key = None
 
-    def _ffn(self, x, resid, alpha, out):
-        h = self.final[0](x)
+    def _pack_fold(self):
+        """LN-folded copy of the FFN up-projection weight (self.final[0] folded in)."""
+        ln = self.final[0]
+        beta = ln.bias.data if ln.bias is not None else None
         if self.final_activation == 'gelu':
-            u = self.final[1](h, _hip.EPI_GELU)
-            return self.final[3](u, _hip.EPI_RESIDUAL, resid, alpha, out)
-        u = self.final[1](h)
-        return self.final[2](u, _hip.EPI_RESIDUAL, resid, alpha, out)
+            up = self.final[1]
+            key = _version_key(up.weight, up.bias, ln.weight, ln.bias)
+            if key != self._fold_key:
+                with torch.no_grad():
+                    self._fold = _fold_layernorm(up.weight.data, up.bias.data if up.bias is not None else None,
+                                                 ln.weight.data, beta)
+                self._fold_key = key
+        else:
+            sw = self.final[1]
+            sw._pack()
+            key = (sw._pack_key, _version_key(ln.weight, ln.bias))
+            if key != self._fold_key:
+                with torch.no_grad():
+                    self._fold = _fold_layernorm(sw._packed, None, ln.weight.data, beta)
+                self._fold_key = key
+        return self._fold
+
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None):
+        down = self.final[3] if self.final_activation == 'gelu' else self.final[2]
+        if x_stats is not None:
+            wf, c1, c2 = self._pack_fold()
+            if self.final_activation == 'gelu':
+                u = _hip.gemm_fused(x, wf, None, _hip.EPI_GELU, ln=(x_stats, c1, c2))
+            else:
+                u = self.final[1](x, ln=(x_stats, c1, c2), packed=wf)
+        else:
+            h = self.final[0](x)
+            u = self.final[1](h, _hip.EPI_GELU) if self.final_activation == 'gelu' else self.final[1](h)
+        return _hip.gemm_fused(u, down.weight, down.bias, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 inplace: bool = False):
         """x + attn(x)/s, then x + ffn(x)/s (reference attention.py:253-255); both adds
-        and the 1/s scale live in GEMM epilogues.  `inplace=True` overwrites x."""
+        and the 1/s scale live in GEMM epilogues.  `inplace=True` overwrites x.  With a
+        folding context (`ctx.fold`) the LayerNorms are folded into the QKV / FFN-up GEMMs
+        and their statistics ride on the residual GEMMs' epilogues."""
         alpha = 1.0 / self.residue_scaling
         y = x if inplace else torch.empty_like(x)
+        T, E = x.shape
+        if ctx is not None and ctx.fold and E % 64 == 0:
+            eps = self.self_attn.norm.eps
+            if ctx.stats is None:                               # first layer: statistics straight from x
+                ctx.stats = _hip.row_stats(x, eps)
+                ctx.stats_next = torch.empty_like(ctx.stats)
+                ctx.partial = torch.empty(E // 64, T, 2, dtype=torch.float32, device=x.device)
+            self.self_attn(x, cu_lens, max_len, lora_names, ctx, resid=x, alpha=alpha, out=y,
+                           x_stats=ctx.stats, stats_out=ctx.partial)
+            mid = _hip.ln_stats_reduce(ctx.partial, T, E, self.final[0].eps, out=ctx.stats_next)
+            self._ffn(y, y, alpha, y, x_stats=mid, stats_out=ctx.partial)
+            _hip.ln_stats_reduce(ctx.partial, T, E, eps, out=ctx.stats)   # statistics of the layer output
+            return y
         self.self_attn(x, cu_lens, max_len, lora_names, ctx, resid=x, alpha=alpha, out=y)
         return self._ffn(y, y, alpha, y)

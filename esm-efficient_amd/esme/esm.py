@@ -60,6 +60,7 @@ class ESM2(nn.Module):
     alphabet = Alphabet
     vocab_size = 33
     zero_mask_rows = True          # `<mask>` embedding rows are zeroed (esm.py:189)
+    fold_layernorm = os.environ.get('ESME_NO_LN_FOLD', '0') != '1'   # LN folded into the QKV / FFN-up GEMMs
 
     def __init__(self, num_layers: int = 33, embed_dim: int = 1280, attention_heads: int = 20,
                  checkpointing: bool = False, rotary_embedding: bool = True, dropout: float = 0.,
@@ -106,7 +107,7 @@ class ESM2(nn.Module):
         cos = sin = None
         if rot is not None:
             cos, sin = rot.tables(int(max_len), device, torch.bfloat16)
-        return ForwardContext(pos, cos, sin)
+        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm)
 
     def _unpad(self, x, tokens):
         """Boolean-mask row gather: the `unpad_input` contract (esm.py:238)."""

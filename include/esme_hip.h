@@ -111,6 +111,46 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
                              const void* sin, const int32_t* pos, int head_dim, int max_len,
                              int rot_cols, void* stream);
 
+/* Optional fusions of esme_hip_gemm_bf16_fused (any subset; zero-initialise the struct):
+ *  - rotary:   head_dim in {16,32,64} != 0 -> as esme_hip_gemm_qkv_rotary (ESME_EPI_NONE only);
+ *  - LN fold:  ln_stats != NULL -> the GEMM consumes the RAW residual stream x with gamma-scaled
+ *              weights W' = W*diag(gamma) and finishes LayerNorm(x) W^T + b in its epilogue:
+ *              y[m,n] = rstd[m]*acc[m,n] - (rstd*mean)[m]*c1[n] + c2[n],
+ *              ln_stats = float (M,2) {rstd, rstd*mean}, c1[n] = sum_k W'[n,k],
+ *              c2[n] = sum_k beta[k] W[n,k] + bias[n]  (float, N each; `bias` is ignored).
+ *              Replaces the nn.LayerNorm in front of q/k/v (esme/attention.py:75,92) and of the FFN
+ *              (esme/attention.py:222,230) without writing or reading a normalised copy of x;
+ *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per 64-column block, the sum and sum
+ *              of squares of the bf16-ROUNDED output, float (N/64, M, 2): what the next
+ *              LayerNorm's statistics are reduced from (esme_hip_ln_stats_reduce). */
+typedef struct esme_gemm_fusion {
+    const float* ln_stats;
+    const float* ln_c1;
+    const float* ln_c2;
+    float* stats_out;
+    const void* cos;
+    const void* sin;
+    const int32_t* pos;
+    int head_dim;
+    int max_len;
+    int rot_cols;
+} esme_gemm_fusion_t;
+
+int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias,
+                             const void* resid, int64_t ldr, void* C, int64_t ldc, int64_t M, int N,
+                             int K, int epilogue, float alpha, const esme_gemm_fusion_t* fusion,
+                             void* stream);
+
+/* LayerNorm statistics as the LN-folding GEMMs consume them: stats[m] = {rstd, rstd*mean} with
+ * mean/var over the last dim E (biased variance, eps inside the sqrt), fp32.
+ *  - esme_hip_row_stats: straight from a (T, E) bf16 tensor (one pass over x);
+ *  - esme_hip_ln_stats_reduce: from the (nblk, T, 2) partial sums a residual-epilogue GEMM emitted
+ *    (nblk = E/64).  Replaces the statistics half of nn.LayerNorm (esme/attention.py:75,222,230). */
+int esme_hip_row_stats(const void* x, int64_t ldx, int64_t T, int E, float eps, float* stats,
+                       void* stream);
+int esme_hip_ln_stats_reduce(const float* partial, int nblk, int64_t T, int E, float eps,
+                             float* stats, void* stream);
+
 /* y = softmax(x) or log_softmax(x) over the last dim V <= 64 (fp32 inside, bf16 out).
  * Replaces: torch.log_softmax / torch.softmax at esme/esm.py:297-298,315-317. */
 int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t T, int V,
