@@ -318,27 +318,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     for (int g = 0; g < 4; ++g) bq[i][g] = u32x2{0u, 0u};
             }
         }
-        u32x2 rq[EPI == ESME_EPI_RESIDUAL ? FN : 1][EPI == ESME_EPI_RESIDUAL ? 4 : 1][EPI == ESME_EPI_RESIDUAL ? FM : 1];
+        // Residual tile: fetched with the LDS-DMA in whole 128-B lines straight into this wave's
+        // slab (same XOR-swizzled layout the results use, swizzle applied on the global source
+        // address), then read back per accumulator quad -- instead of 8-B loads scattered over 32
+        // rows per instruction (measured ~20 us per tile for the scattered form).
         if constexpr (EPI == ESME_EPI_RESIDUAL) {
 #pragma unroll
-            for (int j = 0; j < FM; ++j) {
-                int64_t m = mw0 + j * 32 + l31;
+            for (int it = 0; it < WTM / 8; ++it) {
+                const int r = it * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (r & 7);
+                int64_t m = mw0 + r;
                 m = m < a.M ? m : a.M - 1;
-                const u16* rrow = a.resid + m * a.ldr;
-#pragma unroll
-                for (int i = 0; i < FN; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        int n = nw0 + i * 32 + 8 * g + 4 * hi;
-                        n = n < a.N - 4 ? n : a.N - 4;
-                        rq[i][g][j] = *reinterpret_cast<const u32x2*>(rrow + n);
-                    }
+                int n = nw0 + c * 8;
+                n = n < a.N - 8 ? n : a.N - 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.resid + m * a.ldr + n), (lptr_t)(slab + it * 1024), 16, 0, 0);
             }
-        }
-        float s1[STATS ? FM : 1], s2[STATS ? FM : 1];
-        if constexpr (STATS) {
-#pragma unroll
-            for (int j = 0; j < FM; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int i = 0; i < FNE; ++i) {
@@ -367,30 +363,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                             for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
                         }
                         if constexpr (EPI == ESME_EPI_RESIDUAL) {
-                            const u32x2 rw = rq[i][g][j];
+                            const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3));
                             o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
                             o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
                         }
                     }
                     u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
                     *reinterpret_cast<u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3)) = pk;
-                    if constexpr (STATS) {                      // statistics of what the next LayerNorm will read
-                        const float v0 = bf_lo(pk[0]), v1 = bf_hi(pk[0]), v2 = bf_lo(pk[1]), v3 = bf_hi(pk[1]);
-                        s1[j] += (v0 + v1) + (v2 + v3);
-                        s2[j] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-                    }
                 }
-            }
-        }
-        if constexpr (STATS) {
-            const int cwb = (n0 + wn * WTN) >> 6;                   // 64-column block index of this wave
-            if (n0 + wn * WTN < a.N) {
-#pragma unroll
-                for (int j = 0; j < FM; ++j) {
-                    const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64), t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-                    const int64_t m = mw0 + j * 32 + l31;
-                    if (hi == 0 && m < a.M) *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)cwb * a.M + m)) = f32x2{t1, t2};
-                }
+                if constexpr (EPI == ESME_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later quads from being hoisted (VGPRs)
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -403,6 +384,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int64_t m = mw0 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (m < a.M) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+                if constexpr (STATS) {
+                    // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
+                    // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine.
+                    float f[8];
+                    unpack8(v, f);
+                    float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                    float t2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) +
+                               ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
+#pragma unroll
+                    for (int o = 1; o < CH; o <<= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+                    if (ch == 0 && m < a.M)
+                        *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)((n0 + wn * WTN) >> 6) * a.M + m)) = f32x2{t1, t2};
+                }
             }
         }
         return;
@@ -523,7 +517,7 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
     int vec_ok = (ldc % 8 == 0) && aligned16(C) && (n_out % 8 == 0) && N >= 8;
     if (epilogue == ESME_EPI_RESIDUAL) {
         ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
-        vec_ok = vec_ok && (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(resid) & 7u) == 0;
+        vec_ok = vec_ok && (ldr % 8 == 0) && aligned16(resid) && N >= 8;
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
