@@ -51,6 +51,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// value of another lane through a DPP control (0xB1 = quad_perm[1,0,3,2], 0x4E = quad_perm[2,3,0,1],
+// 0x141 = row_half_mirror): a VALU-rate cross-lane move, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 // erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)) -- the form the reference uses (nn.GELU() /
 // F.gelu default: attention.py:233, head.py:26), NOT the tanh approximation.  erf is evaluated
 // with Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7 + fp32 round-off; measured max |gelu

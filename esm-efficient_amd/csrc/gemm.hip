@@ -39,8 +39,9 @@ struct GemmArgs {
     int nt_store;                // (unused; kept for the tuning hook)
     int stagger;                 // first-wave start skew (units of ~1024 cycles across the 256 first blocks)
     // LayerNorm folded into the consumer GEMM (W already scaled by gamma):
-    //   y = rstd[m]*acc - (rstd*mean)[m]*c1[n] + c2[n],  ln_stats = (rstd, rstd*mean) per row
-    const float* ln_stats; const float* ln_c1; const float* ln_c2;
+    //   y = rstd[m]*acc - (rstd*mean)[m]*c1[n] + c2[n];  mean/rstd of row m are reduced in-kernel from
+    //   ln_partial (ln_nblk, M, 2): per-block (sum, sum of squares) over ln_dim features
+    const float* ln_partial; int ln_nblk; int ln_dim; float ln_eps; const float* ln_c1; const float* ln_c2;
     // residual epilogue also emits per-row partial (sum, sum of squares) of the ROUNDED output
     // over each 64-column block: stats_out[(n/64) * M + m] (float2) -> next LayerNorm's statistics
     float* stats_out;
@@ -55,7 +56,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
-    static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN)), "row statistics are emitted by the residual epilogue");
+    static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64), "row statistics are emitted by the residual epilogue");
     static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
                   "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
     constexpr int NW = WM * WN;               // waves per block
@@ -176,7 +177,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     };
     static_assert(IA % 2 == 0 && IW % 2 == 0, "stage_half splits the per-thread chunks in two");
     stage(0, 0);
-    __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier
+    // ---- folded LayerNorm: reduce this tile's 256 row statistics from the producer's partial sums
+    // once per block, right after K-tile 0's LDS-DMA is issued (the loads overlap its latency), and park {rstd, rstd*mean} in
+    // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
+    f32x2* lnst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);
+    if constexpr (LNF) {
+        if (tid < BM) {
+            int64_t m = m0 + tid;
+            m = m < a.M ? m : a.M - 1;
+            float s1 = 0.f, s2 = 0.f;
+            const f32x2* pp = reinterpret_cast<const f32x2*>(a.ln_partial) + m;
+            int b = 0;
+            for (; b + 10 <= a.ln_nblk; b += 10) {            // 10 independent loads in flight, not a serial latency chain
+                f32x2 p[10];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.M];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
+            }
+            for (; b + 4 <= a.ln_nblk; b += 4) {
+                const f32x2 p0 = pp[(int64_t)b * a.M], p1 = pp[(int64_t)(b + 1) * a.M];
+                const f32x2 p2 = pp[(int64_t)(b + 2) * a.M], p3 = pp[(int64_t)(b + 3) * a.M];
+                s1 += (p0[0] + p1[0]) + (p2[0] + p3[0]);
+                s2 += (p0[1] + p1[1]) + (p2[1] + p3[1]);
+            }
+            for (; b < a.ln_nblk; ++b) {
+                const f32x2 p = pp[(int64_t)b * a.M];
+                s1 += p[0]; s2 += p[1];
+            }
+            const float inv = 1.0f / (float)a.ln_dim;
+            const float mean = s1 * inv;
+            const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
+            lnst[tid] = f32x2{rstd, rstd * mean};
+        }
+    }
+
+    __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier; publishes the LN strip
     Frag f0, f1;
     rd(f0, smem, 0);
     for (int kt = 0; kt < KT; ++kt) {
@@ -227,11 +263,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const int nrow0 = n0 + wn * WTN;                          // packed weight row of the wave's first column
         f32x2 st[FM];
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            int64_t m = mw0 + j * 32 + l31;
-            m = m < a.M ? m : a.M - 1;
-            st[j] = *reinterpret_cast<const f32x2*>(a.ln_stats + 2 * m);
-        }
+        for (int j = 0; j < FM; ++j) st[j] = lnst[wm * WTM + j * 32 + l31];
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -392,8 +424,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
                     float t2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) +
                                ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
-#pragma unroll
-                    for (int o = 1; o < CH; o <<= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+                    // 8 consecutive lanes hold one row: two quad_perm DPP steps + row_half_mirror
+                    t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);      // lane ^ 1
+                    t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);      // lane ^ 2
+                    t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);    // lane -> 7 - lane (other quad)
                     if (ch == 0 && m < a.M)
                         *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)((n0 + wn * WTN) >> 6) * a.M + m)) = f32x2{t1, t2};
                 }
@@ -454,12 +488,12 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = 2 * (BM + BN) * 128 + (LNF ? BM * 8 : 0);
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS>;
-    if (smem > 64 * 1024) {
+    if (smem >= 64 * 1024) {
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); once = true; }
     }
@@ -521,7 +555,7 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
-               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger, nullptr, nullptr, nullptr, nullptr};
+               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr};
     int rotd = 0;
     bool lnf = false, stats = false;
     if (fu) {
@@ -537,12 +571,14 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
             a.max_len = fu->max_len; a.rot_cols = fu->rot_cols;
             rotd = fu->head_dim;
         }
-        if (fu->ln_stats) {                                          // LayerNorm folded into this GEMM
+        if (fu->ln_partial) {                                        // LayerNorm folded into this GEMM
             ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL, "gemm: LN fold does not combine with the residual epilogue");
             ESME_CHECK_ARG(fu->ln_c1 && fu->ln_c2 && aligned16(fu->ln_c1) && aligned16(fu->ln_c2) &&
-                           (reinterpret_cast<uintptr_t>(fu->ln_stats) & 7u) == 0, "gemm: LN fold needs 16-byte aligned c1, c2 and 8-byte aligned stats");
+                           (reinterpret_cast<uintptr_t>(fu->ln_partial) & 7u) == 0 && fu->ln_nblk > 0 && fu->ln_dim > 0,
+                           "gemm: LN fold needs 16-byte aligned c1, c2, 8-byte aligned partial sums, ln_nblk > 0, ln_dim > 0");
             if (N % 4 != 0 || !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: LN fold needs N % 4 == 0 and 16-byte addressable C");
-            a.ln_stats = fu->ln_stats; a.ln_c1 = fu->ln_c1; a.ln_c2 = fu->ln_c2;
+            a.ln_partial = fu->ln_partial; a.ln_nblk = fu->ln_nblk; a.ln_dim = fu->ln_dim; a.ln_eps = fu->ln_eps;
+            a.ln_c1 = fu->ln_c1; a.ln_c2 = fu->ln_c2;
             lnf = true;
         }
         if (fu->stats_out) {                                         // emit row statistics for the next LayerNorm

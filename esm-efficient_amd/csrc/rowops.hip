@@ -97,10 +97,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
 }
 
 // ------------------------------------------------------- LayerNorm statistics
-// stats[row] = {rstd, rstd*mean}: one wave per row straight from x ...
+// sums[row] = {sum x, sum x^2}: one wave per row (the first layer's input; later layers get
+// their statistics from the residual GEMM epilogues)
 template <int NCH>
-__global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ x, int64_t ldx, int64_t T, int E,
-                                                        float eps, f32x2* __restrict__ stats) {
+__global__ __launch_bounds__(256) void row_sums_kernel(const u16* __restrict__ x, int64_t ldx, int64_t T, int E,
+                                                       f32x2* __restrict__ sums) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -117,25 +118,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const u16* __restrict__ 
         }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    const float mean = s1 / (float)E;
-    const float var = fmaxf(s2 / (float)E - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    if (lane == 0) stats[row] = f32x2{rstd, rstd * mean};
-}
-// ... or from the per-64-column-block partial sums a residual-epilogue GEMM emitted
-__global__ __launch_bounds__(256) void ln_stats_reduce_kernel(const f32x2* __restrict__ partial, int nblk, int64_t T,
-                                                              int E, float eps, f32x2* __restrict__ stats) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= T) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const f32x2 p = partial[(int64_t)b * T + row];
-        s1 += p[0]; s2 += p[1];
-    }
-    const float mean = s1 / (float)E;
-    const float var = fmaxf(s2 / (float)E - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    stats[row] = f32x2{rstd, rstd * mean};
+    if (lane == 0) sums[row] = f32x2{s1, s2};
 }
 
 // ------------------------------------------------------------------- rotary
@@ -258,33 +241,22 @@ extern "C" int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, con
     return check_launch("layernorm");
 }
 
-extern "C" int esme_hip_row_stats(const void* x, int64_t ldx, int64_t T, int E, float eps, float* stats, void* stream) {
-    ESME_CHECK_ARG(T >= 0 && E > 0, "row_stats: bad sizes");
+extern "C" int esme_hip_row_sums(const void* x, int64_t ldx, int64_t T, int E, float* sums, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "row_sums: bad sizes");
     if (T == 0) return ESME_OK;
-    ESME_CHECK_ARG(x && stats && E % 8 == 0 && ldx % 8 == 0 && ldx >= E && aligned16(x) &&
-                   (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "row_stats: null/misaligned pointer or E, ldx not multiples of 8");
+    ESME_CHECK_ARG(x && sums && E % 8 == 0 && ldx % 8 == 0 && ldx >= E && aligned16(x) &&
+                   (reinterpret_cast<uintptr_t>(sums) & 7u) == 0, "row_sums: null/misaligned pointer or E, ldx not multiples of 8");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_RS(N) hipLaunchKernelGGL(row_stats_kernel<N>, grid, block, 0, s, (const u16*)x, ldx, T, E, eps, (f32x2*)stats)
+#define ESME_RS(N) hipLaunchKernelGGL(row_sums_kernel<N>, grid, block, 0, s, (const u16*)x, ldx, T, E, (f32x2*)sums)
     if (E <= 512) ESME_RS(1);
     else if (E <= 1024) ESME_RS(2);
     else if (E <= 1536) ESME_RS(3);
     else if (E <= 2560) ESME_RS(5);
     else if (E <= 5120) ESME_RS(10);
-    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "row_stats: E > 5120 unsupported");
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "row_sums: E > 5120 unsupported");
 #undef ESME_RS
-    return check_launch("row_stats");
-}
-
-extern "C" int esme_hip_ln_stats_reduce(const float* partial, int nblk, int64_t T, int E, float eps, float* stats,
-                                        void* stream) {
-    ESME_CHECK_ARG(T >= 0 && nblk > 0 && E > 0, "ln_stats_reduce: bad sizes");
-    if (T == 0) return ESME_OK;
-    ESME_CHECK_ARG(partial && stats && (reinterpret_cast<uintptr_t>(partial) & 7u) == 0 &&
-                   (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, "ln_stats_reduce: null/misaligned pointer");
-    hipLaunchKernelGGL(ln_stats_reduce_kernel, dim3((unsigned int)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const f32x2*)partial, nblk, T, E, eps, (f32x2*)stats);
-    return check_launch("ln_stats_reduce");
+    return check_launch("row_sums");
 }
 
 extern "C" int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,

@@ -23,7 +23,7 @@ EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
 class GemmFusion(Structure):
     """esme_gemm_fusion_t (include/esme_hip.h)."""
-    _fields_ = [('ln_stats', c_void_p), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
+    _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int)]
 
@@ -46,8 +46,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'esme_hip_gemm_bf16_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, POINTER(GemmFusion), c_void_p]),
-    'esme_hip_row_stats': (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p]),
-    'esme_hip_ln_stats_reduce': (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
+    'esme_hip_row_sums': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
@@ -265,7 +264,7 @@ def gemm_qkv_rotary(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None) -> torch.Tensor:
-    """esme_hip_gemm_bf16_fused.  `ln` = (stats (M,2) f32, c1 (N,) f32, c2 (N,) f32) folds the
+    """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (N/64, M, 2) f32 receives per-row partial sums of the rounded output (residual
     epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue)."""
@@ -286,11 +285,11 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     fu = GemmFusion()
     tag = epilogue
     if ln is not None:
-        st, c1, c2 = ln
-        if st.shape != (M, 2) or c1.numel() != N or c2.numel() != N:
+        part, dim, eps, c1, c2 = ln
+        if part.dim() != 3 or part.shape[1] != M or part.shape[2] != 2 or c1.numel() != N or c2.numel() != N or not part.is_contiguous():
             raise ValueError('gemm: LN-fold tensors have the wrong shape')
-        fu.ln_stats, fu.ln_c1, fu.ln_c2 = (_dev(st, 'ln stats', torch.float32), _dev(c1, 'ln c1', torch.float32),
-                                           _dev(c2, 'ln c2', torch.float32))
+        fu.ln_partial, fu.ln_nblk, fu.ln_dim, fu.ln_eps = _dev(part, 'ln partial', torch.float32), part.shape[0], int(dim), float(eps)
+        fu.ln_c1, fu.ln_c2 = _dev(c1, 'ln c1', torch.float32), _dev(c2, 'ln c2', torch.float32)
     if stats_out is not None:
         if stats_out.numel() < (N // 64) * M * 2 or not stats_out.is_contiguous():
             raise ValueError('gemm: stats_out must be a contiguous (N/64, M, 2) float32 buffer')
@@ -308,24 +307,15 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
-def row_stats(x: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(T, 2) float32 {rstd, rstd*mean} of each row of a (T, E) bf16 tensor."""
-    xp, ldx = _rows2d(x, 'row_stats x')
+def row_sums(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(1, T, 2) float32 {sum x, sum x^2} per row of a (T, E) bf16 tensor: the ln_nblk = 1 form of
+    the partial sums the LN-folding GEMMs consume."""
+    xp, ldx = _rows2d(x, 'row_sums x')
     T, E = x.shape
     if out is None:
-        out = torch.empty(T, 2, dtype=torch.float32, device=x.device)
+        out = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
     with _Traced('ln_stats', (T, E)):
-        _check(load().esme_hip_row_stats(xp, ldx, T, E, eps, _dev(out, 'stats', torch.float32), _stream()), 'esme_hip_row_stats')
-    return out
-
-
-def ln_stats_reduce(partial: torch.Tensor, T: int, E: int, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Reduce the (E/64, T, 2) partial sums a residual-epilogue GEMM emitted to (T, 2) {rstd, rstd*mean}."""
-    if out is None:
-        out = torch.empty(T, 2, dtype=torch.float32, device=partial.device)
-    with _Traced('ln_stats', (T, E)):
-        _check(load().esme_hip_ln_stats_reduce(_dev(partial, 'partial', torch.float32), E // 64, T, E, eps,
-                                               _dev(out, 'stats', torch.float32), _stream()), 'esme_hip_ln_stats_reduce')
+        _check(load().esme_hip_row_sums(xp, ldx, T, E, _dev(out, 'sums', torch.float32), _stream()), 'esme_hip_row_sums')
     return out
 
 

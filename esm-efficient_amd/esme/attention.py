@@ -37,14 +37,14 @@ from esme.rotary import RotaryEmbedding
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'stats', 'stats_next', 'partial', 'fold')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold')
 
     def __init__(self, pos, cos, sin, fold=False):
         self.pos, self.cos, self.sin = pos, cos, sin
         self.fold = fold            # run the LN-folded fast path
-        self.stats = None           # (T, 2) f32 {rstd, rstd*mean} of the current residual stream
-        self.stats_next = None      # spare (T, 2) buffer (ping-pong)
-        self.partial = None         # (E/64, T, 2) f32 partial sums written by the residual GEMMs
+        self.sums = None            # partial sums (nblk, T, 2) f32 describing the current residual stream
+        self.part_a = None          # (E/64, T, 2) f32 buffers the residual GEMMs write their row sums to
+        self.part_b = None
 
 
 def _version_key(*params):
@@ -153,7 +153,7 @@ class FlashMultiheadAttention(nn.Module):
                 resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
         resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid).
-        `x_stats` ((T, 2) f32 row statistics of x) selects the LN-folded projection;
+        `x_stats` ((nblk, T, 2) f32 partial row sums of x) selects the LN-folded projection;
         `stats_out` makes the out-projection emit the statistics of its output."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
         T, E = x.shape
@@ -163,7 +163,7 @@ class FlashMultiheadAttention(nn.Module):
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
         if x_stats is not None:
             wf, c1, c2 = self._pack_fold()
-            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, c1, c2), rot=rot)
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, E, self.norm.eps, c1, c2), rot=rot)
         else:
             self._pack()
             qkv = _hip.gemm_fused(self.norm(x), self._qkv_w, self._qkv_b, rot=rot)
@@ -263,9 +263,9 @@ class FlashTransformerLayer(nn.Module):
         if x_stats is not None:
             wf, c1, c2 = self._pack_fold()
             if self.final_activation == 'gelu':
-                u = _hip.gemm_fused(x, wf, None, _hip.EPI_GELU, ln=(x_stats, c1, c2))
+                u = _hip.gemm_fused(x, wf, None, _hip.EPI_GELU, ln=(x_stats, x.shape[1], self.final[0].eps, c1, c2))
             else:
-                u = self.final[1](x, ln=(x_stats, c1, c2), packed=wf)
+                u = self.final[1](x, ln=(x_stats, x.shape[1], self.final[0].eps, c1, c2), packed=wf)
         else:
             h = self.final[0](x)
             u = self.final[1](h, _hip.EPI_GELU) if self.final_activation == 'gelu' else self.final[1](h)
@@ -281,16 +281,14 @@ class FlashTransformerLayer(nn.Module):
         y = x if inplace else torch.empty_like(x)
         T, E = x.shape
         if ctx is not None and ctx.fold and E % 64 == 0:
-            eps = self.self_attn.norm.eps
-            if ctx.stats is None:                               # first layer: statistics straight from x
-                ctx.stats = _hip.row_stats(x, eps)
-                ctx.stats_next = torch.empty_like(ctx.stats)
-                ctx.partial = torch.empty(E // 64, T, 2, dtype=torch.float32, device=x.device)
+            if ctx.sums is None:                                # first layer: row sums straight from x
+                ctx.sums = _hip.row_sums(x)
+                ctx.part_a = torch.empty(E // 64, T, 2, dtype=torch.float32, device=x.device)
+                ctx.part_b = torch.empty_like(ctx.part_a)
             self.self_attn(x, cu_lens, max_len, lora_names, ctx, resid=x, alpha=alpha, out=y,
-                           x_stats=ctx.stats, stats_out=ctx.partial)
-            mid = _hip.ln_stats_reduce(ctx.partial, T, E, self.final[0].eps, out=ctx.stats_next)
-            self._ffn(y, y, alpha, y, x_stats=mid, stats_out=ctx.partial)
-            _hip.ln_stats_reduce(ctx.partial, T, E, eps, out=ctx.stats)   # statistics of the layer output
+                           x_stats=ctx.sums, stats_out=ctx.part_b)
+            self._ffn(y, y, alpha, y, x_stats=ctx.part_b, stats_out=ctx.part_a)
+            ctx.sums = ctx.part_a                               # row sums of the layer output
             return y
         self.self_attn(x, cu_lens, max_len, lora_names, ctx, resid=x, alpha=alpha, out=y)
         return self._ffn(y, y, alpha, y)

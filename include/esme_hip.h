@@ -113,18 +113,23 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
 
 /* Optional fusions of esme_hip_gemm_bf16_fused (any subset; zero-initialise the struct):
  *  - rotary:   head_dim in {16,32,64} != 0 -> as esme_hip_gemm_qkv_rotary (ESME_EPI_NONE only);
- *  - LN fold:  ln_stats != NULL -> the GEMM consumes the RAW residual stream x with gamma-scaled
+ *  - LN fold:  ln_partial != NULL -> the GEMM consumes the RAW residual stream x with gamma-scaled
  *              weights W' = W*diag(gamma) and finishes LayerNorm(x) W^T + b in its epilogue:
  *              y[m,n] = rstd[m]*acc[m,n] - (rstd*mean)[m]*c1[n] + c2[n],
- *              ln_stats = float (M,2) {rstd, rstd*mean}, c1[n] = sum_k W'[n,k],
- *              c2[n] = sum_k beta[k] W[n,k] + bias[n]  (float, N each; `bias` is ignored).
+ *              c1[n] = sum_k W'[n,k], c2[n] = sum_k beta[k] W[n,k] + bias[n] (float, N each; `bias`
+ *              is ignored).  mean/rstd of row m (biased variance over ln_dim features, ln_eps inside
+ *              the sqrt) are reduced in-kernel from ln_partial, float (ln_nblk, M, 2): per-block
+ *              {sum, sum of squares} as emitted by stats_out / esme_hip_row_sums (ln_nblk = 1).
  *              Replaces the nn.LayerNorm in front of q/k/v (esme/attention.py:75,92) and of the FFN
  *              (esme/attention.py:222,230) without writing or reading a normalised copy of x;
  *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per 64-column block, the sum and sum
  *              of squares of the bf16-ROUNDED output, float (N/64, M, 2): what the next
- *              LayerNorm's statistics are reduced from (esme_hip_ln_stats_reduce). */
+ *              LN-folding GEMM reduces its row statistics from. */
 typedef struct esme_gemm_fusion {
-    const float* ln_stats;
+    const float* ln_partial;
+    int ln_nblk;
+    int ln_dim;
+    float ln_eps;
     const float* ln_c1;
     const float* ln_c2;
     float* stats_out;
@@ -141,15 +146,10 @@ int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const vo
                              int K, int epilogue, float alpha, const esme_gemm_fusion_t* fusion,
                              void* stream);
 
-/* LayerNorm statistics as the LN-folding GEMMs consume them: stats[m] = {rstd, rstd*mean} with
- * mean/var over the last dim E (biased variance, eps inside the sqrt), fp32.
- *  - esme_hip_row_stats: straight from a (T, E) bf16 tensor (one pass over x);
- *  - esme_hip_ln_stats_reduce: from the (nblk, T, 2) partial sums a residual-epilogue GEMM emitted
- *    (nblk = E/64).  Replaces the statistics half of nn.LayerNorm (esme/attention.py:75,222,230). */
-int esme_hip_row_stats(const void* x, int64_t ldx, int64_t T, int E, float eps, float* stats,
-                       void* stream);
-int esme_hip_ln_stats_reduce(const float* partial, int nblk, int64_t T, int E, float eps,
-                             float* stats, void* stream);
+/* sums[t] = {sum_e x[t,e], sum_e x[t,e]^2} (fp32) of a (T, E) bf16 tensor: the one-block form of
+ * the partial sums the LN-folding GEMMs consume (ln_nblk = 1), used for the first layer's input.
+ * Replaces the statistics half of nn.LayerNorm (esme/attention.py:75). */
+int esme_hip_row_sums(const void* x, int64_t ldx, int64_t T, int E, float* sums, void* stream);
 
 /* y = softmax(x) or log_softmax(x) over the last dim V <= 64 (fp32 inside, bf16 out).
  * Replaces: torch.log_softmax / torch.softmax at esme/esm.py:297-298,315-317. */

@@ -205,6 +205,58 @@ def test_gemm_qkv_rotary_fused(lengths, H, d, tile):
     check(got[:, 2 * E:], ref[:, 2 * E:], what='fused rotary v (untouched)')
 
 
+@pytest.mark.parametrize('M,N,K,epi', [(300, 3840, 1280, 'none'), (513, 2560, 640, 'gelu'), (77, 960, 320, 'none'),
+                                         (1000, 1024, 128, 'swiglu')])
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_layernorm_fold_and_row_sums(M, N, K, epi, tile):
+    """LN folded into the consumer GEMM == LayerNorm kernel math followed by the plain GEMM, with the
+    row statistics coming from (a) esme_hip_row_sums and (b) the partial sums a residual-epilogue
+    GEMM emitted for the same tensor."""
+    from esme import _hip
+    from esme.attention import _fold_layernorm
+    x = rnd((M, K), 60, 2.0) + 0.3
+    gamma = (1 + 0.1 * rnd((K,), 61).float()).to(torch.bfloat16)
+    beta = rnd((K,), 62, 0.1)
+    w, b = rnd((N, K), 63, 1 / math.sqrt(K)), rnd((N,), 64, 0.1)
+    h = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+    if epi == 'swiglu':
+        F = N // 2
+        lin_a = h @ w[:F].float().T
+        lin_f = h @ w[F:].float().T
+        ref = torch.nn.functional.silu(lin_a) * lin_f
+        wp = torch.cat((w[:F].view(F // 32, 1, 32, K), w[F:].view(F // 32, 1, 32, K)), 1).reshape(N, K).contiguous()
+        wf, c1, c2 = _fold_layernorm(wp.to(dev()), None, gamma.to(dev()), beta.to(dev()))
+        code = _hip.EPI_SWIGLU
+    else:
+        lin = h @ w.float().T + b.float()
+        ref = torch.nn.functional.gelu(lin) if epi == 'gelu' else lin
+        wf, c1, c2 = _fold_layernorm(w.to(dev()), b.to(dev()), gamma.to(dev()), beta.to(dev()))
+        code = _hip.EPI_GELU if epi == 'gelu' else _hip.EPI_NONE
+    xg = x.to(dev())
+    _hip.load().esme_hip_debug_set_gemm_tile(tile)
+    try:
+        sums = _hip.row_sums(xg)
+        ref_s = torch.stack((x.float().sum(1), (x.float() ** 2).sum(1)), 1)
+        assert torch.allclose(sums[0].cpu(), ref_s, rtol=1e-5, atol=1e-3)
+        got = _hip.gemm_fused(xg, wf, None, code, ln=(sums, K, 1e-5, c1, c2))
+        # W' = bf16(W*gamma) is rounded once more than the unfused path: 2^-6 relative on top of bf16 output rounding
+        # (SwiGLU multiplies two such projections: their relative errors add)
+        tol = 2.0 ** -5 if epi == 'swiglu' else 2.0 ** -6
+        check(got, ref, rtol=tol, atol_scale=tol, what=f'LN-fold gemm {epi}')
+        if K % 64 == 0 and epi == 'none':
+            # the same tensor produced by a residual GEMM (identity weight): its emitted partial sums must
+            # describe the ROUNDED output and drive the fold to the same result
+            eye = torch.eye(K, dtype=torch.bfloat16, device=dev())
+            part = torch.empty(K // 64, M, 2, dtype=torch.float32, device=dev())
+            y = _hip.gemm_fused(xg, eye, None, _hip.EPI_RESIDUAL, torch.zeros_like(xg), 1.0, stats_out=part)
+            assert torch.equal(y, xg)
+            assert torch.allclose(part.sum(0).cpu(), ref_s, rtol=1e-5, atol=1e-3)
+            got2 = _hip.gemm_fused(xg, wf, None, code, ln=(part, K, 1e-5, c1, c2))
+            check(got2, got.float(), rtol=2.0 ** -8, atol_scale=2.0 ** -8, what='LN-fold via emitted partial sums')
+    finally:
+        _hip.load().esme_hip_debug_set_gemm_tile(0)
+
+
 def _attn_case(lengths, H, d, seed, qscale=1.0, spike=False):
     from esme import _hip
     T, E = sum(lengths), H * d
