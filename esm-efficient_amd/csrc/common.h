@@ -59,22 +59,23 @@ __device__ __forceinline__ float dpp_f32(float v) {
 }
 
 // erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)) -- the form the reference uses (nn.GELU() /
-// F.gelu default: attention.py:233, head.py:26), NOT the tanh approximation.  erf is evaluated
-// with Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7 + fp32 round-off; measured max |gelu
-// error| 4.7e-7 over [-12, 12], i.e. <= 0.5 bf16 half-ulp of the result for |x| < 4 and
-// absolute 1e-7-level noise in the far negative tail, where the fp32 "1 + erf" form of the
-// reference itself has no correct digits).  ~14 VALU ops instead of libm erff's ~40: the
-// FFN-up epilogue evaluates it T x 4E times per layer.
+// F.gelu default: attention.py:233, head.py:26), NOT the tanh approximation.  Written as
+//     gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)
+// (no 1 - erf cancellation, so the negative tail keeps its relative accuracy) with erfc from
+// Abramowitz-Stegun 7.1.26, erfc(z) = t (a1 + t (a2 + ... a5 t)) exp(-z^2), t = 1/(1 + p z)
+// (|error| <= 1.5e-7); the -0.5 is folded into the coefficients and 1/sqrt 2 into p and the
+// exponent.  Measured max |error| vs float64 erf-GELU over [-12, 12]: 3.3e-7, i.e. < 1 bf16
+// half-ulp of the result for |x| < 5.  14 VALU ops (2 transcendental) instead of libm erff's ~40:
+// the FFN-up epilogue evaluates it T x 4E times per layer with the MFMA pipe idle.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
-    const float erf_abs = fmaf(-(p * t), e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418897f, ax, 1.0f));
+    float p = fmaf(t, -0.5307027145f, 0.7265760135f);      // -0.5 * a5, -0.5 * a4
+    p = fmaf(t, p, -0.7107068705f);                         // -0.5 * a3
+    p = fmaf(t, p, 0.142248368f);                           // -0.5 * a2
+    p = fmaf(t, p, -0.127414796f);                          // -0.5 * a1
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044f);   // exp(-x^2 / 2)
+    return fmaf(ax, (p * t) * e, fmaxf(x, 0.0f));
 }
 
 // Observed dispatcher policy: block b runs on XCD b % 8.  Remap so each XCD (own L2)

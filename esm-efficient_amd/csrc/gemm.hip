@@ -181,6 +181,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // once per block, right after K-tile 0's LDS-DMA is issued (the loads overlap its latency), and park {rstd, rstd*mean} in
     // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
     f32x2* lnst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);
+    int* lpos = reinterpret_cast<int*>(smem + 2 * STAGE + BM * 8);       // rotary: position of each tile row
+    if constexpr (ROTD > 0) {
+        if (tid < BM) {
+            int64_t m = m0 + tid;
+            m = m < a.M ? m : a.M - 1;
+            int p = a.pos[m];
+            lpos[tid] = p < a.max_len ? p : a.max_len - 1;
+        }
+    }
     if constexpr (LNF) {
         if (tid < BM) {
             int64_t m = m0 + tid;
@@ -298,22 +307,37 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
         if (nw0 < a.rot_cols) {                               // wave-uniform: whole heads of q or k
+            // cos/sin rows of this wave's 128 positions: fetched by the LDS-DMA in whole lines into the
+            // wave's slab ([row][cos half | sin half], XOR-swizzled 16-B chunks) instead of 8-B loads
+            // scattered over 32 table rows per instruction; the accumulator quads then read LDS.
+            constexpr int CPRW = ROTD / 8;                    // 16-B chunks per slab row (cos + sin halves)
+            constexpr int TB = 2 * ROTD;                      // bytes per slab row
+            constexpr int NI = WTM * CPRW / 64;
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int idx = it * 64 + lane;
+                const int r = idx / CPRW;
+                const int c = (idx % CPRW) ^ (r & (CPRW - 1));
+                const int p = lpos[wm * WTM + r];
+                const u16* src = (c < CPRW / 2) ? a.cosT + (int64_t)p * ROTD + c * 8
+                                                : a.sinT + (int64_t)p * ROTD + (c - CPRW / 2) * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + it * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                int64_t m = mw0 + j * 32 + l31;
-                m = m < a.M ? m : a.M - 1;
-                int p = a.pos[m];
-                p = p < a.max_len ? p : a.max_len - 1;
-                const u16* ct = a.cosT + (int64_t)p * ROTD + 4 * hi;
-                const u16* st = a.sinT + (int64_t)p * ROTD + 4 * hi;
+                const int r = j * 32 + l31;
+                const char* trow = slab + r * TB + hi * 8;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {                 // q = quad index i*4+g over the 64 columns
                     constexpr int HALF = ROTD / 2;
                     const int c0 = q * 8;                     // first column of the quad pair (per hi: +4)
                     if ((c0 % ROTD) >= HALF) continue;        // upper half of a head: handled with its partner
                     const int q2 = (c0 + HALF) / 8;           // partner quad
-                    const u32x2 cw = *reinterpret_cast<const u32x2*>(ct + (c0 % ROTD));
-                    const u32x2 sw = *reinterpret_cast<const u32x2*>(st + (c0 % ROTD));
+                    const int cc = (c0 % ROTD) / 8;           // cos chunk; the sin chunk sits CPRW/2 further
+                    const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((cc ^ (r & (CPRW - 1))) << 4));
+                    const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + (((cc + CPRW / 2) ^ (r & (CPRW - 1))) << 4));
                     const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
                     const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
 #pragma unroll
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();                  // table reads done before the slab takes results
         }
     }
 
@@ -488,7 +513,7 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128 + (LNF ? BM * 8 : 0);
+    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 : 0);
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
