@@ -1,8 +1,11 @@
 // Varlen (cu_seqlens-indexed, block-diagonal) multi-head self-attention forward for
 // gfx950:  per sequence i and head h,  O = softmax(Q K^T * scale) V, non-causal.
 //
-// Workgroup = 4 waves = one 128-row query tile of one (sequence, head); each wave owns 32
-// query rows and walks the sequence's keys in tiles of 64.
+// Workgroup = 4 waves = one query tile of 128 * QB rows of one (sequence, head); each wave owns
+// QB blocks of 32 query rows (QB = 2 when sequences are long enough: every K / V^T fragment read
+// from LDS then feeds two MFMAs, the two blocks' MFMA chains and softmax VALU work interleave
+// inside the wave, and staging + barrier cost per query row halves) and walks the sequence's keys
+// in tiles of 64.
 //
 // Both contractions run on v_mfma_f32_32x32x16_bf16 in TRANSPOSED form so that the
 // softmax axis (keys) lies along a lane's registers and the query index is the lane:
@@ -26,7 +29,7 @@
 
 namespace esme {
 
-static constexpr int QT = 128;   // query rows per workgroup (4 waves x 32)
+static constexpr int QT = 128;   // query rows per workgroup per q-block (4 waves x 32)
 static constexpr int KT = 64;    // keys per tile
 
 struct AttnArgs {
@@ -45,7 +48,7 @@ __device__ __forceinline__ int kswz(int row) {
     return (row / RPB) & (CPR - 1);
 }
 
-template <int D>
+template <int D, int QB>
 __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     constexpr int DS = D / 16;                   // k-steps of the QK^T contraction
     constexpr int DB = (D + 31) / 32;            // 32-row blocks of O^T
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
-    const int q0 = blockIdx.x * QT;
+    const int q0 = blockIdx.x * (QT * QB);
     if (q0 >= S) return;
 
     const unsigned int ld = (unsigned int)a.ld;
@@ -73,14 +76,22 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     const u16* kb = a.k + (int64_t)s0 * a.ld + h * D;
     const u16* vb = a.v + (int64_t)s0 * a.ld + h * D;
 
-    // ---- Q fragments (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 .. +7]
-    const int qrow = q0 + wave * 32 + l31;
-    const bool wave_active = (q0 + wave * 32) < S;       // wave-uniform
-    const unsigned int qrow_c = qrow < S ? qrow : S - 1;
-    bf16x8 qf[DS];
+    // ---- Q fragments (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 .. +7];
+    // wave w owns rows q0 + w*32*QB + b*32 + l31 for its q-blocks b = 0..QB-1
+    int qrow[QB];
+    bool blk_active[QB];                                   // wave-uniform
+    bf16x8 qf[QB][DS];
 #pragma unroll
-    for (int ds = 0; ds < DS; ++ds)
-        qf[ds] = *reinterpret_cast<const bf16x8*>(qb + (qrow_c * ld + ds * 16 + hi * 8));
+    for (int b = 0; b < QB; ++b) {
+        const int r0 = q0 + (wave * QB + b) * 32;
+        qrow[b] = r0 + l31;
+        blk_active[b] = r0 < S;
+        const unsigned int qc = qrow[b] < S ? qrow[b] : S - 1;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds)
+            qf[b][ds] = *reinterpret_cast<const bf16x8*>(qb + (qc * ld + ds * 16 + hi * 8));
+    }
+    const bool wave_active = blk_active[0];
 
     // ---- staging assignments.  K: chunk c -> (row c / CPR, chunk c % CPR).
     // V: each thread owns 4x4 (key x d) blocks; lane bits are laid out so that the 16
@@ -162,14 +173,17 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     // K row fed to MFMA row i of a key block: bits 2 and 3 of i swapped
     const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
 
-    f32x16 oacc[DB];
+    f32x16 oacc[QB][DB];
+    float mc[QB], l_run[QB];           // running max (already multiplied by c: log2 units) and row sum
 #pragma unroll
-    for (int i = 0; i < DB; ++i)
+    for (int b = 0; b < QB; ++b) {
+        mc[b] = -1e30f; l_run[b] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[b][i][r] = 0.f;
+    }
     const float c = a.scale_log2;
-    float mc = -1e30f;                 // running max, already multiplied by c (log2 units)
-    float l_run = 0.f;
 
     const int ntiles = (S + KT - 1) / KT;
     load_tile(0);
@@ -181,67 +195,74 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
         const char* Ks = smem + (t & 1) * BUF;
         const char* Vt = Ks + K_BYTES;
         if (wave_active) {
-            // ---- S^T = K . Q^T for two 32-key blocks
-            f32x16 sacc[2];
+            // ---- S^T = K . Q^T for two 32-key blocks; each K fragment feeds all QB q-blocks
+            f32x16 sacc[QB][2];
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
+                for (int b = 0; b < QB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[b][kbk][r] = 0.f;
                 const int row = kbk * 32 + krow_perm;
                 const char* rp = Ks + row * (D * 2);
                 const int sw = kswz<D>(row);
 #pragma unroll
                 for (int ds = 0; ds < DS; ++ds) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
-                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[kbk], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b)
+                        sacc[b][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ds], sacc[b][kbk], 0, 0, 0);
                 }
             }
-            // register r of block kbk holds key kv0 + kbk*32 + 16*(r>>3) + 8*hi + (r&7)
-            if (kv0 + KT > S) {
+            bf16x8 pf[QB][2][2];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                // register r of block kbk holds key kv0 + kbk*32 + 16*(r>>3) + 8*hi + (r&7)
+                if (kv0 + KT > S) {
+#pragma unroll
+                    for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kv0 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) >= S) sacc[b][kbk][r] = -1e30f;
+                }
+                float tmax = sacc[b][0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][1][r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float tmc = tmax * c;
+                // defer-max: rescale only when some row's max grew by more than THR (in log2 units);
+                // otherwise keep the old reference max -- P is then bounded by 2^THR, which fp32 sums
+                // and the bf16 P (same relative precision at any scale) absorb.  Wave-uniform branch.
+                if (__any(tmc > mc[b] + THR)) {
+                    const float mn = fmaxf(mc[b], tmc);
+                    const float alpha = __builtin_amdgcn_exp2f(mc[b] - mn);
+                    mc[b] = mn;
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int i = 0; i < DB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[b][i][r] *= alpha;
+                }
+                float psum = 0.f;
 #pragma unroll
                 for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kv0 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) >= S) sacc[kbk][r] = -1e30f;
-            }
-            float tmax = sacc[0][0];
+                    for (int s = 0; s < 2; ++s) {
+                        float p[8];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[1][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float tmc = tmax * c;
-            // defer-max: rescale only when some row's max grew by more than THR (in log2 units);
-            // otherwise keep the old reference max -- P is then bounded by 2^THR, which fp32 sums
-            // and the bf16 P (same relative precision at any scale) absorb.  Wave-uniform branch.
-            if (__any(tmc > mc + THR)) {
-                const float mn = fmaxf(mc, tmc);
-                const float alpha = __builtin_amdgcn_exp2f(mc - mn);
-                mc = mn;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < DB; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            }
-            float psum = 0.f;
-            bf16x8 pf[2][2];
-#pragma unroll
-            for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float p[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        p[j] = __builtin_amdgcn_exp2f(fmaf(sacc[kbk][8 * s + j], c, -mc));
-                        psum += p[j];
+                        for (int j = 0; j < 8; ++j) {
+                            p[j] = __builtin_amdgcn_exp2f(fmaf(sacc[b][kbk][8 * s + j], c, -mc[b]));
+                            psum += p[j];
+                        }
+                        u32x4 pk = pack8(p);
+                        pf[b][kbk][s] = __builtin_bit_cast(bf16x8, pk);
                     }
-                    u32x4 pk = pack8(p);
-                    pf[kbk][s] = __builtin_bit_cast(bf16x8, pk);
-                }
-            l_run += psum;
+                l_run[b] += psum;
+            }
 
-            // ---- O^T += V^T . P^T
+            // ---- O^T += V^T . P^T; each V^T fragment feeds all QB q-blocks
 #pragma unroll
             for (int i = 0; i < DB; ++i) {
                 int drow = i * 32 + l31;
@@ -253,7 +274,9 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
-                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kbk][s], oacc[i], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < QB; ++b)
+                            oacc[b][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][kbk][s], oacc[b][i], 0, 0, 0);
                     }
             }
         }
@@ -269,27 +292,33 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     }
 
     if (!wave_active) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (qrow < S) {
-        u16* op = a.o + (int64_t)(s0 + qrow) * a.ldo + h * D;
 #pragma unroll
-        for (int i = 0; i < DB; ++i)
+    for (int b = 0; b < QB; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (qrow[b] < S) {
+            u16* op = a.o + (int64_t)(s0 + qrow[b]) * a.ldo + h * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = i * 32 + 8 * g + 4 * hi;
-                if (d < D) {
-                    u32x2 pk = {pack_bf16(oacc[i][4 * g] * inv, oacc[i][4 * g + 1] * inv),
-                                pack_bf16(oacc[i][4 * g + 2] * inv, oacc[i][4 * g + 3] * inv)};
-                    *reinterpret_cast<u32x2*>(op + d) = pk;
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = i * 32 + 8 * g + 4 * hi;
+                    if (d < D) {
+                        u32x2 pk = {pack_bf16(oacc[b][i][4 * g] * inv, oacc[b][i][4 * g + 1] * inv),
+                                    pack_bf16(oacc[b][i][4 * g + 2] * inv, oacc[b][i][4 * g + 3] * inv)};
+                        *reinterpret_cast<u32x2*>(op + d) = pk;
+                    }
                 }
-            }
+        }
     }
 }
 
 }  // namespace esme
 
 using namespace esme;
+
+static int g_force_qb = 0;      // test hook: force q-blocks per wave (0 = heuristic)
+extern "C" void esme_hip_debug_set_attn_qb(int v) { g_force_qb = v; }
 
 extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
                                         int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
@@ -304,14 +333,25 @@ extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
                softmax_scale * 1.4426950408889634f};
-    const dim3 grid((unsigned int)((max_len + QT - 1) / QT), (unsigned int)H, (unsigned int)B), block(256);
+    // two 32-row q-blocks per wave when the longest sequence fills at least one 256-row tile
+    // (head dim 128 keeps one: its accumulators alone take 128 VGPRs per q-block)
+    const int qb = (g_force_qb ? g_force_qb : (max_len >= 192 ? 2 : 1));
+    const bool two = qb == 2 && d <= 64;
+    const int rows = QT * (two ? 2 : 1);
+    const dim3 grid((unsigned int)((max_len + rows - 1) / rows), (unsigned int)H, (unsigned int)B), block(256);
     const hipStream_t s = (hipStream_t)stream;
+#define ESME_ATTN(DD)                                                                         \
+    case DD:                                                                                   \
+        if (two) hipLaunchKernelGGL((attn_varlen_kernel<DD, (DD <= 64 ? 2 : 1)>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((attn_varlen_kernel<DD, 1>), grid, block, 0, s, a);            \
+        break;
     switch (d) {
-        case 16: hipLaunchKernelGGL(attn_varlen_kernel<16>, grid, block, 0, s, a); break;
-        case 32: hipLaunchKernelGGL(attn_varlen_kernel<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(attn_varlen_kernel<64>, grid, block, 0, s, a); break;
-        case 128: hipLaunchKernelGGL(attn_varlen_kernel<128>, grid, block, 0, s, a); break;
+        ESME_ATTN(16)
+        ESME_ATTN(32)
+        ESME_ATTN(64)
+        ESME_ATTN(128)
         default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn: head dim must be 16, 32, 64 or 128");
     }
+#undef ESME_ATTN
     return check_launch("attn_varlen_fwd");
 }

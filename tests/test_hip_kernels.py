@@ -282,8 +282,16 @@ def _attn_case(lengths, H, d, seed, qscale=1.0, spike=False):
     ([130, 9, 61], 20, 32), ([37, 70, 193], 20, 64), ([500, 500], 20, 64), ([1, 300, 63, 64], 5, 64),
     ([700], 2, 128), ([1253], 4, 64),
 ])
-def test_attention(lengths, H, d):
-    got, ref = _attn_case(lengths, H, d, seed=20)
+@pytest.mark.parametrize('qb', [1, 2])
+def test_attention(lengths, H, d, qb):
+    from esme import _hip
+    lib = _hip.load()
+    lib.esme_hip_debug_set_attn_qb.restype = None
+    lib.esme_hip_debug_set_attn_qb(qb)          # q-blocks per wave (2 = the long-sequence configuration)
+    try:
+        got, ref = _attn_case(lengths, H, d, seed=20)
+    finally:
+        lib.esme_hip_debug_set_attn_qb(0)
     # P is rounded to bf16 before PV (FA-2 convention): allow 2^-6 relative + 2^-6 of the rms
     check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention {lengths} H{H} d{d}')
 
