@@ -43,7 +43,7 @@ struct GemmArgs {
     //   ln_partial (ln_nblk, M, 2): per-block (sum, sum of squares) over ln_dim features
     const float* ln_partial; int ln_nblk; int ln_dim; float ln_eps; const float* ln_c1; const float* ln_c2;
     // residual epilogue also emits per-row partial (sum, sum of squares) of the ROUNDED output
-    // over each 64-column block: stats_out[(n/64) * M + m] (float2) -> next LayerNorm's statistics
+    // over each column tile of the launch: stats_out[(n/BN) * M + m] (float2) -> next LayerNorm's statistics
     float* stats_out;
 };
 
@@ -434,28 +434,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         __builtin_amdgcn_wave_barrier();
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
-        if (n < n_out) {                              // n_out % 8 == 0 on this path
+        const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
+        f32x2* blkst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);      // STATS: [wn][tile row] partial sums
+        if (col_ok || STATS) {
 #pragma unroll
             for (int it = 0; it < WTM / RPI; ++it) {
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
-                if (m < a.M) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+                if (col_ok && m < a.M) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
-                    // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine.
+                    // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
+                    // (two quad_perm DPP steps + row_half_mirror), the 4 column waves of the block
+                    // combine through a small LDS strip below.
                     float f[8];
                     unpack8(v, f);
                     float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
                     float t2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) +
                                ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
-                    // 8 consecutive lanes hold one row: two quad_perm DPP steps + row_half_mirror
                     t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);      // lane ^ 1
                     t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);      // lane ^ 2
                     t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);    // lane -> 7 - lane (other quad)
-                    if (ch == 0 && m < a.M)
-                        *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)((n0 + wn * WTN) >> 6) * a.M + m)) = f32x2{t1, t2};
+                    if (ch == 0) blkst[wn * BM + wm * WTM + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
                 }
+            }
+        }
+        if constexpr (STATS) {
+            __syncthreads();
+            if (tid < BM && m0 + tid < a.M) {
+                f32x2 acc2 = blkst[tid];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) { const f32x2 p = blkst[w * BM + tid]; acc2[0] += p[0]; acc2[1] += p[1]; }
+                *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(n0 / BN) * a.M + m0 + tid)) = acc2;
             }
         }
         return;
@@ -513,7 +524,7 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 : 0);
+    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
@@ -557,6 +568,16 @@ extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
 extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
 extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
 extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
+
+static int pick_tile(int64_t M, int N) {
+    if (g_force_tile) return g_force_tile;
+    return (M >= 4096 && N >= 256) ? 2 : 1;
+}
+
+extern "C" int esme_hip_gemm_stats_blocks(int64_t M, int N) {
+    const int bn = pick_tile(M, N) == 2 ? 256 : 128;
+    return (N + bn - 1) / bn;
+}
 
 extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
                                         int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
@@ -615,9 +636,7 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
         }
     }
     const hipStream_t s = (hipStream_t)stream;
-    int tile = g_force_tile;
-    if (tile == 0) tile = (M >= 4096 && N >= 256) ? 2 : 1;
-    switch (tile) {
+    switch (pick_tile(M, N)) {
         case 1: return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
         case 2: return launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);      // wave tile 128(m) x 64(n)
         default: ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");

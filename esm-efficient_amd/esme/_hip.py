@@ -46,6 +46,7 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'esme_hip_gemm_bf16_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, POINTER(GemmFusion), c_void_p]),
+    'esme_hip_gemm_stats_blocks': (c_int, [c_int64, c_int]),
     'esme_hip_row_sums': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
@@ -261,12 +262,17 @@ def gemm_qkv_rotary(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     return out
 
 
+def stats_blocks(M: int, N: int) -> int:
+    """Column-tile blocks a residual-epilogue GEMM of this shape writes to `stats_out`."""
+    return int(load().esme_hip_gemm_stats_blocks(M, N))
+
+
 def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
-    `stats_out` (N/64, M, 2) f32 receives per-row partial sums of the rounded output (residual
+    `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
     epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue)."""
     ap, lda = _rows2d(a, 'gemm a')
     if not w.is_contiguous():
@@ -291,8 +297,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         fu.ln_partial, fu.ln_nblk, fu.ln_dim, fu.ln_eps = _dev(part, 'ln partial', torch.float32), part.shape[0], int(dim), float(eps)
         fu.ln_c1, fu.ln_c2 = _dev(c1, 'ln c1', torch.float32), _dev(c2, 'ln c2', torch.float32)
     if stats_out is not None:
-        if stats_out.numel() < (N // 64) * M * 2 or not stats_out.is_contiguous():
-            raise ValueError('gemm: stats_out must be a contiguous (N/64, M, 2) float32 buffer')
+        if stats_out.numel() < stats_blocks(M, N) * M * 2 or not stats_out.is_contiguous():
+            raise ValueError('gemm: stats_out must be a contiguous (stats_blocks(M, N), M, 2) float32 buffer')
         fu.stats_out = _dev(stats_out, 'stats_out', torch.float32)
     if rot is not None:
         cos, sin, pos, head_dim, rot_cols = rot

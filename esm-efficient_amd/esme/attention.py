@@ -43,7 +43,7 @@ class ForwardContext:
         self.pos, self.cos, self.sin = pos, cos, sin
         self.fold = fold            # run the LN-folded fast path
         self.sums = None            # partial sums (nblk, T, 2) f32 describing the current residual stream
-        self.part_a = None          # (E/64, T, 2) f32 buffers the residual GEMMs write their row sums to
+        self.part_a = None          # (stats_blocks, T, 2) f32 buffers the residual GEMMs write their row sums to
         self.part_b = None
 
 
@@ -283,7 +283,7 @@ class FlashTransformerLayer(nn.Module):
         if ctx is not None and ctx.fold and E % 64 == 0:
             if ctx.sums is None:                                # first layer: row sums straight from x
                 ctx.sums = _hip.row_sums(x)
-                ctx.part_a = torch.empty(E // 64, T, 2, dtype=torch.float32, device=x.device)
+                ctx.part_a = torch.empty(_hip.stats_blocks(T, E), T, 2, dtype=torch.float32, device=x.device)
                 ctx.part_b = torch.empty_like(ctx.part_a)
             self.self_attn(x, cu_lens, max_len, lora_names, ctx, resid=x, alpha=alpha, out=y,
                            x_stats=ctx.sums, stats_out=ctx.part_b)

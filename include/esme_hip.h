@@ -122,9 +122,10 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              {sum, sum of squares} as emitted by stats_out / esme_hip_row_sums (ln_nblk = 1).
  *              Replaces the nn.LayerNorm in front of q/k/v (esme/attention.py:75,92) and of the FFN
  *              (esme/attention.py:222,230) without writing or reading a normalised copy of x;
- *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per 64-column block, the sum and sum
- *              of squares of the bf16-ROUNDED output, float (N/64, M, 2): what the next
- *              LN-folding GEMM reduces its row statistics from. */
+ *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per column tile of the launch, the sum
+ *              and sum of squares of the bf16-ROUNDED output, float (nblk, M, 2) with
+ *              nblk = esme_hip_gemm_stats_blocks(M, N): what the next LN-folding GEMM reduces its
+ *              row statistics from (pass it as ln_partial / ln_nblk). */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;
@@ -140,6 +141,9 @@ typedef struct esme_gemm_fusion {
     int max_len;
     int rot_cols;
 } esme_gemm_fusion_t;
+
+/* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
+int esme_hip_gemm_stats_blocks(int64_t M, int N);
 
 int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias,
                              const void* resid, int64_t ldr, void* C, int64_t ldc, int64_t M, int N,

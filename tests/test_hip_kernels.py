@@ -247,7 +247,7 @@ def test_gemm_layernorm_fold_and_row_sums(M, N, K, epi, tile):
             # the same tensor produced by a residual GEMM (identity weight): its emitted partial sums must
             # describe the ROUNDED output and drive the fold to the same result
             eye = torch.eye(K, dtype=torch.bfloat16, device=dev())
-            part = torch.empty(K // 64, M, 2, dtype=torch.float32, device=dev())
+            part = torch.empty(_hip.stats_blocks(M, K), M, 2, dtype=torch.float32, device=dev())
             y = _hip.gemm_fused(xg, eye, None, _hip.EPI_RESIDUAL, torch.zeros_like(xg), 1.0, stats_out=part)
             assert torch.equal(y, xg)
             assert torch.allclose(part.sum(0).cpu(), ref_s, rtol=1e-5, atol=1e-3)

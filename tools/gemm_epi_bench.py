@@ -18,10 +18,11 @@ wo, bo = bf(E, E, scale=E ** -0.5), bf(E, scale=0.1)
 w1, b1 = bf(4 * E, E, scale=E ** -0.5), bf(4 * E, scale=0.1)
 w2, b2 = bf(E, 4 * E, scale=(4 * E) ** -0.5), bf(E, scale=0.1)
 stats1 = _hip.row_sums(x)
-stats = (stats1 / 20).expand(20, T, 2).contiguous()      # same sums split over 20 blocks, as a residual GEMM emits them
+NB = _hip.stats_blocks(T, E)
+stats = (stats1 / NB).expand(NB, T, 2).contiguous()      # same sums split over the blocks a residual GEMM emits
 c1q, c2q = torch.randn(3 * E, device=dev), torch.randn(3 * E, device=dev)
 c11, c21 = torch.randn(4 * E, device=dev), torch.randn(4 * E, device=dev)
-partial = torch.empty(E // 64, T, 2, device=dev)
+partial = torch.empty(_hip.stats_blocks(T, E), T, 2, device=dev)
 pos = (torch.arange(T, device=dev, dtype=torch.int32) % 500).contiguous()
 ang = torch.outer(torch.arange(500.), 1.0 / (10000 ** (torch.arange(0, d, 2) / d)))
 ang = torch.cat((ang, ang), -1)
