@@ -182,6 +182,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
     f32x2* lnst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);
     int* lpos = reinterpret_cast<int*>(smem + 2 * STAGE + BM * 8);       // rotary: position of each tile row
+    f32x4* c1s = reinterpret_cast<f32x4*>(smem + 2 * STAGE + BM * 12);    // LN fold: c1 / c2 of the tile's columns
+    f32x4* c2s = c1s + BN / 4;
     if constexpr (ROTD > 0) {
         if (tid < BM) {
             int64_t m = m0 + tid;
@@ -218,6 +220,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             const float mean = s1 * inv;
             const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
             lnst[tid] = f32x2{rstd, rstd * mean};
+        }
+        if (tid < BN / 4) {                                     // this tile's c1 / c2 columns -> LDS strip
+            int n = n0 + tid * 4;
+            n = n < a.N - 4 ? n : a.N - 4;
+            c1s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c1 + n);
+            c2s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c2 + n);
         }
     }
 
@@ -269,7 +277,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // finish LN(x) W^T + b algebraically per element (fp32), so no normalised copy of x is ever
     // written or read:  y = rstd*(x.W') - rstd*mean*sum_k W'[n,k] + (sum_k beta_k W[n,k] + b[n]).
     if constexpr (LNF) {
-        const int nrow0 = n0 + wn * WTN;                          // packed weight row of the wave's first column
         f32x2 st[FM];
 #pragma unroll
         for (int j = 0; j < FM; ++j) st[j] = lnst[wm * WTM + j * 32 + l31];
@@ -277,10 +284,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         for (int i = 0; i < FN; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int n = nrow0 + i * 32 + 8 * g + 4 * hi;
-                n = n < a.N - 4 ? n : a.N - 4;
-                const f32x4 c1q = *reinterpret_cast<const f32x4*>(a.ln_c1 + n);
-                const f32x4 c2q = *reinterpret_cast<const f32x4*>(a.ln_c2 + n);
+                const int q4 = (wn * WTN + i * 32 + 8 * g + 4 * hi) >> 2;      // float4 index inside the tile
+                const f32x4 c1q = c1s[q4], c2q = c2s[q4];
 #pragma unroll
                 for (int j = 0; j < FM; ++j)
 #pragma unroll
@@ -524,7 +529,7 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 : 0) + (STATS ? WN * BM * 8 : 0);
+    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
