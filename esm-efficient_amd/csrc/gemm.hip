@@ -574,9 +574,12 @@ extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = g
 extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
 extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
 
+// 256x256 tiles (one workgroup per CU) once they fill the chip about twice over; otherwise the
+// 128x128 configuration (2-3 workgroups per CU, 4x the tiles) keeps more CUs busy.
 static int pick_tile(int64_t M, int N) {
     if (g_force_tile) return g_force_tile;
-    return (M >= 4096 && N >= 256) ? 2 : 1;
+    const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    return (N >= 256 && big_tiles >= 384) ? 2 : 1;
 }
 
 extern "C" int esme_hip_gemm_stats_blocks(int64_t M, int N) {
