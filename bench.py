@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-tokens', type=int, default=8000)
     ap.add_argument('--no-gather', action='store_true', help='skip the logits all-gather when N>1')
+    ap.add_argument('--quantization', choices=['none', '4bit'], default='none',
+                    help="'4bit': layer projections resident in the esme-q4 format (not the headline config)")
     return ap.parse_args()
 
 
@@ -114,7 +116,8 @@ def main():
         from safetensors.torch import save_file
         path = os.path.join(td, f'{args.model}.safetensors')
         save_file(weights, path, metadata=syn.checkpoint_metadata(args.model, L, E, H))
-        model = ESM.from_pretrained(path, device=str(dev))
+        model = ESM.from_pretrained(path, quantization=None if args.quantization == 'none' else args.quantization,
+                                    device=str(dev))
 
     # ---- this rank's packed batch (resident in HBM before the timed region)
     if args.batch == 'uniform':
@@ -164,7 +167,8 @@ def main():
                                f'{args.batch} batch ({len(lengths)} seqs, max_len {max_len})',
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
                    'parallelism': f'dp{world} (protein-sharded, logits all-gather)' if world > 1 else 'single GPU',
-                   'weights': 'synthetic (numpy PCG64), reference checkpoint layout'},
+                   'weights': 'synthetic (numpy PCG64), reference checkpoint layout'
+                              + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme-q4 fp4)')},
         'e2e': {'algorithmic_tflop_per_step': round(flops_step / 1e12, 3),
                 'tflops_per_gpu': round(flops_step / (ms_per_step * 1e-3) / 1e12, 1),
                 'frac_bf16_mfma_peak': round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
@@ -211,6 +215,13 @@ def main():
                 hbm['layernorm'] = round(4.0 * E * T / (sum(v) / len(v) * 1e-3) / 1e9, 1)
             if op == 'rotary':
                 hbm['rotary'] = round(8.0 * E * T / (sum(v) / len(v) * 1e-3) / 1e9, 1)
+            if op == 'dequant4':        # 0.5 B code + 2 B bf16 per weight (+ 1/16 B absmax)
+                hbm.setdefault('dequant4_bytes', 0.0)
+                hbm.setdefault('dequant4_ms', 0.0)
+                hbm['dequant4_bytes'] += 2.5625 * meta[0] * meta[1] * len(v)
+                hbm['dequant4_ms'] += sum(v)
+        if 'dequant4_ms' in hbm:
+            hbm['dequant4'] = round(hbm.pop('dequant4_bytes') / (hbm.pop('dequant4_ms') * 1e-3) / 1e9, 1)
         result['hbm_bound_GBps'] = hbm
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(weights, H, kind, L, E, args.seq_len,

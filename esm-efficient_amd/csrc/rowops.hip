@@ -187,6 +187,58 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restric
     }
 }
 
+
+// ------------------------------------------------------- per-sequence mean
+// One workgroup per (sequence, 512-column slab): wave w walks rows w, w+4, ... of the
+// sequence with 16-byte loads (bf16: 8 columns per lane; fp32: two 16-byte halves), fp32
+// accumulation, then the four waves' partials meet in LDS.
+template <bool F32>
+__global__ __launch_bounds__(256) void segment_mean_kernel(const void* __restrict__ xv, int64_t ldx,
+                                                           const int32_t* __restrict__ cu, int E,
+                                                           void* __restrict__ outv, int64_t ldo) {
+    __shared__ float part[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seq = blockIdx.x;
+    const int col = blockIdx.y * 512 + lane * 8;
+    const int a = cu[seq], b = cu[seq + 1];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < E) {
+        for (int r = a + wave; r < b; r += 4) {
+            float f[8];
+            if (F32) {
+                const float* x = (const float*)xv + (int64_t)r * ldx + col;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(x);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(x + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+            } else {
+                unpack8(*reinterpret_cast<const u32x4*>((const u16*)xv + (int64_t)r * ldx + col), f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
+    __syncthreads();
+    if (wave == 0 && col < E) {
+        const float inv = b > a ? 1.0f / (float)(b - a) : 0.f;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane * 8 + j;
+            f[j] = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) * inv;
+        }
+        if (F32) {
+            float* o = (float*)outv + (int64_t)seq * ldo + col;
+            *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
+        } else {
+            *reinterpret_cast<u32x4*>((u16*)outv + (int64_t)seq * ldo + col) = pack8(f);
+        }
+    }
+}
+
 }  // namespace esme
 
 using namespace esme;
@@ -301,4 +353,20 @@ extern "C" int esme_hip_gather_rows(const void* src, const int64_t* idx, void* d
 }
 extern "C" int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream) {
     return gather_scatter(src, idx, dst, n, E, stream, 1);
+}
+
+extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* cu_lens, int B, int E, void* out,
+                                     int64_t ldo, int dtype_f32, void* stream) {
+    ESME_CHECK_ARG(B >= 0 && E > 0, "segment_mean: bad sizes");
+    if (B == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && cu_lens && out && ldx >= E && ldo >= E, "segment_mean: null pointer or bad stride");
+    const int vec = dtype_f32 ? 4 : 8;
+    ESME_CHECK_ARG(E % 8 == 0 && ldx % vec == 0 && ldo % vec == 0 && aligned16(x) && aligned16(out),
+                   "segment_mean: E %% 8 != 0 or misaligned rows");
+    const dim3 grid((unsigned int)B, (unsigned int)((E + 511) / 512));
+    if (dtype_f32)
+        hipLaunchKernelGGL(segment_mean_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, cu_lens, E, out, ldo);
+    else
+        hipLaunchKernelGGL(segment_mean_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, cu_lens, E, out, ldo);
+    return check_launch("segment_mean");
 }

@@ -51,6 +51,11 @@ SIGNATURES = {
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_segment_mean': (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_quantize_4bit': (c_int, [c_void_p, c_int64, c_int64, c_int, POINTER(c_float), c_void_p, c_void_p,
+                                       c_void_p]),
+    'esme_hip_dequantize_4bit': (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_float), c_void_p, c_void_p,
+                                         c_int64, c_void_p]),
 }
 
 _lib = None
@@ -134,12 +139,12 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _rows2d(t: torch.Tensor, what: str):
+def _rows2d(t: torch.Tensor, what: str, dtype=torch.bfloat16):
     """(rows, cols) view with unit column stride; returns (ptr, ld)."""
     if t.dim() != 2 or t.stride(1) != 1:
         raise ValueError(f'{what}: need a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} '
                          f'stride {t.stride()}')
-    return _dev(t, what, torch.bfloat16), t.stride(0)
+    return _dev(t, what, dtype), t.stride(0)
 
 
 # ------------------------------------------------------------------ wrappers
@@ -350,4 +355,64 @@ def scatter_rows(src: torch.Tensor, idx: torch.Tensor, rows: int) -> torch.Tenso
     out = torch.zeros(rows, src.shape[1], dtype=torch.bfloat16, device=src.device)
     _check(load().esme_hip_scatter_rows(_dev(src, 'scatter src', torch.bfloat16), _dev(idx.contiguous(), 'scatter idx', torch.int64),
                                         out.data_ptr(), idx.numel(), src.shape[1], _stream()), 'esme_hip_scatter_rows')
+    return out
+
+
+def segment_mean(x: torch.Tensor, cu_lens: torch.Tensor) -> torch.Tensor:
+    """(B, E) per-sequence mean of the packed rows of x (T, E), bf16 or fp32, fp32 accumulation."""
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError(f'segment_mean: expected bfloat16 or float32, got {x.dtype}')
+    xp, ldx = _rows2d(x, 'segment_mean x', x.dtype)
+    if cu_lens.dtype != torch.int32:
+        cu_lens = cu_lens.to(torch.int32)
+    B = cu_lens.numel() - 1
+    out = torch.empty(B, x.shape[1], dtype=x.dtype, device=x.device)
+    _check(load().esme_hip_segment_mean(xp, ldx, _dev(cu_lens.contiguous(), 'cu_lens', torch.int32), B, x.shape[1],
+                                        out.data_ptr(), out.stride(0), 1 if x.dtype == torch.float32 else 0,
+                                        _stream()), 'esme_hip_segment_mean')
+    return out
+
+
+def _codebook_arg(codebook):
+    vals = [float(v) for v in codebook]
+    if len(vals) != 16:
+        raise ValueError('a 4-bit codebook has exactly 16 entries')
+    return (c_float * 16)(*vals)
+
+
+def quantize_4bit(w: torch.Tensor, codebook):
+    """bf16 (N, K) -> (codes uint8 (N, K/2), absmax float32 (N, K/64)) in the esme-q4 format
+    (include/esme_hip.h)."""
+    wp, ldw = _rows2d(w, 'quantize_4bit w')
+    _dev(w, 'quantize_4bit w', torch.bfloat16)
+    N, K = w.shape
+    codes = torch.empty(N, K // 2, dtype=torch.uint8, device=w.device)
+    absmax = torch.empty(N, K // 64, dtype=torch.float32, device=w.device)
+    _check(load().esme_hip_quantize_4bit(wp, ldw, N, K, _codebook_arg(codebook), codes.data_ptr(), absmax.data_ptr(),
+                                         _stream()), 'esme_hip_quantize_4bit')
+    return codes, absmax
+
+
+def dequantize_4bit(codes: torch.Tensor, absmax: torch.Tensor, codebook, col_scale: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(N, K) bf16 = codebook[codes] * absmax (* col_scale[k]); `out` may be a scratch view."""
+    _dev(codes, 'dequantize_4bit codes', torch.uint8)
+    _dev(absmax, 'dequantize_4bit absmax', torch.float32)
+    if codes.dim() != 2 or not codes.is_contiguous() or not absmax.is_contiguous():
+        raise ValueError('dequantize_4bit: codes (N, K/2) and absmax (N, K/64) must be contiguous')
+    N, K = codes.shape[0], codes.shape[1] * 2
+    if absmax.numel() != N * (K // 64):
+        raise ValueError(f'dequantize_4bit: absmax has {absmax.numel()} entries, expected {N * (K // 64)}')
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=codes.device)
+    elif tuple(out.shape) != (N, K):
+        raise ValueError(f'dequantize_4bit: out shape {tuple(out.shape)} != {(N, K)}')
+    op, ldo = _rows2d(out, 'dequantize_4bit out')
+    _dev(out, 'dequantize_4bit out', torch.bfloat16)
+    sp = _dev(col_scale, 'dequantize_4bit col_scale', torch.float32) if col_scale is not None else None
+    if col_scale is not None and (col_scale.numel() != K or not col_scale.is_contiguous()):
+        raise ValueError('dequantize_4bit: col_scale must be a contiguous float32 (K,) tensor')
+    with _Traced('dequant4', (N, K)):
+        _check(load().esme_hip_dequantize_4bit(codes.data_ptr(), absmax.data_ptr(), N, K, _codebook_arg(codebook), sp,
+                                               op, ldo, _stream()), 'esme_hip_dequantize_4bit')
     return out

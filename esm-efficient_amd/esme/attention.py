@@ -89,6 +89,8 @@ class FlashMultiheadAttention(nn.Module):
         self._pack_key = None
         self._fold = None           # (W', c1, c2) of the LN-folded QKV projection
         self._fold_key = None
+        self._q4_qkv = None         # esme.quantization.Q4Matrix pair when the layer is 4-bit
+        self._q4_out = None
 
     # -- weight layout ------------------------------------------------------
     def _pack(self):
@@ -125,15 +127,32 @@ class FlashMultiheadAttention(nn.Module):
             self._fold_key = key
         return self._fold
 
+    def _weights_qkv(self, fold: bool):
+        """(W, bias, c1, c2) of the fused QKV projection: the LN-folded form when `fold`
+        (bias inside c2), else the plain one.  4-bit layers expand into the shared scratch."""
+        if self._q4_qkv is not None:
+            if fold:
+                w, c1, c2 = self._q4_qkv.folded()
+                return w, None, c1, c2
+            return (*self._q4_qkv.plain(), None, None)
+        if fold:
+            wf, c1, c2 = self._pack_fold()
+            return wf, None, c1, c2
+        self._pack()
+        return self._qkv_w, self._qkv_b, None, None
+
+    def _weights_out(self):
+        if self._q4_out is not None:
+            return self._q4_out.plain()
+        return self.out.weight, self.out.bias
+
     # -- stages (names follow the reference) --------------------------------
     def _qkv(self, x, lora_names=None):
         """LN -> fused QKV (-> ESM-C q/k LayerNorm over the full E, attention.py:104-105).
         Returns q, k, v as (T, H, d) views of one (T, 3E) buffer."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
-        self._pack()
-        T, E = x.shape
-        h = self.norm(x)
-        qkv = _hip.gemm(h, self._qkv_w, self._qkv_b)
+        w, b, _, _ = self._weights_qkv(False)
+        qkv = _hip.gemm(self.norm(x), w, b)
         return self._split_qkv(qkv)
 
     def _split_qkv(self, qkv):
@@ -162,11 +181,11 @@ class FlashMultiheadAttention(nn.Module):
                        and d in (16, 32, 64) and E % 32 == 0)
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
         if x_stats is not None:
-            wf, c1, c2 = self._pack_fold()
+            wf, _, c1, c2 = self._weights_qkv(True)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, E, self.norm.eps, c1, c2), rot=rot)
         else:
-            self._pack()
-            qkv = _hip.gemm_fused(self.norm(x), self._qkv_w, self._qkv_b, rot=rot)
+            w, b, _, _ = self._weights_qkv(False)
+            qkv = _hip.gemm_fused(self.norm(x), w, b, rot=rot)
         q, k, v = self._split_qkv(qkv)                      # ESM-C: q/k LayerNorm in place
         if self.rot_emb is not None and rot is None:
             if ctx is not None:
@@ -174,10 +193,10 @@ class FlashMultiheadAttention(nn.Module):
             else:
                 q, k = self.rot_emb(q, k, cu_lens, max_len)
         a = self._attn(q, k, v, cu_lens, max_len)
+        wo, bo = self._weights_out()
         if resid is not None:
-            return _hip.gemm_fused(a, self.out.weight, self.out.bias, _hip.EPI_RESIDUAL, resid, alpha, out,
-                                   stats_out=stats_out)
-        return self.out(a, out=out)
+            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
+        return _hip.gemm(a, wo, bo, out=out)
 
 
 class SwiGLU(nn.Module):
@@ -235,6 +254,8 @@ class FlashTransformerLayer(nn.Module):
         self.final_activation = final_activation
         self._fold = None
         self._fold_key = None
+        self._q4_up = None          # esme.quantization.Q4Matrix pair when the layer is 4-bit
+        self._q4_down = None
 
     def _pack_fold(self):
         """LN-folded copy of the FFN up-projection weight (self.final[0] folded in)."""
@@ -258,18 +279,37 @@ class FlashTransformerLayer(nn.Module):
                 self._fold_key = key
         return self._fold
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None):
-        down = self.final[3] if self.final_activation == 'gelu' else self.final[2]
-        if x_stats is not None:
+    def _weights_up(self, fold: bool):
+        """(W, bias, c1, c2) of the FFN up-projection (gate/fc interleaved for SwiGLU)."""
+        if self._q4_up is not None:
+            if fold:
+                w, c1, c2 = self._q4_up.folded()
+                return w, None, c1, c2
+            return (*self._q4_up.plain(), None, None)
+        if fold:
             wf, c1, c2 = self._pack_fold()
-            if self.final_activation == 'gelu':
-                u = _hip.gemm_fused(x, wf, None, _hip.EPI_GELU, ln=(x_stats, x.shape[1], self.final[0].eps, c1, c2))
-            else:
-                u = self.final[1](x, ln=(x_stats, x.shape[1], self.final[0].eps, c1, c2), packed=wf)
+            return wf, None, c1, c2
+        if self.final_activation == 'gelu':
+            return self.final[1].weight, self.final[1].bias, None, None
+        self.final[1]._pack()
+        return self.final[1]._packed, None, None, None
+
+    def _weights_down(self):
+        if self._q4_down is not None:
+            return self._q4_down.plain()
+        down = self.final[3] if self.final_activation == 'gelu' else self.final[2]
+        return down.weight, down.bias
+
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None):
+        epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
+        if x_stats is not None:
+            wf, _, c1, c2 = self._weights_up(True)
+            u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, x.shape[1], self.final[0].eps, c1, c2))
         else:
-            h = self.final[0](x)
-            u = self.final[1](h, _hip.EPI_GELU) if self.final_activation == 'gelu' else self.final[1](h)
-        return _hip.gemm_fused(u, down.weight, down.bias, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
+            w, b, _, _ = self._weights_up(False)
+            u = _hip.gemm_fused(self.final[0](x), w, b, epi)
+        wd, bd = self._weights_down()
+        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 inplace: bool = False):

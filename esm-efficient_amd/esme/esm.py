@@ -9,6 +9,7 @@ assertion/ValueError behaviour, so callers of
 edits.  Everything arithmetic runs in HIP kernels behind `esme._hip`; a tensor
 that is not on a HIP device raises (there is no CPU fallback).
 
+`quantization='4bit'` keeps the layer projections 4-bit in HBM (esme/quantization.py).
 Out of scope here: ESM-1b/1v, LoRA management, 8-bit loaders,
 activation checkpointing (training only), hub download (no network).
 """
@@ -61,6 +62,7 @@ class ESM2(nn.Module):
     vocab_size = 33
     zero_mask_rows = True          # `<mask>` embedding rows are zeroed (esm.py:189)
     fold_layernorm = os.environ.get('ESME_NO_LN_FOLD', '0') != '1'   # LN folded into the QKV / FFN-up GEMMs
+    quant_type_4bit = 'fp4'        # codebook of quantization='4bit' (esme.quantization.CODEBOOKS)
 
     def __init__(self, num_layers: int = 33, embed_dim: int = 1280, attention_heads: int = 20,
                  checkpointing: bool = False, rotary_embedding: bool = True, dropout: float = 0.,
@@ -196,7 +198,9 @@ class ESM2(nn.Module):
             f'load_in must be one of [None, "8bit", "4bit"] but got {quantization}'
         if quantization is not None:
             assert device != 'cpu', 'Quantized model cannot be loaded on cpu provide CUDA gpu device'
-            raise NotImplementedError('weight quantisation is a later row of the scope table (SURVEY.md §8f)')
+            if quantization != '4bit':
+                raise NotImplementedError('only the 4-bit weight format is implemented on the MI355X path '
+                                          '(8-bit loaders: SURVEY.md §2, out of scope)')
         from safetensors.torch import load_file
         model = cls.create_model(path, checkpointing=checkpointing)
         dev = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
@@ -204,6 +208,9 @@ class ESM2(nn.Module):
         model.load_state_dict(state, strict=True, assign=True)
         for p in model.parameters():
             p.requires_grad_(False)
+        if quantization == '4bit':
+            from esme.quantization import quantize_model_
+            quantize_model_(model, cls.quant_type_4bit)
         return model.eval()
 
 

@@ -168,6 +168,37 @@ int esme_hip_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t
 int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E,
                           void* stream);
 
+/* out[i, :] = mean over rows cu_lens[i] .. cu_lens[i+1]-1 of x (fp32 accumulation; an
+ * empty segment gives zeros).  x, out: bf16 (dtype_f32 = 0) or fp32 (dtype_f32 = 1), E a
+ * multiple of 8 (bf16) / 4 (fp32), 16-byte aligned rows.
+ * Replaces: partition_mean_pool / PartitionMeanPool.forward esme/pooling.py:36-69 (there:
+ * index_add_ in the embedding dtype, then a divide). */
+int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* cu_lens, int B, int E,
+                          void* out, int64_t ldo, int dtype_f32, void* stream);
+
+/* ---- 4-bit weight-only block quantisation ("esme-q4") ------------------------------
+ * The reference delegates this to bitsandbytes.nn.Linear4bit (esme/esm.py:434-446,
+ * :482-484, :915-946), a third-party CUDA library that is not vendored; the format here is
+ * this library's own, modelled on that library's published defaults:
+ *   - a weight matrix (N, K) bf16, K % 64 == 0, is cut into blocks of 64 consecutive
+ *     elements of a row;
+ *   - absmax[n][K/64] (fp32) = max |w| over the block;
+ *   - each element is stored as the index (0..15) of the codebook entry nearest to
+ *     w / absmax (fp32 divide; first index wins a tie; a zero block encodes as the entry
+ *     nearest 0), two per byte, element 2i in the HIGH nibble: codes (N, K/2) uint8;
+ *   - codebook: 16 fp32 values in [-1, 1] (HOST pointer; copied at launch).
+ * dequantize writes out[n,k] = bf16((codebook[c] * absmax) * col_scale[k]) (col_scale:
+ * device fp32 (K) or NULL = 1), which lets the LayerNorm gain be folded into the weight
+ * while it is expanded.  The expanded weight then feeds esme_hip_gemm_bf16*: on MI355X the
+ * 32 k-token batches of this workload are MFMA-bound, so weights stay 4-bit in HBM and are
+ * expanded per layer into a scratch tile (0.5 B read + 2 B written per weight, ~0.3 ms per
+ * 600 M-parameter forward) instead of slowing the GEMM main loop with in-loop decoding. */
+int esme_hip_quantize_4bit(const void* w, int64_t ldw, int64_t N, int K, const float* codebook,
+                           void* codes, float* absmax, void* stream);
+int esme_hip_dequantize_4bit(const void* codes, const float* absmax, int64_t N, int K,
+                             const float* codebook, const float* col_scale, void* out,
+                             int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,247 @@
+"""GPU parity of the "next" rows: masked-marginal scoring, per-protein mean
+pooling, FASTA token-budget batches through the model, and the 4-bit weight path.
+
+4-bit tolerances: the encoder / decoder kernels are byte work and must equal the oracle's
+restatement of the esme-q4 format BIT FOR BIT; the quantised forward is compared with the
+oracle's forward on the quantise->dequantise image of the same weights under the same
+floating-point rule as the bf16 model (tests/test_model_gpu.py).  Parity of the FORMAT with
+bitsandbytes is unpinned (third-party, absent) -- the drift against the bf16 model is
+reported instead (Frobenius-relative logits error, Spearman of the mask-margin scores).
+"""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN, load_golden, rel_fro
+from oracle import esm_oracle as O
+from esme import synthetic as syn
+from esme.alphabet import Alphabet, Alphabet3, tokenize, tokenize_unpad
+from test_model_gpu import assert_parity, build
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+FASTA = os.path.join(GOLDEN, 'data', 'test.fa')
+
+
+def build_q4(kind, L, E, H, seed):
+    from esme import ESM
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), f'{kind}_test', L, E, H, seed=seed)
+        return ESM.from_pretrained(path, quantization='4bit', device=DEV)
+
+
+def spearman(a, b):
+    from scipy.stats import spearmanr
+    return float(spearmanr(np.asarray(a), np.asarray(b)).statistic)
+
+
+# ------------------------------------------------------------ masked marginals
+@pytest.mark.parametrize('case', range(4))
+def test_predict_mask_margin_vs_reference(case):
+    from esme.variant import predict_mask_margin
+    with open(os.path.join(GOLDEN, 'g7_variant.json')) as f:
+        g = json.load(f)
+    c = g['scores'][case]
+    ref32 = next(s for s in g['scores'] if s['dtype'] == 'f32' and s['max_len'] == c['max_len'])
+    model = build(c['kind'], c['L'], c['E'], c['H'], c['seed'])
+    df = predict_mask_margin(model, g['short'], batch_size=c['batch_size'], max_len=c['max_len'])
+    assert list(df.index) == c['variants'] and list(df.columns) == ['score']
+    got, want32 = df['score'].to_numpy(), np.asarray(ref32['score'])
+    refbf = np.asarray(next(s for s in g['scores'] if s['dtype'] == 'bf16' and s['max_len'] == c['max_len'])['score'])
+    err, err_ref = np.abs(got - want32).max(), np.abs(refbf - want32).max()
+    print(f'\n[mask-margin] max|hip - ref_fp32| {err:.4f}; max|ref_bf16 - ref_fp32| {err_ref:.4f}; '
+          f'spearman {spearman(got, want32):.5f}')
+    assert err <= max(1.25 * err_ref, 0.05)            # scores are differences of bf16 log-probs (ulp 2^-6 at |x|~4)
+    assert spearman(got, want32) >= 0.995
+    wt_rows = [i for i, v in enumerate(c['variants']) if v[0] == v[-1]]
+    assert np.all(got[wt_rows] == 0.0)                  # wild type scores are exactly zero
+
+
+def test_masked_rows_equal_full_log_prob_rows():
+    """Gathering the masked row BEFORE the LM head == indexing predict_log_prob afterwards."""
+    from esme.variant import MaskMarginDataset, masked_row_log_prob, predict_pseudoperplexity
+    model = build('esm2', 2, 64, 4, 11)
+    seq = 'MEEPQSDPSVEPPLSQETFSDLWKLLPENNVLSPLPSQAMDDLMLSPDDIEQWFTEDPGPDEAP'
+    ds = MaskMarginDataset(seq, max_len=30, alphabet=Alphabet)
+    ds.token = tokenize([seq], alphabet=Alphabet)[0]
+    batch = ds.batch(5, 37)
+    got = masked_row_log_prob(model, batch['token'], batch['local_pos'])
+    full = model.predict_log_prob(batch['token'].to(DEV), pad_output=True)
+    want = full[torch.arange(32, device=DEV), batch['local_pos'].to(DEV)]
+    assert torch.equal(got, want)
+    # ragged user batch goes through the padded path
+    tok = batch['token'].clone()
+    tok[0, -4:] = Alphabet.padding_idx
+    got2 = masked_row_log_prob(model, tok, batch['local_pos'])
+    assert got2.shape == got.shape and torch.equal(got2[1:], got[1:])
+    # pseudo-perplexity == exp(mean NLL of the wild type) from the oracle's log-probs
+    w = {k: v.bfloat16() for k, v in syn.synthetic_state_dict('esm2', 2, 64, 11).items()}
+    rows, local = O.mask_margin_rows(ds.token, 30, mask_idx=Alphabet.mask_idx)
+    n, L = rows.shape
+    cu = torch.arange(0, (n + 1) * L, L, dtype=torch.int32)
+    lp = O.predict_log_prob(w, 4, rows.reshape(-1), cu, L, dtype=torch.float32).view(n, L, -1)
+    wt = torch.tensor([Alphabet.token_to_idx[a] for a in seq])
+    want_ppl = float(torch.exp(-lp[torch.arange(n), local, wt].double().mean()))
+    got_ppl = predict_pseudoperplexity(model, ds, batch_size=16, alphabet=Alphabet)
+    print(f'\n[pseudo-perplexity] hip {got_ppl:.4f} oracle-fp32 {want_ppl:.4f}')
+    assert abs(got_ppl - want_ppl) / want_ppl < 2e-2
+
+
+# -------------------------------------------------------------------- pooling
+def test_segment_mean_vs_reference_and_properties():
+    from esme.pooling import PartitionMeanPool, partition_mean_pool
+    g = load_golden('g9_pooling.npz')
+    x, cu = g['x'].to(DEV), g['cu_lens'].to(DEV)
+    got = partition_mean_pool(x, cu)
+    assert got.dtype == torch.float32 and torch.allclose(got.cpu(), g['pool_f32'], atol=1e-6, rtol=1e-6)
+    gb = PartitionMeanPool()(x.bfloat16(), cu)
+    assert gb.dtype == torch.bfloat16
+    exact = torch.stack([x.bfloat16().float()[a:b].mean(0) for a, b in zip(cu[:-1].tolist(), cu[1:].tolist())])
+    assert torch.equal(gb.float(), exact.bfloat16().float()) or (gb.float() - exact).abs().max() <= 2 ** -8 * exact.abs().max()
+    # fp32 accumulation is at least as close to the exact mean as the reference's bf16 index_add_
+    assert (gb.float().cpu() - exact.cpu()).abs().max() <= (g['pool_bf16'].float() - exact.cpu()).abs().max() + 1e-6
+    # known answer of the reference's tests/test_pooling.py:22-38 (E padded to the 8-column vector width)
+    embed = torch.zeros(7, 8, device=DEV)
+    embed[:, :3] = torch.arange(1, 22, dtype=torch.float32, device=DEV).view(7, 3)
+    out = partition_mean_pool(embed, torch.tensor([0, 3, 5, 7], device=DEV))
+    assert torch.equal(out[:, :3].cpu(), torch.tensor([[4., 5., 6.], [11.5, 12.5, 13.5], [17.5, 18.5, 19.5]]))
+    # ragged, wide, with an empty protein; mean * len == sum
+    rng = np.random.Generator(np.random.PCG64(2))
+    lens = [1, 0, 700, 33, 2, 1023]
+    cu2 = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int32, device=DEV)
+    big = torch.from_numpy(rng.standard_normal((sum(lens), 1280), dtype=np.float32)).to(DEV)
+    m = partition_mean_pool(big.bfloat16(), cu2).float()
+    for i, (a, b) in enumerate(zip(cu2[:-1].tolist(), cu2[1:].tolist())):
+        want = big.bfloat16().float()[a:b].sum(0) / max(b - a, 1)
+        assert torch.allclose(m[i], want, atol=2e-3, rtol=8e-3), i
+    assert bool((m[1] == 0).all())
+
+
+def test_fasta_batches_through_the_model():
+    """FastaTokenDataset items are forward inputs as they are; every protein's rows depend
+    only on that protein (same bits alone or inside a token-budget batch)."""
+    from esme.data import FastaTokenDataset
+    from esme.pooling import partition_mean_pool
+    model = build('esmc', 2, 128, 2, 21)
+    ds = FastaTokenDataset(FASTA, token_per_batch=1500, shuffle=False)
+    tok, (cu, max_len) = ds[0]
+    rep = model.forward_representation(tok.to(DEV), (cu.to(DEV), max_len))
+    assert rep.shape == (tok.numel(), 128)
+    pooled = partition_mean_pool(rep, cu.to(DEV))
+    assert pooled.shape == (len(ds.sampler[0]), 128)
+    t1, _, cu1, ml1 = tokenize_unpad([ds.read_seq(ds.sampler[0][1])], alphabet=Alphabet3)
+    alone = model.forward_representation(t1.to(DEV), (cu1.to(DEV), ml1))
+    a, b = int(cu[1]), int(cu[2])
+    assert torch.equal(alone, rep[a:b])
+
+
+# ------------------------------------------------------------------- esme-q4
+@pytest.mark.parametrize('name', ['fp4', 'nf4'])
+@pytest.mark.parametrize('shape', [(48, 256), (1280, 1280), (5, 64), (2560, 960)])
+def test_q4_kernels_bit_exact_vs_oracle(name, shape):
+    from esme import _hip
+    from esme.quantization import CODEBOOKS
+    cb = CODEBOOKS[name]
+    rng = np.random.Generator(np.random.PCG64(shape[0]))
+    w = torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * 0.03).bfloat16()
+    w[0, :64] = 0
+    w[-1, -64:] = torch.linspace(-1, 1, 64).bfloat16()      # hits exact codebook points / ties
+    codes, absmax = _hip.quantize_4bit(w.to(DEV), cb)
+    oc, oa = O.quantize_4bit(w, cb)
+    assert torch.equal(absmax.cpu(), oa)
+    assert torch.equal(codes.cpu(), oc)
+    d = _hip.dequantize_4bit(codes, absmax, cb)
+    assert torch.equal(d.cpu(), O.dequantize_4bit(oc, oa, cb))
+    sc = torch.from_numpy(rng.uniform(0.2, 2.0, shape[1]).astype(np.float32))
+    out = torch.full((shape[0] + 2, shape[1]), 7.0, dtype=torch.bfloat16, device=DEV)
+    d2 = _hip.dequantize_4bit(codes, absmax, cb, col_scale=sc.to(DEV), out=out[1:-1])
+    assert torch.equal(d2.cpu(), O.dequantize_4bit(oc, oa, cb, sc))
+    assert bool((out[0] == 7).all()) and bool((out[-1] == 7).all())
+    # a strided source (row slice of a wider buffer)
+    wide = torch.zeros(shape[0], shape[1] + 64, dtype=torch.bfloat16, device=DEV)
+    wide[:, :shape[1]] = w.to(DEV)
+    c3, a3 = _hip.quantize_4bit(wide[:, :shape[1]], cb)
+    assert torch.equal(c3, codes) and torch.equal(a3, absmax)
+
+
+def test_q4_api_errors():
+    from esme import _hip
+    from esme.quantization import FP4_CODEBOOK
+    with pytest.raises(RuntimeError, match='multiple of the block size'):
+        _hip.quantize_4bit(torch.zeros(4, 96, dtype=torch.bfloat16, device=DEV), FP4_CODEBOOK)
+    with pytest.raises(ValueError):
+        _hip.quantize_4bit(torch.zeros(4, 64, dtype=torch.bfloat16, device=DEV), FP4_CODEBOOK[:8])
+    with pytest.raises(RuntimeError, match='codebook'):
+        _hip.quantize_4bit(torch.zeros(4, 64, dtype=torch.bfloat16, device=DEV), [2.0] * 16)
+    with pytest.raises(TypeError):
+        _hip.quantize_4bit(torch.zeros(4, 64, device=DEV), FP4_CODEBOOK)
+
+
+@pytest.mark.parametrize('kind,L,E,H,seed,lengths', [('esm2', 2, 64, 4, 11, [5, 26, 61]),
+                                                     ('esmc', 2, 128, 2, 21, [7, 33, 50]),
+                                                     ('esm2', 1, 1280, 20, 3, [37, 70, 193]),
+                                                     ('esmc', 1, 960, 15, 22, [45, 150, 5])])
+def test_q4_model_vs_oracle_on_dequantised_weights(kind, L, E, H, seed, lengths):
+    from esme.quantization import Linear4bit, weight_bytes
+    model = build_q4(kind, L, E, H, seed)
+    sd = model.state_dict()
+    quant_keys = [k for k in sd if k.startswith('layers.') and k.endswith(O.QUANTISED_SUFFIXES)]
+    assert len(quant_keys) == L * (6 if kind == 'esm2' else 7)
+    assert all(sd[k].dtype == torch.uint8 for k in quant_keys)              # reference tests/test_esm.py:140-154
+    assert sd['embed_tokens.weight'].dtype == torch.bfloat16 and sd['lm_head.dense.weight'].dtype == torch.bfloat16
+    assert isinstance(model.layers[0].self_attn.q, Linear4bit)
+    w = {k: v.bfloat16() for k, v in syn.synthetic_state_dict(kind, L, E, seed).items()}
+    for k in w:                                                             # biases / norms untouched
+        if 'bias' in k or 'norm' in k:
+            assert torch.equal(sd[k].cpu(), w[k]), k
+    qw = O.quantized_weights(w)
+    # the resident codes are the oracle's codes
+    for k in quant_keys:
+        oc, _ = O.quantize_4bit(w[k])
+        assert torch.equal(sd[k].cpu(), oc), k
+    tokens = syn.random_tokens(lengths, seed=seed)
+    cu = syn.cu_lens_of(lengths)
+    ml = max(lengths)
+    ref32 = O.forward_logits(qw, H, tokens, cu, ml, dtype=torch.float32)
+    refbf = O.forward_logits(qw, H, tokens, cu, ml, dtype=torch.bfloat16)
+    got = model(tokens.to(DEV), (cu.to(DEV), ml))
+    assert_parity(got, ref32, refbf, f'q4 {kind} E={E} logits vs oracle(dequantised weights)')
+    # unfused stage path (LN kernel + plain GEMM on the expanded weights) agrees with the folded one
+    type(model).fold_layernorm, keep = False, type(model).fold_layernorm
+    try:
+        got_nofold = model(tokens.to(DEV), (cu.to(DEV), ml))
+    finally:
+        type(model).fold_layernorm = keep
+    assert_parity(got_nofold, ref32, refbf, f'q4 {kind} E={E} (no LN fold)')
+    # drift against the bf16 model + resident bytes
+    dense = build(kind, L, E, H, seed)
+    drift = rel_fro(got.float().cpu(), dense(tokens.to(DEV), (cu.to(DEV), ml)).float().cpu())
+    ratio = weight_bytes(model) / weight_bytes(dense)
+    print(f'\n[q4 drift] {kind} E={E}: rel_fro(q4 logits, bf16 logits) = {drift:.3f}; resident weight bytes '
+          f'{weight_bytes(model)} vs {weight_bytes(dense)} ({ratio:.2f}x)')
+    assert drift < 0.6
+    if E >= 960:
+        assert ratio < 0.45
+    # stand-alone module forward
+    lin = model.layers[0].self_attn.out
+    x = torch.randn(9, E, device=DEV).bfloat16()
+    want = torch.nn.functional.linear(x.float().cpu(), qw['layers.0.self_attn.out.weight'].float(),
+                                      w['layers.0.self_attn.out.bias'].float() if 'layers.0.self_attn.out.bias' in w else None)
+    assert rel_fro(lin(x).float().cpu(), want) < 1e-2
+
+
+def test_q4_mask_margin_drift_report():
+    """BASELINE config 5 in miniature: mask-margin scores of the 4-bit model track the bf16
+    model's (Spearman), on an ESM-C-shaped model."""
+    from esme.variant import predict_mask_margin
+    seq = 'MADQLTEEQIAEFKEAFSLFDKDGDGTITTKELGTVMRSLGQNPTEAELQDMINEVDADGNGTIDFPEFLTMMARK'
+    dense, q4 = build('esmc', 4, 256, 4, 31), build_q4('esmc', 4, 256, 4, 31)
+    a = predict_mask_margin(dense, seq, batch_size=16)['score'].to_numpy()
+    b = predict_mask_margin(q4, seq, batch_size=16)['score'].to_numpy()
+    rho = spearman(a, b)
+    print(f'\n[q4 mask-margin] spearman(q4, bf16) = {rho:.4f}; mean |delta| = {np.abs(a - b).mean():.4f}')
+    assert rho > 0.7
