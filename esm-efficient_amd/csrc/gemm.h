@@ -1,0 +1,51 @@
+// Declarations shared by the GEMM kernel and its launch code (and by the parked experiments
+// under tools/lab that build against the same argument block).
+#pragma once
+#include "common.h"
+#include "launch.h"
+
+namespace esme {
+
+struct GemmArgs {
+    const u16* A; int64_t lda;
+    const u16* W;
+    const u16* bias;
+    const u16* resid; int64_t ldr;
+    u16* C; int64_t ldc;
+    int64_t M; int N; int K;
+    float alpha;
+    int tiles_n;
+    int vec_ok;                  // C rows allow 16-byte stores (ldc % 8 == 0, 16-B aligned) and resid rows 8-byte loads
+    // fused rotary (QKV projection): columns < rot_cols are rotated with position pos[m]
+    const u16* cosT; const u16* sinT; const int32_t* pos; int max_len; int rot_cols;
+    // tile rasterisation: bands of gm tile-rows, inside a band groups of gn tile-columns walked
+    // column-major (gm = 1, gn = tiles_n is plain row-major)
+    int tiles_m, gm, gn;
+    int nt_store;                // tuning hook: 2 = skip the C stores, 3 = skip the whole epilogue (timing experiments only)
+    int stagger;                 // first-wave start skew (units of ~1024 cycles across the 256 first blocks)
+    // LayerNorm folded into the consumer GEMM (W already scaled by gamma):
+    //   y = rstd[m]*acc - (rstd*mean)[m]*c1[n] + c2[n];  mean/rstd of row m are reduced in-kernel from
+    //   ln_partial (ln_nblk, M, 2): per-block (sum, sum of squares) over ln_dim features
+    const float* ln_partial; int ln_nblk; int ln_dim; float ln_eps; const float* ln_c1; const float* ln_c2;
+    // residual epilogue also emits per-row partial (sum, sum of squares) of the ROUNDED output
+    // over each column tile of the launch: stats_out[(n/BN) * M + m] (float2) -> next LayerNorm's statistics
+    float* stats_out;
+    unsigned long long* trace = nullptr;      // ESME_GEMM_TRACE builds only: per-block phase timestamps (16 per block)
+};
+
+#ifdef ESME_GEMM_TRACE
+#define ESME_TRACE_MARK(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define ESME_TRACE_REAL(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ESME_TRACE_MARK(i) do {} while (0)
+#define ESME_TRACE_REAL(i) do {} while (0)
+#endif
+
+static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
+constexpr bool WTN_OK(int bn, int wn) { return bn / wn == 64; }
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+
+}  // namespace esme

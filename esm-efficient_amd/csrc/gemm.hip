@@ -16,42 +16,9 @@
 //
 // M/N edges: loads clamp the row index (re-reading a valid row), stores are guarded; the
 // only shape requirement is K % 64 == 0.
-#include "common.h"
-#include "launch.h"
+#include "gemm.h"
 
 namespace esme {
-
-struct GemmArgs {
-    const u16* A; int64_t lda;
-    const u16* W;
-    const u16* bias;
-    const u16* resid; int64_t ldr;
-    u16* C; int64_t ldc;
-    int64_t M; int N; int K;
-    float alpha;
-    int tiles_n;
-    int vec_ok;                  // C rows allow 16-byte stores (ldc % 8 == 0, 16-B aligned) and resid rows 8-byte loads
-    // fused rotary (QKV projection): columns < rot_cols are rotated with position pos[m]
-    const u16* cosT; const u16* sinT; const int32_t* pos; int max_len; int rot_cols;
-    // tile rasterisation: bands of gm tile-rows, inside a band groups of gn tile-columns walked
-    // column-major (gm = 1, gn = tiles_n is plain row-major)
-    int tiles_m, gm, gn;
-    int nt_store;                // (unused; kept for the tuning hook)
-    int stagger;                 // first-wave start skew (units of ~1024 cycles across the 256 first blocks)
-    // LayerNorm folded into the consumer GEMM (W already scaled by gamma):
-    //   y = rstd[m]*acc - (rstd*mean)[m]*c1[n] + c2[n];  mean/rstd of row m are reduced in-kernel from
-    //   ln_partial (ln_nblk, M, 2): per-block (sum, sum of squares) over ln_dim features
-    const float* ln_partial; int ln_nblk; int ln_dim; float ln_eps; const float* ln_c1; const float* ln_c2;
-    // residual epilogue also emits per-row partial (sum, sum of squares) of the ROUNDED output
-    // over each column tile of the launch: stats_out[(n/BN) * M + m] (float2) -> next LayerNorm's statistics
-    float* stats_out;
-};
-
-static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)
-constexpr bool WTN_OK(int bn, int wn) { return bn / wn == 64; }
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
@@ -76,6 +43,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, hi = lane >> 5;
+    ESME_TRACE_REAL(8);
+    ESME_TRACE_MARK(0);
 
     // Optional start skew for the first wave of workgroups: de-synchronises the CUs so that the
     // epilogue store bursts (and the prologue fetch bursts) of different CUs do not coincide.
@@ -230,6 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     }
 
     __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier; publishes the LN strip
+    ESME_TRACE_MARK(1);
     Frag f0, f1;
     rd(f0, smem, 0);
     for (int kt = 0; kt < KT; ++kt) {
@@ -258,6 +228,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                          // all waves past their last LDS fragment use before the slab overwrites it
+    ESME_TRACE_MARK(2);
+    if (a.nt_store == 3) return;              // tuning hook: main loop only (results discarded)
 
     // ---- epilogue.  Lane owns token row m; accumulator quad g = 4 consecutive output columns.
     // Fast path: bias / activation / residual are applied in the accumulator layout, the bf16
@@ -357,6 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         }
     }
 
+    ESME_TRACE_MARK(3);
     if (a.vec_ok) {
         // Branch-free: every load of the epilogue (bias quads, residual quads) is issued up front
         // with clamped addresses (overhanging rows/columns are computed but never stored), so the
@@ -398,6 +371,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        ESME_TRACE_MARK(4);
 #pragma unroll
         for (int i = 0; i < FNE; ++i) {
 #pragma unroll
@@ -437,6 +411,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
         __builtin_amdgcn_wave_barrier();
+        ESME_TRACE_MARK(5);
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
         const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
@@ -447,7 +422,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
-                if (col_ok && m < a.M) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+                if (col_ok && m < a.M && a.nt_store != 2) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
@@ -465,6 +440,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
         }
+        ESME_TRACE_MARK(6);
         if constexpr (STATS) {
             __syncthreads();
             if (tid < BM && m0 + tid < a.M) {
@@ -474,6 +450,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(n0 / BN) * a.M + m0 + tid)) = acc2;
             }
         }
+        ESME_TRACE_MARK(7);
+        ESME_TRACE_REAL(9);
         return;
     }
 
@@ -573,6 +551,8 @@ extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
 extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
 extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
 extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
+static unsigned long long* g_trace = nullptr;     // honoured by ESME_GEMM_TRACE builds only
+extern "C" void esme_hip_debug_set_gemm_trace(void* p) { g_trace = (unsigned long long*)p; }
 
 // 256x256 tiles (one workgroup per CU) once they fill the chip about twice over; otherwise the
 // 128x128 configuration (2-3 workgroups per CU, 4x the tiles) keeps more CUs busy.
@@ -610,6 +590,7 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
                nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr};
+    a.trace = g_trace;
     int rotd = 0;
     bool lnf = false, stats = false;
     if (fu) {

@@ -46,6 +46,16 @@ variants = {
     'ffn2 resid+stats':     lambda: _hip.gemm_fused(h4, w2, b2, _hip.EPI_RESIDUAL, y, 1.0, y, stats_out=partial),
     'ffn2 plain(no resid)': lambda: _hip.gemm_fused(h4, w2, b2, out=y),
 }
+def dbg(v, fn):
+    def run():
+        _hip.load().esme_hip_debug_set_gemm_nt(v)
+        fn()
+        _hip.load().esme_hip_debug_set_gemm_nt(0)
+    return run
+if os.environ.get('EPI_ABLATE', '1') == '1':
+    for k in ('qkv +rot+lnf', 'out resid+stats', 'ffn1 gelu+lnf', 'ffn2 resid+stats'):
+        variants[k + ' [no C store]'] = dbg(2, variants[k])
+        variants[k + ' [loop only]'] = dbg(3, variants[k])
 flops = {'qkv': 2 * T * 3 * E * E, 'out': 2 * T * E * E, 'ffn1': 2 * T * 4 * E * E, 'ffn2': 2 * T * 4 * E * E}
 ROUNDS, ITERS = int(os.environ.get('ROUNDS', 5)), int(os.environ.get('ITERS', 20))
 times = {k: [] for k in variants}

@@ -522,6 +522,141 @@ static void launch_pp(LabArgs a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_n * a.tiles_m), dim3(512), smem, s, a);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Variant T: Q generalised over the wave grid: 2 x WNW waves (WNW = 4: wave tile 128 x 64, 2 waves/SIMD;
+// WNW = 2: wave tile 128 x 128, ONE wave/SIMD with 256 accumulator AGPRs).  FLAGS bit3: no LDS reads in
+// the loop (fragments stay constant); bit4: no LDS-DMA in the loop; bit5: no barrier in the loop.
+template <int WNW, int FLAGS>
+__global__ __launch_bounds__(128 * WNW) void lab_gemm_t(const LabArgs a) {
+    constexpr int BM = 256, BN = 256, WM = 2;
+    constexpr int NW = 2 * WNW, NT = NW * 64, WTM = 128, WTN = 256 / WNW, FM = 4, FN = WTN / 32;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, IA = 2048 / NT, IW = 2048 / NT, IH = IA / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM, l31 = lane & 31, hi = lane >> 5;
+    unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = pid % a.tiles_n; const int64_t tile_m = pid / a.tiles_n;
+    const int64_t m0 = tile_m * BM; const int n0 = tile_n * BN;
+    const int64_t lm0 = (FLAGS & 1) ? 0 : m0; const int ln0 = (FLAGS & 1) ? 0 : n0;
+    const u16* srcA[IA]; const u16* srcW[IW];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) { const int q = (i * NW + wave) * 64 + lane; const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+        int64_t gr = lm0 + row; gr = gr < a.M ? gr : a.M - 1; srcA[i] = a.A + gr * a.lda + c * 8; }
+#pragma unroll
+    for (int i = 0; i < IW; ++i) { const int q = (i * NW + wave) * 64 + lane; const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+        int gr = ln0 + row; gr = gr < a.N ? gr : a.N - 1; srcW[i] = a.W + (int64_t)gr * a.K + c * 8; }
+    auto stageA = [&](int kt, int buf, int i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + kt * 64), (lptr_t)(smem + buf * STAGE + (i * NW + wave) * 1024), 16, 0, 0); };
+    auto stageW = [&](int kt, int buf, int i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + kt * 64), (lptr_t)(smem + buf * STAGE + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0); };
+    const int swz = (l31 >> 1) & 7; int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + hi) ^ swz) << 4;
+    const int rowA = (wm * WTM + l31) * 128, rowW = A_BYTES + (wn * WTN + l31) * 128;
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct Frag { bf16x8 w[FN], a[FM]; };
+    auto rd = [&](Frag& f, const char* base, int ks) {
+        if (FLAGS & 8) return;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 4096 + coff[ks]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 4096 + coff[ks]);
+    };
+    auto rd_init = [&](Frag& f, const char* base, int ks) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 4096 + coff[ks]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 4096 + coff[ks]);
+    };
+    auto mm = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
+    };
+    // touch prefetch: one 4-byte LDS-DMA per lane pulls the 128-B line of row (tid) of [A rows | W rows] of
+    // K-tile kt+TD into L2 ahead of the real LDS-DMA (needs NT == 512: one lane per tile row)
+    constexpr int TD = 2;
+    const u16* tsrc;
+    { const int r = tid & 255;
+      if (tid < 256) { int64_t gr = lm0 + r; gr = gr < a.M ? gr : a.M - 1; tsrc = a.A + gr * a.lda; }
+      else { int gr = ln0 + r; gr = gr < a.N ? gr : a.N - 1; tsrc = a.W + (int64_t)gr * a.K; } }
+    auto dma = [&](int kt, int buf, int half) {
+        if (FLAGS & 16) return;
+#pragma unroll
+        for (int i = 0; i < IH; ++i) { stageA(kt, buf, half * IH + i); stageW(kt, buf, half * IH + i); }
+    };
+    const int KT = a.K / 64;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) { stageA(0, 0, i); stageW(0, 0, i); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    rd_init(f0, smem, 0);
+    rd_init(f1, smem, 1);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const char* base = smem + buf * STAGE;
+        const bool more = kt + 1 < KT;
+        rd(f1, base, 1);
+        if (more) dma(kt + 1, buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(f0, base, 2);
+        if (more) dma(kt + 1, buf ^ 1, 1);
+        const bool touch = (FLAGS & 128) && (kt + TD < KT);
+        if (touch) __builtin_amdgcn_global_load_lds((gptr_t)(tsrc + (kt + TD) * 64), (lptr_t)(smem + 2 * STAGE + wave * 256), 4, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(f1, base, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FLAGS & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (touch) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (!(FLAGS & 32)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) rd(f0, smem + (buf ^ 1) * STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((FLAGS & 2) && a.K > 0) return;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int64_t m = m0 + wm * WTM + j * 32 + l31;
+                if (m >= a.M) continue;
+                u32x2 pk = {pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+                *reinterpret_cast<u32x2*>(a.C + m * a.ldc + n) = pk;
+            }
+        }
+}
+
+template <int WNW, int FLAGS>
+static void launch_t(LabArgs a, hipStream_t s) {
+    constexpr int smem = 2 * 512 * 128 + 2048;
+    a.tiles_n = (a.N + 255) / 256; a.tiles_m = (int)((a.M + 255) / 256);
+    auto kern = lab_gemm_t<WNW, FLAGS>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_n * a.tiles_m), dim3(128 * WNW), smem, s, a);
+}
+
 template <int BM, int BN, int WM, int WN, int FLAGS>
 static void launch(LabArgs a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
@@ -560,6 +695,28 @@ extern "C" int lab_run(int variant, const void* A, const void* W, void* C, int64
         case 20: launch_s<0>(a, s); break;
         case 21: launch_s<2>(a, s); break;
         case 22: launch_s<3>(a, s); break;
+        case 23: launch<256, 256, 2, 2, 0>(a, s); break;  // 4 waves, wave tile 128 x 128, 1 wave/SIMD
+        case 24: launch<256, 256, 2, 2, 2>(a, s); break;
+        case 25: launch<256, 256, 2, 2, 3>(a, s); break;
+        case 30: launch_t<4, 0>(a, s); break;
+        case 31: launch_t<4, 3>(a, s); break;
+        case 32: launch_t<4, 3 + 8>(a, s); break;
+        case 33: launch_t<4, 3 + 8 + 16>(a, s); break;
+        case 34: launch_t<4, 3 + 8 + 16 + 32>(a, s); break;
+        case 35: launch_t<4, 3 + 16>(a, s); break;
+        case 38: launch_t<4, 2>(a, s); break;
+        case 39: launch_t<4, 2 + 128>(a, s); break;
+        case 50: launch_t<4, 128>(a, s); break;
+        case 36: launch_t<4, 3 + 64>(a, s); break;
+        case 37: launch_t<4, 3 + 8 + 64>(a, s); break;
+        case 46: launch_t<2, 3 + 64>(a, s); break;
+        case 47: launch_t<2, 3 + 8 + 64>(a, s); break;
+        case 40: launch_t<2, 0>(a, s); break;
+        case 41: launch_t<2, 3>(a, s); break;
+        case 42: launch_t<2, 3 + 8>(a, s); break;
+        case 43: launch_t<2, 3 + 8 + 16>(a, s); break;
+        case 44: launch_t<2, 3 + 8 + 16 + 32>(a, s); break;
+        case 45: launch_t<2, 3 + 16>(a, s); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
