@@ -158,6 +158,97 @@ __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* _
     }
 }
 
+
+// ------------------------------------------- q/k LayerNorm + rotary (ESM-C)
+// ESM-C normalises q and k over the FULL embedding width between the projection and the rotary
+// (attention.py:104-105), so that LayerNorm cannot ride in a GEMM epilogue (a row spans several
+// column tiles).  One wave per (row, q|k): the row stays in registers, gets normalised, rounded to
+// bf16 (the value the stand-alone LayerNorm kernel would have written) and rotated in place; the
+// rotary partner of a lane's 8 elements (d/2 further inside the head) lives d/16 lanes away, so
+// the exchange is four 32-bit lane shuffles.  One read + one write of q and k: 8*E bytes per row,
+// instead of three passes (two LayerNorms + rotary).
+template <int NCH>
+__global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q, u16* __restrict__ k, int64_t ld,
+                                                             const u16* __restrict__ wq, const u16* __restrict__ wk,
+                                                             const u16* __restrict__ bq, const u16* __restrict__ bk,
+                                                             float eps, const u16* __restrict__ cosT,
+                                                             const u16* __restrict__ sinT, const int32_t* __restrict__ pos,
+                                                             int64_t T, int E, int d, int max_len) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = item >> 1;
+    if (row >= T) return;
+    const bool is_k = item & 1;
+    u16* xr = (is_k ? k : q) + row * ld;
+    const u16* w = is_k ? wk : wq;
+    const u16* b = is_k ? bk : bq;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float inv_e = 1.0f / (float)E;
+    const float mean = wave_sum(s) * inv_e;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dv = v[c][j] - mean; ss += dv * dv; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
+    int p = pos[row];
+    p = p < max_len ? p : max_len - 1;
+    const int half = d >> 1, shift = d >> 4;            // partner lane = lane ^ shift
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        const bool ok = e0 < E;
+        u32x4 y = {0u, 0u, 0u, 0u};
+        if (ok) {
+            float wf[8], o[8];
+            unpack8(*reinterpret_cast<const u32x4*>(w + e0), wf);
+            if (b) {
+                float bfv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(b + e0), bfv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
+            }
+            y = pack8(o);                                 // bf16 rounding point of the LayerNorm output
+        }
+        u32x4 other;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
+        if (ok) {
+            const int local = e0 % d;
+            const bool lower = local < half;
+            const int jc = lower ? local : local - half;
+            float a[8], o2[8], cs[8], sn[8], r[8];
+            unpack8(y, a);
+            unpack8(other, o2);
+            unpack8(*reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc), cs);
+            unpack8(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc), sn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = lower ? a[j] * cs[j] - o2[j] * sn[j] : a[j] * cs[j] + o2[j] * sn[j];
+            *reinterpret_cast<u32x4*>(xr + e0) = pack8(r);
+        }
+    }
+}
+
 // ------------------------------------------------------------- row softmax
 // V <= 64: one wave per row, one lane per column.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* __restrict__ x, int64_t ldx,
@@ -369,4 +460,32 @@ extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* 
     else
         hipLaunchKernelGGL(segment_mean_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, cu_lens, E, out, ldo);
     return check_launch("segment_mean");
+}
+
+extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                       const void* bk, float eps, const void* cosT, const void* sinT,
+                                       const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && heads > 0 && head_dim > 0 && max_len > 0, "qk_norm_rotary: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(q && k && wq && wk && cosT && sinT && pos, "qk_norm_rotary: null pointer");
+    if (head_dim != 16 && head_dim != 32 && head_dim != 64 && head_dim != 128)
+        ESME_FAIL(ESME_ERR_UNSUPPORTED, "qk_norm_rotary: head dim must be 16, 32, 64 or 128");
+    const int64_t E64 = (int64_t)heads * head_dim;
+    if (E64 > 5120) ESME_FAIL(ESME_ERR_UNSUPPORTED, "qk_norm_rotary: heads * head_dim > 5120 unsupported");
+    const int E = (int)E64;
+    ESME_CHECK_ARG(ld % 8 == 0 && ld >= E, "qk_norm_rotary: bad row stride");
+    ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(wq) && aligned16(wk) && (!bq || aligned16(bq)) &&
+                   (!bk || aligned16(bk)) && aligned16(cosT) && aligned16(sinT), "qk_norm_rotary: misaligned");
+    const dim3 grid((unsigned int)((2 * T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_QKN(N)                                                                                                 \
+    hipLaunchKernelGGL(qk_norm_rotary_kernel<N>, grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
+                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len)
+    if (E <= 512) ESME_QKN(1);
+    else if (E <= 1024) ESME_QKN(2);
+    else if (E <= 1536) ESME_QKN(3);
+    else if (E <= 2560) ESME_QKN(5);
+    else ESME_QKN(10);
+#undef ESME_QKN
+    return check_launch("qk_norm_rotary");
 }

@@ -17,8 +17,8 @@ statistics reductions, no elementwise pass over HBM):
 
 The LayerNorm fold:  LN(x) W^T + b = rstd*(x W'^T) - rstd*mean*c1 + c2  with W' = W*diag(gamma),
 c1[n] = sum_k W'[n,k], c2[n] = sum_k beta[k] W[n,k] + b[n]; no normalised copy of x is written.
-ESM-C (q/k LayerNorm between projection and rotary) keeps separate LN / rotary kernels for
-those two steps.  The stage methods named like the reference's (`_qkv`, `_attn`) run the
+ESM-C (q/k LayerNorm over the full width between projection and rotary) runs those two steps
+as ONE in-place kernel over q and k (`esme_hip_qk_norm_rotary`).  The stage methods named like the reference's (`_qkv`, `_attn`) run the
 unfused kernels (LN kernel, plain GEMM, rotary kernel) and are what the stage-tap tests use.
 """
 from __future__ import annotations
@@ -186,12 +186,20 @@ class FlashMultiheadAttention(nn.Module):
         else:
             w, b, _, _ = self._weights_qkv(False)
             qkv = _hip.gemm_fused(self.norm(x), w, b, rot=rot)
-        q, k, v = self._split_qkv(qkv)                      # ESM-C: q/k LayerNorm in place
-        if self.rot_emb is not None and rot is None:
-            if ctx is not None:
-                _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
-            else:
-                q, k = self.rot_emb(q, k, cu_lens, max_len)
+        if (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128)
+                and E <= 5120):
+            # ESM-C: q/k LayerNorm over the full width + rotary in ONE in-place pass over q and k
+            _hip.qk_norm_rotary_(qkv[:, :E], qkv[:, E:2 * E], self.layernorm_q.weight, self.layernorm_k.weight,
+                                 self.layernorm_q.bias, self.layernorm_k.bias, self.layernorm_q.eps,
+                                 ctx.cos, ctx.sin, ctx.pos, H)
+            q, k, v = (qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
+        else:
+            q, k, v = self._split_qkv(qkv)                  # ESM-C: q/k LayerNorm in place
+            if self.rot_emb is not None and rot is None:
+                if ctx is not None:
+                    _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
+                else:
+                    q, k = self.rot_emb(q, k, cu_lens, max_len)
         a = self._attn(q, k, v, cu_lens, max_len)
         wo, bo = self._weights_out()
         if resid is not None:

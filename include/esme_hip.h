@@ -79,6 +79,16 @@ int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cos, const 
                            const int32_t* pos, int64_t T, int H, int d, int max_len,
                            void* stream);
 
+/* ESM-C's q/k normalisation + rotary in one in-place pass: for x in {q, k} (each (T, H*d) with
+ * row stride ld):  x <- rotary(bf16(LayerNorm_{H*d}(x) * w + b)), b may be NULL.  Bit-identical
+ * to esme_hip_layernorm on q and on k followed by esme_hip_rotary_varlen; d in {16,32,64,128}.
+ * Replaces: layernorm_q / layernorm_k (esme/attention.py:88-89,104-105) + RotaryEmbedding.forward
+ * (esme/rotary.py:151-165). */
+int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk,
+                            const void* bq, const void* bk, float eps, const void* cos,
+                            const void* sin, const int32_t* pos, int64_t T, int H, int d,
+                            int max_len, void* stream);
+
 /* Varlen (block-diagonal) multi-head self-attention, non-causal, no dropout:
  * per sequence i and head h, O = softmax(Q K^T * softmax_scale) V over that sequence's
  * rows only.  q, k, v: (T, H, d) views with row stride ld_qkv; o: (T, H*d) with row

@@ -350,3 +350,36 @@ def test_error_reporting():
         _hip.gemm(a, w)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _hip.layernorm(rnd((4, 64), 1), rnd((64,), 2))
+
+
+@pytest.mark.parametrize('T,H,d,bias', [(300, 15, 64, False), (77, 18, 64, False), (130, 4, 32, True), (64, 20, 16, False),
+                                        (50, 8, 128, True), (257, 40, 128, False)])
+def test_qk_norm_rotary_fused_equals_unfused(T, H, d, bias):
+    """ESM-C's q/k LayerNorm + rotary as one pass == LayerNorm kernel on q, on k, then the rotary kernel,
+    bit for bit (same fp32 arithmetic, same bf16 rounding points), and within tolerance of torch."""
+    from esme import _hip
+    DEV = torch.device('cuda', 0)
+    E = H * d
+    g = torch.Generator().manual_seed(T + d)
+    qkv = (torch.randn(T, 3 * E, generator=g) * 1.7 + 0.3).bfloat16().to(DEV)
+    wq, wk = (torch.rand(E, generator=g) + 0.5).bfloat16().to(DEV), (torch.rand(E, generator=g) + 0.5).bfloat16().to(DEV)
+    bq = (torch.randn(E, generator=g) * 0.1).bfloat16().to(DEV) if bias else None
+    bk = (torch.randn(E, generator=g) * 0.1).bfloat16().to(DEV) if bias else None
+    lens = [T // 3, T - T // 3]
+    cu = torch.tensor([0, lens[0], T], dtype=torch.int32, device=DEV)
+    pos, _ = _hip.seq_positions(cu, T)
+    cos, sin = (t.to(DEV) for t in O.rotary_tables(max(lens), d, torch.bfloat16))
+    a = qkv.clone()
+    _hip.layernorm(a[:, :E], wq, bq, 1e-5, a[:, :E])
+    _hip.layernorm(a[:, E:2 * E], wk, bk, 1e-5, a[:, E:2 * E])
+    _hip.rotary_(a[:, :E], a[:, E:2 * E], cos, sin, pos, H)
+    b = qkv.clone()
+    _hip.qk_norm_rotary_(b[:, :E], b[:, E:2 * E], wq, wk, bq, bk, 1e-5, cos, sin, pos, H)
+    assert torch.equal(a, b)
+    assert torch.equal(b[:, 2 * E:], qkv[:, 2 * E:])                    # v untouched
+    x = qkv.float().cpu()
+    for part, (w, bb) in enumerate(((wq, bq), (wk, bk))):
+        y = torch.nn.functional.layer_norm(x[:, part * E:(part + 1) * E], (E,), w.float().cpu(),
+                                           bb.float().cpu() if bb is not None else None)
+        r = O.apply_rotary(y.view(T, H, d), cos.float().cpu(), sin.float().cpu(), pos.cpu().long()).reshape(T, E)
+        assert rel_fro(b[:, part * E:(part + 1) * E].float().cpu(), r) < 6e-3

@@ -168,3 +168,21 @@ def test_large_batch_properties():
     back = torch.cat([out2[syn.cu_lens_of(l2)[j]:syn.cu_lens_of(l2)[j + 1]] for j in
                       sorted(range(len(order)), key=lambda j: order[j])])
     assert torch.equal(back, out)
+
+
+@pytest.mark.parametrize('kind,L,E,H,lengths', [('esm2', 1, 2560, 20, [150, 70, 33]),       # head dim 128 (the ESM2-15B head)
+                                                ('esm2', 2, 320, 20, [9, 300]),             # head dim 16 (ESM2-8M)
+                                                ('esmc', 1, 1152, 18, [40, 260])])          # ESM-C 600M width
+def test_other_head_dims_vs_oracle(kind, L, E, H, lengths):
+    """Model widths / head dims without a golden fixture: HIP forward vs the oracle on the same
+    synthetic weights (the oracle itself is pinned by the goldens)."""
+    seed = 40 + E // 64
+    model = build(kind, L, E, H, seed)
+    w = {k: v.bfloat16() for k, v in syn.synthetic_state_dict(kind, L, E, seed).items()}
+    tokens = syn.random_tokens(lengths, seed=seed)
+    cu = syn.cu_lens_of(lengths)
+    ml = max(lengths)
+    ref32 = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.float32)
+    refbf = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.bfloat16)
+    got = model(tokens.to(DEV), (cu.to(DEV), ml))
+    assert_parity(got, ref32, refbf, f'{kind} E={E} H={H} (d={E // H}) logits vs oracle')
