@@ -23,6 +23,29 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
     }
 }
 
+// token row (+ `<mask>` zeroing) + learned-position row, one rounding: ESM-1b / ESM-1v
+__global__ __launch_bounds__(256) void embed_pos_kernel(const int64_t* __restrict__ tokens,
+                                                        const u32x4* __restrict__ table,
+                                                        const u32x4* __restrict__ pos_table,
+                                                        const int32_t* __restrict__ pos_idx, int pos_offset,
+                                                        u32x4* __restrict__ out, int64_t T, int chunks, int V, int P,
+                                                        int mask_idx) {
+    const int64_t total = T * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / chunks;
+        const int c = (int)(i - t * chunks);
+        const int64_t tok = tokens[t];
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[8];
+        if (tok != mask_idx && tok >= 0 && tok < V) unpack8(table[tok * chunks + c], a);
+        int p = pos_idx[t] + pos_offset;
+        p = p < 0 ? 0 : (p < P ? p : P - 1);
+        unpack8(pos_table[(int64_t)p * chunks + c], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        out[i] = pack8(a);
+    }
+}
+
 // ------------------------------------------------------- sequence positions
 // binary search of the row in cu_lens (B+1 entries, L2 resident)
 __global__ __launch_bounds__(256) void seqpos_kernel(const int32_t* __restrict__ cu, int B, int64_t T,
@@ -488,4 +511,19 @@ extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void*
     else ESME_QKN(10);
 #undef ESME_QKN
     return check_launch("qk_norm_rotary");
+}
+
+extern "C" int esme_hip_embed_positions(const int64_t* tokens, const void* table, const void* pos_table,
+                                        const int32_t* pos_idx, int pos_offset, void* out, int64_t T, int E, int V,
+                                        int P, int mask_idx, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0 && V > 0 && P > 0, "embed_positions: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(tokens && table && pos_table && pos_idx && out, "embed_positions: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && aligned16(table) && aligned16(pos_table) && aligned16(out),
+                   "embed_positions: E %% 8 != 0 or misaligned");
+    const int chunks = E / 8;
+    hipLaunchKernelGGL(embed_pos_kernel, dim3(grid_for(T * chunks, 256)), dim3(256), 0, (hipStream_t)stream, tokens,
+                       (const u32x4*)table, (const u32x4*)pos_table, pos_idx, pos_offset, (u32x4*)out, T, chunks, V, P,
+                       mask_idx);
+    return check_launch("embed_positions");
 }

@@ -33,6 +33,8 @@ SIGNATURES = {
     'esme_hip_abi_version': (c_int, []),
     'esme_hip_last_error': (c_char_p, []),
     'esme_hip_embed': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_embed_positions': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
+                                         c_int, c_int, c_void_p]),
     'esme_hip_seq_positions': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     'esme_hip_layernorm': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                    c_float, c_void_p]),
@@ -157,6 +159,20 @@ def embed(tokens: torch.Tensor, table: torch.Tensor, mask_idx: int = -1, pad_idx
     out = torch.empty(tok.numel(), E, dtype=torch.bfloat16, device=table.device)
     _check(load().esme_hip_embed(_dev(tok, 'embed tokens', torch.int64), _dev(table.contiguous(), 'embed table', torch.bfloat16),
                                  out.data_ptr(), tok.numel(), E, V, mask_idx, pad_idx, _stream()), 'esme_hip_embed')
+    return out.view(*tokens.shape, E)
+
+
+def embed_positions(tokens: torch.Tensor, table: torch.Tensor, pos_table: torch.Tensor, pos_idx: torch.Tensor,
+                    pos_offset: int, mask_idx: int = -1) -> torch.Tensor:
+    """Token rows (`<mask>` zeroed) + learned-position rows pos_table[pos_idx + pos_offset] (ESM-1b / 1v)."""
+    tok = tokens.reshape(-1).contiguous()
+    V, E = table.shape
+    out = torch.empty(tok.numel(), E, dtype=torch.bfloat16, device=table.device)
+    _check(load().esme_hip_embed_positions(
+        _dev(tok, 'embed tokens', torch.int64), _dev(table.contiguous(), 'embed table', torch.bfloat16),
+        _dev(pos_table.contiguous(), 'position table', torch.bfloat16),
+        _dev(pos_idx.reshape(-1).contiguous(), 'position index', torch.int32), int(pos_offset), out.data_ptr(),
+        tok.numel(), E, V, pos_table.shape[0], mask_idx, _stream()), 'esme_hip_embed_positions')
     return out.view(*tokens.shape, E)
 
 

@@ -10,7 +10,8 @@ edits.  Everything arithmetic runs in HIP kernels behind `esme._hip`; a tensor
 that is not on a HIP device raises (there is no CPU fallback).
 
 `quantization='4bit'` keeps the layer projections 4-bit in HBM (esme/quantization.py).
-Out of scope here: ESM-1b/1v, LoRA management, 8-bit loaders,
+ESM-1b / ESM-1v (learned positions, no rotary) run on the same kernels (`ESM1b`, `ESM1v`).
+Out of scope here: LoRA management, 8-bit loaders,
 activation checkpointing (training only), hub download (no network).
 """
 from __future__ import annotations
@@ -26,10 +27,11 @@ from esme import _hip
 from esme.alphabet import Alphabet, Alphabet3
 from esme.attention import FlashTransformerLayer, ForwardContext
 from esme.head import RobertaLMHead
+from esme.embedding import LearnedPositionalEmbedding
 from esme.nn import LayerNorm
 
 model_names = ['esm2_8m', 'esm2_35m', 'esm2_150m', 'esm2_650m', 'esm2_3b', 'esm2_15b',
-               'esmc_300m', 'esmc_600m']
+               'esmc_300m', 'esmc_600m', 'esm1b', 'esm1v']
 
 
 def _read_metadata(path: str) -> dict:
@@ -52,8 +54,10 @@ class ESM(nn.Module):
             return ESM2.from_pretrained(path, quantization, checkpointing, device)
         if name == 'esmc':
             return ESMC.from_pretrained(path, quantization, checkpointing, device)
-        if name in ('esm1b', 'esm1v'):
-            raise NotImplementedError(f'{name} (learned positions) is not on the MI355X hot path yet')
+        if name == 'esm1b':
+            return ESM1b.from_pretrained(path, quantization, checkpointing, device)
+        if name == 'esm1v':
+            return ESM1v.from_pretrained(path, quantization, checkpointing, device)
         raise ValueError(f'Invalid model name: {name}. Must be one of {model_names}')
 
 
@@ -236,3 +240,61 @@ class ESMC(ESM2):
         # the reference compares against the *argument* list here (esm.py:873) -- reproduced as is
         assert all(i < len(layers) for i in layers), \
             f'Invalid layer indices {layers}. The number of layers in the model is {len(self.layers)}.'
+
+
+class _LearnedPositionESM(ESM2):
+    """Shared part of ESM-1b / ESM-1v (reference esme/esm.py:618-735): ESM-2's transformer stack without
+    rotary, plus a learned position table added to the token embedding.  The reference fixes the size at
+    33 x 1280 x 20; the dimensions are arguments here (same defaults) so small instances can be tested."""
+    norm_before = False
+
+    def __init__(self, checkpointing: bool = False, dtype=torch.bfloat16, num_layers: int = 33,
+                 embed_dim: int = 1280, attention_heads: int = 20):
+        super().__init__(num_layers=num_layers, embed_dim=embed_dim, attention_heads=attention_heads,
+                         checkpointing=checkpointing, rotary_embedding=False, dtype=dtype)
+        if self.norm_before:
+            self.emb_layer_norm_before = LayerNorm(embed_dim, dtype=dtype)
+        self.embed_positions = LearnedPositionalEmbedding(4096, embed_dim, dtype=dtype)
+
+    def embedding(self, tokens, pad_args=None):
+        """token rows (`<mask>` zeroed) + learned position rows [-> LayerNorm (ESM-1b)] -> `<pad>` rows zeroed
+        (esm.py:634-652 / :694-711)."""
+        pe = self.embed_positions
+        if tokens.ndim == 2:
+            assert pad_args is None, 'pad_args must be None for esm1b with 2D tokens'
+            idx, offset = pe.positions(tokens).to(torch.int32), 0
+        elif tokens.ndim == 1:
+            assert pad_args is not None, 'pad_args must be provided for esm1b with 1D tokens'
+            cu_lens, max_len = pad_args
+            if int(max_len) > pe.max_positions:
+                raise ValueError(f'Sequence length {max_len} above maximum  sequence length of {pe.max_positions}')
+            idx, offset = _hip.seq_positions(cu_lens, tokens.numel())[0], pe.padding_idx + 1
+        else:
+            raise ValueError('tokens must be 1D or 2D for esm1v')
+        x = _hip.embed_positions(tokens, self.embed_tokens.weight, pe.weight, idx, offset,
+                                 mask_idx=self.alphabet.mask_idx)
+        if self.norm_before:
+            x2 = x.view(-1, x.shape[-1])
+            self.emb_layer_norm_before(x2, out=x2)
+        if tokens.ndim == 2:
+            x.masked_fill_(tokens.eq(self.alphabet.padding_idx).unsqueeze(-1), 0.0)   # row selection, no arithmetic
+        return x
+
+    @classmethod
+    def create_model(cls, path, checkpointing=False):
+        md = _read_metadata(path)
+        name = md['name'].split('_')[0]
+        assert name == cls.__name__.lower(), \
+            f'Invalid weight for the {cls.__name__} model. ' \
+            f'You are trying to load a {name} model weights to a {cls.__name__} model.'
+        with torch.device('meta'):
+            return cls(checkpointing=checkpointing, num_layers=int(md.get('num_layers', 33)),
+                       embed_dim=int(md.get('embed_dim', 1280)), attention_heads=int(md.get('attention_heads', 20)))
+
+
+class ESM1b(_LearnedPositionESM):
+    norm_before = True
+
+
+class ESM1v(_LearnedPositionESM):
+    norm_before = False

@@ -25,6 +25,8 @@ MODEL_ZOO = {
     'esm2_150m': ('esm2', 30, 640, 20),
     'esm2_650m': ('esm2', 33, 1280, 20),
     'esm2_3b':   ('esm2', 36, 2560, 40),
+    'esm1b':     ('esm1b', 33, 1280, 20),
+    'esm1v':     ('esm1v', 33, 1280, 20),
     'esmc_300m': ('esmc', 30, 960, 15),
     'esmc_600m': ('esmc', 36, 1152, 18),
 }
@@ -39,9 +41,14 @@ def tensor_shapes(kind: str, num_layers: int, embed_dim: int) -> Dict[str, Tuple
     """Checkpoint tensor names and shapes, in file order, for an ESM-2 or ESM-C model."""
     E = embed_dim
     shapes: Dict[str, Tuple[int, ...]] = {}
-    if kind == 'esm2':
+    if kind in ('esm2', 'esm1b', 'esm1v'):
         V, F = 33, 4 * E
         shapes['embed_tokens.weight'] = (V, E)
+        if kind != 'esm2':                      # learned positions (+ LayerNorm before, ESM-1b)
+            shapes['embed_positions.weight'] = (4098, E)
+            if kind == 'esm1b':
+                shapes['emb_layer_norm_before.weight'] = (E,)
+                shapes['emb_layer_norm_before.bias'] = (E,)
         for i in range(num_layers):
             p = f'layers.{i}.'
             shapes[p + 'self_attn.norm.weight'] = (E,)

@@ -57,6 +57,17 @@ const char* esme_hip_last_error(void);
 int esme_hip_embed(const int64_t* tokens, const void* table, void* out, int64_t T, int E,
                    int V, int mask_idx, int pad_idx, void* stream);
 
+/* out[t] = bf16(table[tokens[t]] (zeros for `<mask>`) + pos_table[pos_idx[t] + pos_offset]): token
+ * embedding plus LEARNED position embedding of ESM-1b / ESM-1v in one pass (fp32 add, one
+ * rounding = the reference's bf16 `x += embed_positions(...)`).  pos_idx: int32 (T), e.g. the
+ * in-sequence positions of esme_hip_seq_positions with pos_offset = padding_idx + 1 = 2;
+ * pos_table: (P, E) bf16 (indices are clamped to [0, P)).
+ * Replaces: ESM1b.embedding / ESM1v.embedding esme/esm.py:634-652,694-711 and
+ * LearnedPositionalEmbedding esme/embedding.py:7-107. */
+int esme_hip_embed_positions(const int64_t* tokens, const void* table, const void* pos_table,
+                             const int32_t* pos_idx, int pos_offset, void* out, int64_t T, int E,
+                             int V, int P, int mask_idx, void* stream);
+
 /* pos[t] = t - cu_lens[seq(t)], seq_id[t] = seq(t) for every packed row (either output
  * may be NULL).  Replaces: culen_indices esme/rotary.py:5-14 (recomputed twice per layer
  * there, with a host sync; computed once per forward here). */

@@ -5,7 +5,7 @@ the GPU box).  Same rules as make_golden.py: only inputs + the reference's outpu
 stored; import-only stubs stand in for packages that are absent here and that the
 exercised functions never call (`torchmetrics`, `lightning`, `polars`).
 
-    python tests/golden/make_golden_next.py     # rewrites g7_variant.json, g8_batching.json, g9_pooling.npz
+    python tests/golden/make_golden_next.py     # rewrites g7_variant.json, g8_batching.json, g9_pooling.npz, g10_esm1.npz
 
 tests/golden/data/test.fa(.fai) are the data files the reference's own tests use
 (reference tests/data/), copied as data.
@@ -113,7 +113,37 @@ def main():
           'pool_f32': partition_mean_pool(x, cu.long()).numpy(),
           'pool_bf16': mg.bits(partition_mean_pool(x.bfloat16(), cu.long()))}
     np.savez_compressed(os.path.join(HERE, 'g9_pooling.npz'), **g9)
-    for fn in ('g7_variant.json', 'g8_batching.json', 'g9_pooling.npz'):
+    # ---- G10 ESM-1b / ESM-1v (learned positions): the reference classes are fixed at 33 x 1280 x 20;
+    # the fixture keeps their first two layers (ModuleList slice) to stay small
+    from esme import ESM1b as RefESM1b, ESM1v as RefESM1v
+    from esme.embedding import LearnedPositionalEmbedding as RefLPE
+    lengths = [7, 40, 21]
+    tokens = syn.random_tokens(lengths, seed=10)
+    tokens[3] = 32
+    tokens[30] = 32
+    cu = syn.cu_lens_of(lengths)
+    ml = max(lengths)
+    tok2d = torch.full((len(lengths), ml), 1, dtype=torch.int64)
+    for i, (a, b) in enumerate(zip(cu[:-1].tolist(), cu[1:].tolist())):
+        tok2d[i, :b - a] = tokens[a:b]
+    g10 = {'tokens': tokens.numpy(), 'cu_lens': cu.numpy(), 'max_len': ml, 'tokens2d': tok2d.numpy(), 'L': 2, 'E': 1280,
+           'H': 20, 'seed': 10}
+    lpe = RefLPE(33, 8)
+    g10['positions2d'] = lpe.positions(tok2d[:, :30]).numpy()
+    g10['positions_packed'] = lpe.position_unpad(tokens[:28], (torch.tensor([0, 7, 28]), 21)).numpy()
+    for kind, cls in (('esm1b', RefESM1b), ('esm1v', RefESM1v)):
+        sd = syn.synthetic_state_dict(kind, 2, 1280, 10)
+        for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+            model = cls(dtype=dt)
+            model.layers = model.layers[:2]
+            missing, unexpected = model.load_state_dict({k: v.to(dt) for k, v in sd.items()}, strict=True)
+            assert not missing and not unexpected
+            model.eval()
+            g10[f'{kind}_emb_{tag}'] = mg.f32(model.embedding(tokens, (cu, ml)))
+            g10[f'{kind}_logits_{tag}'] = mg.f32(model(tokens, (cu, ml)))
+            g10[f'{kind}_logits2d_{tag}'] = mg.f32(model(tok2d))
+    np.savez_compressed(os.path.join(HERE, 'g10_esm1.npz'), **g10)
+    for fn in ('g7_variant.json', 'g8_batching.json', 'g9_pooling.npz', 'g10_esm1.npz'):
         print(f'  {fn:24s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB')
 
 

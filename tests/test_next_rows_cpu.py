@@ -237,3 +237,43 @@ def test_q4_host_errors_without_gpu():
         _hip.dequantize_4bit(torch.zeros(4, 32, dtype=torch.uint8), torch.zeros(4, 1), FP4_CODEBOOK)
     with pytest.raises(RuntimeError):
         _hip.segment_mean(torch.zeros(4, 8), torch.tensor([0, 4], dtype=torch.int32))
+
+
+# ------------------------------------------------------ ESM-1b / ESM-1v (oracle)
+@pytest.mark.parametrize('kind', ['esm1b', 'esm1v'])
+def test_oracle_esm1_matches_reference(kind):
+    """Learned-position models: oracle vs the reference's ESM1b / ESM1v (first two layers), packed and 2-D."""
+    g = load_golden('g10_esm1.npz')
+    tokens, cu, ml, tok2d = g['tokens'], g['cu_lens'], g['max_len'], g['tokens2d']
+    sd = syn.synthetic_state_dict(kind, g['L'], g['E'], g['seed'])
+    assert O._cfg_of(sd)[0] == kind
+    for dt, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+        w = {k: v.to(dt) for k, v in sd.items()}
+        emb = O.embedding(w, tokens, kind, dt, cu)
+        logits = O.forward_logits(w, g['H'], tokens, cu, ml, dtype=dt)
+        logits2d = O.forward_logits_padded(w, g['H'], tok2d, dtype=dt)
+        if dt == torch.bfloat16:
+            assert torch.equal(emb, g[f'{kind}_emb_bf16'])
+            assert torch.equal(logits, g[f'{kind}_logits_bf16'])
+            assert torch.equal(logits2d, g[f'{kind}_logits2d_bf16'])
+        else:
+            assert torch.allclose(emb, g[f'{kind}_emb_f32'], atol=2e-6, rtol=0)
+            assert torch.allclose(logits, g[f'{kind}_logits_f32'], atol=2e-5, rtol=2e-5)
+            assert torch.allclose(logits2d, g[f'{kind}_logits2d_f32'], atol=2e-5, rtol=2e-5)
+
+
+def test_learned_positional_embedding_indices():
+    from esme.embedding import LearnedPositionalEmbedding
+    g = load_golden('g10_esm1.npz')
+    lpe = LearnedPositionalEmbedding(33, 8)
+    # reference tests/test_embedding.py:6-29
+    assert (lpe.num_embeddings, lpe.embedding_dim, lpe.padding_idx, lpe.max_positions) == (35, 8, 1, 33)
+    assert tuple(lpe.weight.shape) == (35, 8)
+    assert lpe.positions(torch.tensor([[20, 29, 28], [8, 13, 9]])).tolist() == [[2, 3, 4], [2, 3, 4]]
+    assert lpe.position_unpad(torch.tensor([20, 29, 28, 8, 13, 9]), (torch.tensor([0, 3, 6]), 3)).tolist() == [2, 3, 4, 2, 3, 4]
+    assert torch.equal(lpe.positions(g['tokens2d'][:, :30]), g['positions2d'])
+    assert torch.equal(lpe.position_unpad(g['tokens'][:28], (torch.tensor([0, 7, 28]), 21)), g['positions_packed'])
+    with pytest.raises(ValueError):
+        lpe.positions(torch.zeros(1, 34, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        lpe.position_unpad(torch.zeros(40, dtype=torch.int64), (torch.tensor([0, 40]), 40))

@@ -245,3 +245,28 @@ def test_q4_mask_margin_drift_report():
     rho = spearman(a, b)
     print(f'\n[q4 mask-margin] spearman(q4, bf16) = {rho:.4f}; mean |delta| = {np.abs(a - b).mean():.4f}')
     assert rho > 0.7
+
+
+# ------------------------------------------------------------- ESM-1b / ESM-1v
+@pytest.mark.parametrize('kind', ['esm1b', 'esm1v'])
+def test_esm1_learned_positions_vs_reference(kind):
+    from esme import ESM, ESM1b, ESM1v
+    g = load_golden('g10_esm1.npz')
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), kind, g['L'], g['E'], g['H'], seed=g['seed'])
+        model = ESM.from_pretrained(path, device=DEV)
+    assert isinstance(model, ESM1b if kind == 'esm1b' else ESM1v) and len(model.layers) == g['L']
+    assert model.layers[0].self_attn.rot_emb is None
+    tokens, cu, ml = g['tokens'].to(DEV), g['cu_lens'].to(DEV), g['max_len']
+    emb = model.embedding(tokens, (cu, ml))
+    assert_parity(emb, g[f'{kind}_emb_f32'], g[f'{kind}_emb_bf16'], f'{kind} embedding')
+    if kind == 'esm1v':
+        assert torch.equal(emb.cpu(), g['esm1v_emb_bf16'])          # lookup + one add: exact
+    logits = model(tokens, (cu, ml))
+    assert_parity(logits, g[f'{kind}_logits_f32'], g[f'{kind}_logits_bf16'], f'{kind} packed logits')
+    logits2d = model(g['tokens2d'].to(DEV))
+    assert_parity(logits2d, g[f'{kind}_logits2d_f32'], g[f'{kind}_logits2d_bf16'], f'{kind} padded logits')
+    with pytest.raises(AssertionError):
+        model.embedding(tokens)                                     # 1-D tokens need pad_args (esm.py:644-646)
+    with pytest.raises(ValueError):
+        model.embedding(tokens, (cu, 5000))                         # beyond the 4096 learned positions
