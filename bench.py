@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-tokens', type=int, default=8000)
     ap.add_argument('--no-gather', action='store_true', help='skip the logits all-gather when N>1')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the forward from a hipGraph (esme/graph.py); matters for small models / batches')
     ap.add_argument('--quantization', choices=['none', '4bit'], default='none',
                     help="'4bit': layer projections resident in the esme-q4 format (not the headline config)")
     return ap.parse_args()
@@ -130,7 +132,7 @@ def main():
     gathered = torch.empty(world * T, V, dtype=torch.bfloat16, device=dev) if world > 1 else None
 
     def step():
-        logits = model(tokens, (cu, max_len))
+        logits = model.graphed(tokens, (cu, max_len), 'forward', clone=False) if args.graph else model(tokens, (cu, max_len))
         if world > 1 and not args.no_gather:
             dist.all_gather_into_tensor(gathered, logits)
         return logits
@@ -167,6 +169,7 @@ def main():
                                f'{args.batch} batch ({len(lengths)} seqs, max_len {max_len})',
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
                    'parallelism': f'dp{world} (protein-sharded, logits all-gather)' if world > 1 else 'single GPU',
+                   'launch': 'hipGraph replay' if args.graph else 'eager (one ctypes launch per kernel)',
                    'weights': 'synthetic (numpy PCG64), reference checkpoint layout'
                               + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme-q4 fp4)')},
         'e2e': {'algorithmic_tflop_per_step': round(flops_step / 1e12, 3),

@@ -139,8 +139,33 @@ def _dev(t: torch.Tensor, what: str, dtype=None) -> int:
     return t.data_ptr()
 
 
+_PINNED_STREAM = None           # set by stream_scope(): one current_stream() lookup per forward, not per launch
+
+
 def _stream() -> int:
+    if _PINNED_STREAM is not None:
+        return _PINNED_STREAM
     return torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope:
+    """`with _hip.stream_scope():` pins the HIP stream handle for every launch inside the block (the
+    torch lookup costs ~9 us, i.e. more than the launch itself for small models).  Re-entrant; the stream
+    that is current when the outermost scope is entered is used, which is also the capture stream inside
+    `torch.cuda.graph(...)`."""
+    __slots__ = ('prev',)
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.prev = _PINNED_STREAM
+        if _PINNED_STREAM is None and torch.cuda.is_available():     # no device: the first launch raises 'no CPU fallback'
+            _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        _PINNED_STREAM = self.prev
+        return False
 
 
 def _rows2d(t: torch.Tensor, what: str, dtype=torch.bfloat16):

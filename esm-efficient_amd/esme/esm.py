@@ -144,6 +144,10 @@ class ESM2(nn.Module):
         layers = list(layers) if layers else []
         self._check_layers_arg(layers)
 
+        with _hip.stream_scope():
+            return self._forward_representation(tokens, pad_args, pad_output, pad_indices, layers)
+
+    def _forward_representation(self, tokens, pad_args, pad_output, pad_indices, layers):
         x = self.embedding(tokens, pad_args)
         if pad_args is not None:
             assert tokens.ndim == 1, 'tokens are expected to be unpadded with shape (batch * seq_len)'
@@ -171,14 +175,28 @@ class ESM2(nn.Module):
 
     def forward(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         """Logits (T, V) / (B, S, V), bf16, on the model's device (esm.py:268-282)."""
-        return self.lm_head(self.forward_representation(tokens, pad_args, pad_output, pad_indices, lora_names))
+        with _hip.stream_scope():
+            return self.lm_head(self.forward_representation(tokens, pad_args, pad_output, pad_indices, lora_names))
 
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
-        return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
+        with _hip.stream_scope():
+            return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
 
     def predict_prob(self, tokens, log=False, pad_args=None, pad_output=False, pad_indices=None,
                      lora_names=None):
-        return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
+        with _hip.stream_scope():
+            return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
+
+    def graphed(self, tokens, pad_args, what: str = 'forward', clone: bool = True):
+        """`getattr(self, what)(tokens, pad_args)` replayed from a hipGraph captured on first use of this
+        input shape (esme/graph.py).  For repeated shapes of small batches, where ~160 Python-issued launches
+        cost more than the GPU work.  With `clone=False` the result is a static buffer that the next replay of
+        the same shape overwrites."""
+        assert what in ('forward', 'forward_representation', 'predict_log_prob')
+        if getattr(self, '_graph_cache', None) is None:
+            from esme.graph import GraphCache
+            self._graph_cache = GraphCache(self)
+        return self._graph_cache.run(what, tokens, pad_args, clone)
 
     # -- loading -------------------------------------------------------------------
     @classmethod

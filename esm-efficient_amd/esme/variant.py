@@ -92,9 +92,10 @@ class MaskMarginDataset(Dataset):
             yield self.batch(first, first + batch_size)
 
 
-def masked_row_log_prob(model, token: torch.Tensor, local_pos: torch.Tensor) -> torch.Tensor:
+def masked_row_log_prob(model, token: torch.Tensor, local_pos: torch.Tensor, graph: bool = False) -> torch.Tensor:
     """log-softmax over the vocabulary at `token[b, local_pos[b]]` for every row b of a
-    (B, L) batch: (B, V) bf16 on the model's device."""
+    (B, L) batch: (B, V) bf16 on the model's device.  `graph=True` replays the transformer stack from a
+    hipGraph captured for this (B, L) (every full batch of one protein has the same shape)."""
     device = model.embed_tokens.weight.device
     token = token.to(device)
     B, L = token.shape
@@ -103,7 +104,10 @@ def masked_row_log_prob(model, token: torch.Tensor, local_pos: torch.Tensor) -> 
         lp = model.predict_log_prob(token, pad_output=True)
         return lp[torch.arange(B, device=device), local_pos.to(device)]
     cu_lens = torch.arange(0, (B + 1) * L, L, dtype=torch.int32, device=device)
-    rep = model.forward_representation(token.reshape(-1), (cu_lens, L))
+    if graph:
+        rep = model.graphed(token.reshape(-1), (cu_lens, L), 'forward_representation', clone=False)
+    else:
+        rep = model.forward_representation(token.reshape(-1), (cu_lens, L))
     rows = torch.arange(B, dtype=torch.int64) * L + local_pos.to(torch.int64).cpu()
     picked = _hip.gather_rows(rep, rows.to(device))
     return _hip.softmax_rows(model.lm_head(picked), log=True)
@@ -133,10 +137,14 @@ def predict_mask_margin(model, seq, batch_size: int = 32, max_len: Optional[int]
         from tqdm import tqdm
         batches = tqdm(batches)
 
+    # batches of one protein share (batch_size, L): worth a hipGraph once there are a few of them
+    n_items = len(seq) if isinstance(seq, (str, MaskMarginDataset)) else 0
+    use_graph = n_items >= 4 * batch_size
     names, scores = [], []
     with torch.no_grad():
         for batch in batches:
-            lp = masked_row_log_prob(model, batch['token'], batch['local_pos']).cpu()      # (B, V) bf16
+            full = use_graph and batch['token'].shape[0] == batch_size
+            lp = masked_row_log_prob(model, batch['token'], batch['local_pos'], graph=full).cpu()   # (B, V) bf16
             wt_lp = lp[torch.arange(lp.shape[0]), torch.as_tensor(batch['wt_token'])]
             margin = lp - wt_lp.unsqueeze(1)                                                # bf16 - bf16
             scores.append(margin[:, aa_idx].float().numpy())

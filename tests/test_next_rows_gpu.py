@@ -270,3 +270,46 @@ def test_esm1_learned_positions_vs_reference(kind):
         model.embedding(tokens)                                     # 1-D tokens need pad_args (esm.py:644-646)
     with pytest.raises(ValueError):
         model.embedding(tokens, (cu, 5000))                         # beyond the 4096 learned positions
+
+
+# ------------------------------------------------------------- hipGraph replay
+def test_graph_replay_equals_eager():
+    """model.graphed(...) replays a captured forward: same bits as the eager path, for new data of the
+    same shape, for every supported method, and shape changes get their own graph."""
+    model = build('esm2', 2, 320, 20, 7)
+    lengths = [40, 90, 26]
+    cu = syn.cu_lens_of(lengths).to(DEV)
+    for what in ('forward', 'forward_representation', 'predict_log_prob'):
+        for seed in (1, 2, 3):
+            tokens = syn.random_tokens(lengths, seed=seed).to(DEV)
+            eager = getattr(model, what)(tokens, (cu, 90))
+            got = model.graphed(tokens, (cu, 90), what)
+            assert torch.equal(got, eager), (what, seed)
+    # same token count, different split: cu_lens is data, max_len / n_seqs are part of the key
+    lengths2 = [66, 60, 30]
+    cu2 = syn.cu_lens_of(lengths2).to(DEV)
+    t2 = syn.random_tokens(lengths2, seed=5).to(DEV)
+    assert torch.equal(model.graphed(t2, (cu2, 66)), model(t2, (cu2, 66)))
+    assert len(model._graph_cache.entries) == 4
+    static = model.graphed(t2, (cu2, 66), clone=False)
+    assert static.data_ptr() == model.graphed(t2, (cu2, 66), clone=False).data_ptr()
+    # 4-bit model (scratch-expanded weights) through a graph
+    q4 = build_q4('esmc', 2, 128, 2, 21)
+    lens = [7, 33, 50]
+    tk, c3 = syn.random_tokens(lens, seed=3).to(DEV), syn.cu_lens_of(lens).to(DEV)
+    assert torch.equal(q4.graphed(tk, (c3, 50)), q4(tk, (c3, 50)))
+
+
+def test_mask_margin_graph_path_equals_eager():
+    from esme.variant import MaskMarginDataset, masked_row_log_prob, predict_mask_margin
+    model = build('esmc', 2, 128, 2, 21)
+    seq = 'MADQLTEEQIAEFKEAFSLFDKDGDGTITTKELGTVMRSLGQNPTEAELQDMINEVDADGNGTIDFPEFLTMMARK'
+    ds = MaskMarginDataset(seq)
+    for first in (0, 8, 16):
+        b = ds.batch(first, first + 8)
+        assert torch.equal(masked_row_log_prob(model, b['token'], b['local_pos'], graph=True),
+                           masked_row_log_prob(model, b['token'], b['local_pos'], graph=False))
+    a = predict_mask_margin(model, seq, batch_size=8)['score'].to_numpy()       # 75 residues >= 4 * 8: graphed
+    model._graph_cache = None
+    e = np.concatenate([predict_mask_margin(model, seq[i:i + 0] or seq, batch_size=64)['score'].to_numpy() for i in (0,)])
+    assert np.array_equal(a, e)                                                  # batch 64 < 4 * 64 items: eager
