@@ -47,6 +47,43 @@ class ForwardContext:
         self.part_b = None
 
 
+SUPPORTED_HEAD_DIMS = (16, 32, 64, 128)        # head dims of the attention / fused-rotary kernels
+
+
+def padded_head_dim(d: int) -> int:
+    """Smallest kernel head dim >= d (ESM2-35M: 24 -> 32)."""
+    for p in SUPPORTED_HEAD_DIMS:
+        if p >= d:
+            return p
+    raise NotImplementedError(f'head dim {d} > {SUPPORTED_HEAD_DIMS[-1]} is not supported')
+
+
+def head_slots(heads: int, d: int, dp: int, device=None) -> torch.Tensor:
+    """Slot of logical feature h*d + c in a head-padded layout of `dp` per head: the two rotary halves of
+    a head stay `dp/2` apart (c < d/2 -> c, else dp/2 + c - d/2), so a dp-wide rotary with cos = 1, sin = 0
+    on the pad slots is exactly the d-wide rotary on the real ones."""
+    c = torch.arange(d, device=device)
+    within = torch.where(c < d // 2, c, dp // 2 + c - d // 2)
+    return (torch.arange(heads, device=device).unsqueeze(1) * dp + within.unsqueeze(0)).reshape(-1)
+
+
+def _pad_last(t: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    """Zero-pad the last dim of a weight / vector to n."""
+    if t is None or t.shape[-1] == n:
+        return t
+    out = torch.zeros(*t.shape[:-1], n, dtype=t.dtype, device=t.device)
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    if t.shape[0] == n:
+        return t
+    out = torch.zeros(n, *t.shape[1:], dtype=t.dtype, device=t.device)
+    out[:t.shape[0]] = t
+    return out
+
+
 def _version_key(*params):
     return tuple((p.data_ptr(), p._version) for p in params if p is not None)
 
@@ -66,7 +103,8 @@ def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.
 
 class FlashMultiheadAttention(nn.Module):
     def __init__(self, embed_dim: int, num_heads: int, dropout=0.0, pre_layernorm=True,
-                 rotary_embedding=True, bias=False, dtype=torch.bfloat16):
+                 rotary_embedding=True, bias=False, dtype=torch.bfloat16, phys_dim: Optional[int] = None,
+                 head_pad: Optional[int] = None):
         super().__init__()
         if dropout != 0.0:
             raise NotImplementedError('attention dropout is not supported on the inference path')
@@ -79,7 +117,16 @@ class FlashMultiheadAttention(nn.Module):
         self.k = Linear(embed_dim, embed_dim, bias=bias, dtype=dtype)
         self.v = Linear(embed_dim, embed_dim, bias=bias, dtype=dtype)
         self.out = Linear(embed_dim, embed_dim, bias=bias, dtype=dtype)
-        self.rot_emb = RotaryEmbedding(dim=self.head_dim) if rotary_embedding else None
+        # Physical layout (ESM2-35M: E = 480, d = 24): the residual stream is `phys_dim` wide (multiple of the
+        # GEMM's 64-element K tile, zero pad columns) and heads are `head_pad` wide inside the q/k/v buffer;
+        # the padding lives entirely in the packed weight copies, so no kernel knows about it.
+        self.phys_dim = phys_dim or embed_dim
+        self.head_pad = head_pad or self.head_dim
+        self.attn_dim = num_heads * self.head_pad
+        self.padded = self.phys_dim != embed_dim or self.head_pad != self.head_dim
+        if self.padded and pre_layernorm:
+            raise NotImplementedError('padded layouts are implemented for the ESM-2 block (no q/k LayerNorm)')
+        self.rot_emb = RotaryEmbedding(dim=self.head_dim, pad_to=self.head_pad) if rotary_embedding else None
         self.pre_layernorm = pre_layernorm
         if pre_layernorm:
             self.layernorm_q = LayerNorm(embed_dim, bias=bias, dtype=dtype)
@@ -91,16 +138,35 @@ class FlashMultiheadAttention(nn.Module):
         self._fold_key = None
         self._q4_qkv = None         # esme.quantization.Q4Matrix pair when the layer is 4-bit
         self._q4_out = None
+        self._out_w = self._out_b = None    # padded out-projection (padded layouts only)
 
     # -- weight layout ------------------------------------------------------
     def _pack(self):
         """Fuse q/k/v into one (3E, E) weight (+ (3E,) bias) and re-point the three
         parameters at row slices of it: state_dict() is unchanged, memory is not
         duplicated, and the projection is a single N = 3E GEMM."""
-        key = _version_key(self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias)
+        key = _version_key(self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias,
+                           *((self.out.weight, self.out.bias) if self.padded else ()))
         if key == self._pack_key:
             return
         E = self.embed_dim
+        if self.padded:
+            Ea, Ep = self.attn_dim, self.phys_dim
+            with torch.no_grad():
+                slots = head_slots(self.num_heads, self.head_dim, self.head_pad, self.q.weight.device)
+                w = torch.zeros(3 * Ea, Ep, dtype=self.q.weight.dtype, device=self.q.weight.device)
+                b = torch.zeros(3 * Ea, dtype=w.dtype, device=w.device) if self.q.bias is not None else None
+                for i, lin in enumerate((self.q, self.k, self.v)):
+                    w[i * Ea + slots, :E] = lin.weight.data
+                    if b is not None:
+                        b[i * Ea + slots] = lin.bias.data
+                self._qkv_w, self._qkv_b = w, b
+                ow = torch.zeros(Ep, Ea, dtype=w.dtype, device=w.device)
+                ow[:E, slots] = self.out.weight.data
+                self._out_w = ow
+                self._out_b = _pad_last(self.out.bias.data, Ep) if self.out.bias is not None else None
+            self._pack_key = key
+            return
         with torch.no_grad():
             w = torch.cat((self.q.weight.data, self.k.weight.data, self.v.weight.data), dim=0).contiguous()
             for i, lin in enumerate((self.q, self.k, self.v)):
@@ -122,8 +188,8 @@ class FlashMultiheadAttention(nn.Module):
         key = (self._pack_key, _version_key(self.norm.weight, self.norm.bias))
         if key != self._fold_key:
             with torch.no_grad():
-                self._fold = _fold_layernorm(self._qkv_w, self._qkv_b, self.norm.weight.data,
-                                             self.norm.bias.data if self.norm.bias is not None else None)
+                self._fold = _fold_layernorm(self._qkv_w, self._qkv_b, _pad_last(self.norm.weight.data, self.phys_dim),
+                                             _pad_last(self.norm.bias.data, self.phys_dim) if self.norm.bias is not None else None)
             self._fold_key = key
         return self._fold
 
@@ -144,6 +210,9 @@ class FlashMultiheadAttention(nn.Module):
     def _weights_out(self):
         if self._q4_out is not None:
             return self._q4_out.plain()
+        if self.padded:
+            self._pack()
+            return self._out_w, self._out_b
         return self.out.weight, self.out.bias
 
     # -- stages (names follow the reference) --------------------------------
@@ -151,22 +220,25 @@ class FlashMultiheadAttention(nn.Module):
         """LN -> fused QKV (-> ESM-C q/k LayerNorm over the full E, attention.py:104-105).
         Returns q, k, v as (T, H, d) views of one (T, 3E) buffer."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
+        if self.padded:
+            raise NotImplementedError('the unfused stage methods are not available for padded layouts')
         w, b, _, _ = self._weights_qkv(False)
         qkv = _hip.gemm(self.norm(x), w, b)
         return self._split_qkv(qkv)
 
     def _split_qkv(self, qkv):
-        T, E = qkv.shape[0], self.embed_dim
+        T, E = qkv.shape[0], self.attn_dim
         if self.pre_layernorm:
             self.layernorm_q(qkv[:, :E], out=qkv[:, :E])
             self.layernorm_k(qkv[:, E:2 * E], out=qkv[:, E:2 * E])
-        H, d = self.num_heads, self.head_dim
+        H, d = self.num_heads, self.head_pad
         return tuple(qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
 
     def _attn(self, q, k, v, cu_lens, max_len):
         T = q.shape[0]
-        E = self.embed_dim
-        return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads)
+        E = self.attn_dim
+        return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads,
+                                softmax_scale=self.head_dim ** -0.5)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None):
@@ -175,15 +247,18 @@ class FlashMultiheadAttention(nn.Module):
         `x_stats` ((nblk, T, 2) f32 partial row sums of x) selects the LN-folded projection;
         `stats_out` makes the out-projection emit the statistics of its output."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
-        T, E = x.shape
-        H, d = self.num_heads, self.head_dim
+        T = x.shape[0]
+        E = self.attn_dim                                   # width of each of q, k, v (H * padded head dim)
+        H, d = self.num_heads, self.head_pad
         rot_fusable = (self.rot_emb is not None and ctx is not None and not self.pre_layernorm
                        and d in (16, 32, 64) and E % 32 == 0)
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True)
-            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, E, self.norm.eps, c1, c2), rot=rot)
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot)
         else:
+            if self.padded:
+                raise NotImplementedError('padded layouts run the LayerNorm-folded path only')
             w, b, _, _ = self._weights_qkv(False)
             qkv = _hip.gemm_fused(self.norm(x), w, b, rot=rot)
         if (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128)
@@ -241,12 +316,18 @@ class SwiGLU(nn.Module):
 
 class FlashTransformerLayer(nn.Module):
     def __init__(self, embed_dim, expand_dim, attention_heads, rotary_embedding=True, pre_layernorm=False,
-                 bias=False, residue_scaling=1., final_activation='swiglu', dropout=0.0, dtype=torch.bfloat16):
+                 bias=False, residue_scaling=1., final_activation='swiglu', dropout=0.0, dtype=torch.bfloat16,
+                 phys_dim: Optional[int] = None, head_pad: Optional[int] = None):
         super().__init__()
         self.embed_dim, self.expand_dim = embed_dim, expand_dim
         self.attention_heads, self.residue_scaling = attention_heads, residue_scaling
         self.self_attn = FlashMultiheadAttention(embed_dim, attention_heads, pre_layernorm=pre_layernorm, bias=bias,
-                                                 dropout=dropout, rotary_embedding=rotary_embedding, dtype=dtype)
+                                                 dropout=dropout, rotary_embedding=rotary_embedding, dtype=dtype,
+                                                 phys_dim=phys_dim, head_pad=head_pad)
+        self.phys_dim = self.self_attn.phys_dim
+        self.padded = self.self_attn.padded
+        self._down_pad = None
+        self._down_key = None
         if final_activation == 'swiglu':
             width = int(((expand_dim * embed_dim) + 255) // 256 * 256)
             self.final = nn.Sequential(LayerNorm(embed_dim, dtype=dtype),
@@ -274,8 +355,9 @@ class FlashTransformerLayer(nn.Module):
             key = _version_key(up.weight, up.bias, ln.weight, ln.bias)
             if key != self._fold_key:
                 with torch.no_grad():
-                    self._fold = _fold_layernorm(up.weight.data, up.bias.data if up.bias is not None else None,
-                                                 ln.weight.data, beta)
+                    Ep = self.phys_dim
+                    self._fold = _fold_layernorm(_pad_last(up.weight.data, Ep), up.bias.data if up.bias is not None else None,
+                                                 _pad_last(ln.weight.data, Ep), _pad_last(beta, Ep))
                 self._fold_key = key
         else:
             sw = self.final[1]
@@ -297,6 +379,8 @@ class FlashTransformerLayer(nn.Module):
         if fold:
             wf, c1, c2 = self._pack_fold()
             return wf, None, c1, c2
+        if self.padded:
+            raise NotImplementedError('padded layouts run the LayerNorm-folded path only')
         if self.final_activation == 'gelu':
             return self.final[1].weight, self.final[1].bias, None, None
         self.final[1]._pack()
@@ -306,13 +390,21 @@ class FlashTransformerLayer(nn.Module):
         if self._q4_down is not None:
             return self._q4_down.plain()
         down = self.final[3] if self.final_activation == 'gelu' else self.final[2]
+        if self.padded:                                     # zero rows / bias entries for the pad columns of the stream
+            key = _version_key(down.weight, down.bias)
+            if key != self._down_key:
+                with torch.no_grad():
+                    self._down_pad = (_pad_rows(down.weight.data, self.phys_dim),
+                                      _pad_last(down.bias.data, self.phys_dim) if down.bias is not None else None)
+                self._down_key = key
+            return self._down_pad
         return down.weight, down.bias
 
     def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_up(True)
-            u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, x.shape[1], self.final[0].eps, c1, c2))
+            u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, self.embed_dim, self.final[0].eps, c1, c2))
         else:
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
@@ -338,5 +430,7 @@ class FlashTransformerLayer(nn.Module):
             self._ffn(y, y, alpha, y, x_stats=ctx.part_b, stats_out=ctx.part_a)
             ctx.sums = ctx.part_a                               # row sums of the layer output
             return y
+        if self.padded:
+            raise NotImplementedError('padded layouts need a folding context (ForwardContext(fold=True))')
         self.self_attn(x, cu_lens, max_len, lora_names, ctx, resid=x, alpha=alpha, out=y)
         return self._ffn(y, y, alpha, y)

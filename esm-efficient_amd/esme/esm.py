@@ -77,6 +77,15 @@ class ESM2(nn.Module):
         if checkpointing:
             raise NotImplementedError('activation checkpointing is a training feature (out of scope)')
         self.num_layers, self.embed_dim, self.attention_heads = num_layers, embed_dim, attention_heads
+        # Physical layout: the GEMM walks K in tiles of 64 and the attention kernels know head dims
+        # 16/32/64/128, so a model like ESM2-35M (E = 480, d = 24) runs with a 512-wide residual stream
+        # (zero pad columns) and 32-wide heads.  The padding lives in derived weight copies only.
+        from esme.attention import padded_head_dim
+        self.phys_dim = (embed_dim + 63) // 64 * 64
+        self.head_pad = padded_head_dim(embed_dim // attention_heads)
+        self.padded = self.phys_dim != embed_dim or self.head_pad != embed_dim // attention_heads
+        self._embed_pad = None
+        self._embed_pad_key = None
         self.checkpointing = False
         self.embed_scale = 1
         self.embed_tokens = nn.Embedding(self.vocab_size, embed_dim, dtype=dtype,
@@ -85,13 +94,13 @@ class ESM2(nn.Module):
         self.layers = nn.ModuleList(self._make_layer(rotary_embedding, dropout, dtype)
                                     for _ in range(num_layers))
         self.emb_layer_norm_after = self._make_final_norm(dtype)
-        self.lm_head = RobertaLMHead(embed_dim, self.vocab_size, dtype=dtype)
+        self.lm_head = RobertaLMHead(embed_dim, self.vocab_size, dtype=dtype, phys_dim=self.phys_dim)
 
     # -- construction hooks (ESMC overrides) ---------------------------------
     def _make_layer(self, rotary_embedding, dropout, dtype):
         return FlashTransformerLayer(self.embed_dim, 4, self.attention_heads, rotary_embedding=rotary_embedding,
                                      pre_layernorm=False, bias=True, final_activation='gelu',
-                                     dropout=dropout, dtype=dtype)
+                                     dropout=dropout, dtype=dtype, phys_dim=self.phys_dim, head_pad=self.head_pad)
 
     def _make_final_norm(self, dtype):
         return LayerNorm(self.embed_dim, dtype=dtype)
@@ -102,7 +111,24 @@ class ESM2(nn.Module):
         tokens `<pad>` rows are zeroed too (esm.py:191-193)."""
         if tokens.ndim not in (1, 2):
             raise ValueError('tokens must be 1D or 2D')
-        return _hip.embed(tokens, self.embed_tokens.weight,
+        x = self._embedding_phys(tokens, pad_args)
+        return x[..., :self.embed_dim].contiguous() if self.padded else x
+
+    def _embed_table(self):
+        """Embedding table at the physical width (a zero-padded copy for padded layouts)."""
+        w = self.embed_tokens.weight
+        if not self.padded:
+            return w
+        key = (w.data_ptr(), w._version)
+        if key != self._embed_pad_key:
+            from esme.attention import _pad_last
+            with torch.no_grad():
+                self._embed_pad = _pad_last(w.data, self.phys_dim)
+            self._embed_pad_key = key
+        return self._embed_pad
+
+    def _embedding_phys(self, tokens, pad_args=None):
+        return _hip.embed(tokens, self._embed_table(),
                           mask_idx=self.alphabet.mask_idx if self.zero_mask_rows else -1,
                           pad_idx=self.alphabet.padding_idx if (tokens.ndim == 2 and self.zero_mask_rows) else -1)
 
@@ -145,10 +171,15 @@ class ESM2(nn.Module):
         self._check_layers_arg(layers)
 
         with _hip.stream_scope():
-            return self._forward_representation(tokens, pad_args, pad_output, pad_indices, layers)
+            x = self._forward_representation(tokens, pad_args, pad_output, pad_indices, layers)
+            if self.padded:                                       # physical -> logical width, per concatenated block
+                E, Ep = self.embed_dim, self.phys_dim
+                x = torch.cat([x[..., i * Ep:i * Ep + E] for i in range(x.shape[-1] // Ep)], dim=-1)
+            return x
 
     def _forward_representation(self, tokens, pad_args, pad_output, pad_indices, layers):
-        x = self.embedding(tokens, pad_args)
+        """forward_representation at the PHYSICAL width (== the logical one unless the layout is padded)."""
+        x = self._embedding_phys(tokens, pad_args)
         if pad_args is not None:
             assert tokens.ndim == 1, 'tokens are expected to be unpadded with shape (batch * seq_len)'
             cu_lens, max_len = pad_args
@@ -165,7 +196,8 @@ class ESM2(nn.Module):
             x = layer(x, cu_lens, max_len, None, ctx, inplace=True)
             if i in layers:
                 taps.append(x.clone())
-        x = self.emb_layer_norm_after(x, out=x)
+        E = self.embed_dim
+        self.emb_layer_norm_after(x[:, :E], out=x[:, :E])        # pad columns (if any) stay zero
 
         if pad_output or (pad_args is None):
             nseq = cu_lens.numel() - 1
@@ -175,8 +207,9 @@ class ESM2(nn.Module):
 
     def forward(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         """Logits (T, V) / (B, S, V), bf16, on the model's device (esm.py:268-282)."""
+        assert lora_names is None, 'LoRA adapters are outside the inference hot path'
         with _hip.stream_scope():
-            return self.lm_head(self.forward_representation(tokens, pad_args, pad_output, pad_indices, lora_names))
+            return self.lm_head(self._forward_representation(tokens, pad_args, pad_output, pad_indices, []))
 
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         with _hip.stream_scope():
@@ -274,9 +307,10 @@ class _LearnedPositionESM(ESM2):
             self.emb_layer_norm_before = LayerNorm(embed_dim, dtype=dtype)
         self.embed_positions = LearnedPositionalEmbedding(4096, embed_dim, dtype=dtype)
 
-    def embedding(self, tokens, pad_args=None):
+    def _embedding_phys(self, tokens, pad_args=None):
         """token rows (`<mask>` zeroed) + learned position rows [-> LayerNorm (ESM-1b)] -> `<pad>` rows zeroed
         (esm.py:634-652 / :694-711)."""
+        assert not self.padded, 'learned-position models are built at 64-aligned widths'
         pe = self.embed_positions
         if tokens.ndim == 2:
             assert pad_args is None, 'pad_args must be None for esm1b with 2D tokens'

@@ -143,6 +143,8 @@ def quantize_layer_(layer, quant_type: str, scratch: WeightScratch):
     Linear4bit (the set the reference converts, esme/esm.py:455-468, :921-943) and the layer
     gets the row-packed Q4Matrix objects its forward runs."""
     att = layer.self_attn
+    if getattr(layer, 'padded', False):
+        raise NotImplementedError('4-bit weights are not implemented for padded layouts (e.g. ESM2-35M)')
     with torch.no_grad():
         q4 = [Linear4bit.from_linear(getattr(att, n), quant_type) for n in ('q', 'k', 'v', 'out')]
         codes = torch.cat([m.weight.data for m in q4[:3]], dim=0).contiguous()

@@ -29,9 +29,13 @@ def culen_indices(cu_lens: torch.Tensor) -> torch.Tensor:
 
 
 class RotaryEmbedding(nn.Module):
-    def __init__(self, dim: int, base: float = 10000.0, pos_idx_in_fp32: bool = True, device=None):
+    def __init__(self, dim: int, base: float = 10000.0, pos_idx_in_fp32: bool = True, device=None,
+                 pad_to: Optional[int] = None):
         super().__init__()
         self.dim, self.base = dim, float(base)
+        # tables `pad_to` wide for a head-padded layout: the real halves sit pad_to/2 apart, pad slots get
+        # cos = 1, sin = 0 (esme.attention.head_slots)
+        self.pad_to = pad_to if pad_to and pad_to != dim else None
         self._seq_len_cached = 0
         self._cos_cached: Optional[torch.Tensor] = None
         self._sin_cached: Optional[torch.Tensor] = None
@@ -48,8 +52,16 @@ class RotaryEmbedding(nn.Module):
             t = torch.arange(seqlen, dtype=torch.float32)
             ang = torch.outer(t, self._compute_inv_freq())
             ang = torch.cat((ang, ang), dim=-1)
-            self._cos_cached = ang.cos().to(dtype).to(device)
-            self._sin_cached = ang.sin().to(dtype).to(device)
+            cos, sin = ang.cos().to(dtype), ang.sin().to(dtype)
+            if self.pad_to is not None:
+                h, hp = self.dim // 2, self.pad_to // 2
+                pc, ps = torch.ones(seqlen, self.pad_to, dtype=dtype), torch.zeros(seqlen, self.pad_to, dtype=dtype)
+                for src, dst in ((0, 0), (h, hp)):
+                    pc[:, dst:dst + h] = cos[:, src:src + h]
+                    ps[:, dst:dst + h] = sin[:, src:src + h]
+                cos, sin = pc, ps
+            self._cos_cached = cos.to(device)
+            self._sin_cached = sin.to(device)
             self._seq_len_cached = seqlen
 
     def tables(self, max_len: int, device, dtype=torch.bfloat16) -> Tuple[torch.Tensor, torch.Tensor]:

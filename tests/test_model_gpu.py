@@ -186,3 +186,60 @@ def test_other_head_dims_vs_oracle(kind, L, E, H, lengths):
     refbf = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.bfloat16)
     got = model(tokens.to(DEV), (cu.to(DEV), ml))
     assert_parity(got, ref32, refbf, f'{kind} E={E} H={H} (d={E // H}) logits vs oracle')
+
+
+@pytest.mark.parametrize('L,E,H,lengths', [(2, 480, 20, [9, 130, 61]),     # ESM2-35M geometry: stream 480 -> 512, heads 24 -> 32
+                                           (1, 192, 8, [40, 7]),           # head padding only (E already 64-aligned)
+                                           (2, 96, 4, [33, 20, 5])])       # both
+def test_padded_layout_models_vs_oracle(L, E, H, lengths):
+    """Widths / head dims the kernels do not natively cover run through zero-padded weight copies: logits,
+    log-probs, representations (+ layer taps), the 2-D path and the state dict must look exactly like an
+    unpadded model of the logical size."""
+    seed = 70 + E
+    model = build('esm2', L, E, H, seed)
+    assert model.padded and model.phys_dim % 64 == 0 and model.head_pad == 32
+    w = {k: v.bfloat16() for k, v in syn.synthetic_state_dict('esm2', L, E, seed).items()}
+    sd = model.state_dict()
+    assert set(sd) == set(w) and all(torch.equal(sd[k].cpu(), w[k]) for k in w)       # checkpoint layout untouched
+    tokens = syn.random_tokens(lengths, seed=seed)
+    tokens[2] = 32
+    cu = syn.cu_lens_of(lengths)
+    ml = max(lengths)
+    ref32 = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.float32)
+    refbf = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.bfloat16)
+    got = model(tokens.to(DEV), (cu.to(DEV), ml))
+    assert got.shape == ref32.shape
+    assert_parity(got, ref32, refbf, f'padded E={E} H={H} logits vs oracle')
+    rep = model.forward_representation(tokens.to(DEV), (cu.to(DEV), ml), layers=[0])
+    assert rep.shape == (tokens.numel(), 2 * E) and rep.is_contiguous()
+    r32 = O.forward_representation(w, H, tokens, cu, ml, dtype=torch.float32, layers=[0])
+    rbf = O.forward_representation(w, H, tokens, cu, ml, dtype=torch.bfloat16, layers=[0])
+    assert_parity(rep, r32, rbf, f'padded E={E} representation + tap')
+    emb = model.embedding(tokens.to(DEV))
+    assert emb.shape == (tokens.numel(), E) and torch.equal(emb.cpu(), O.embedding(w, tokens, 'esm2', torch.bfloat16))
+    tok2d = torch.full((len(lengths), ml), 1, dtype=torch.int64)
+    for i, (a, b) in enumerate(zip(cu[:-1].tolist(), cu[1:].tolist())):
+        tok2d[i, :b - a] = tokens[a:b]
+    l2 = model(tok2d.to(DEV))
+    assert l2.shape == (len(lengths), ml, 33)
+    assert_parity(l2, O.forward_logits_padded(w, H, tok2d, dtype=torch.float32),
+                  O.forward_logits_padded(w, H, tok2d, dtype=torch.bfloat16), f'padded E={E} 2-D logits')
+    lp = model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), ml))
+    assert torch.equal(model.graphed(tokens.to(DEV), (cu.to(DEV), ml), 'predict_log_prob'), lp)
+    # the LM head also accepts logical-width features (esme.variant gathers rows before the head)
+    feats = model.forward_representation(tokens.to(DEV), (cu.to(DEV), ml))
+    assert torch.equal(model.lm_head(feats), got)
+
+
+def test_esm2_35m_from_zoo():
+    from esme import ESM
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, '35M.safetensors'), 'esm2_35m', seed=3)
+        model = ESM.from_pretrained(path, device=DEV)
+        with pytest.raises(NotImplementedError):
+            ESM.from_pretrained(path, quantization='4bit', device=DEV)
+    assert (model.num_layers, model.embed_dim, model.attention_heads, model.phys_dim, model.head_pad) == (12, 480, 20, 512, 32)
+    tokens, cu, ml, _ = syn.uniform_batch(2048, 256, seed=1)
+    lp = model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), ml))
+    assert lp.shape == (2048, 33) and torch.isfinite(lp.float()).all()
+    assert torch.allclose(lp.float().exp().sum(-1).cpu(), torch.ones(2048), atol=3e-2)
