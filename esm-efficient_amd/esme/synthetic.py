@@ -25,6 +25,7 @@ MODEL_ZOO = {
     'esm2_150m': ('esm2', 30, 640, 20),
     'esm2_650m': ('esm2', 33, 1280, 20),
     'esm2_3b':   ('esm2', 36, 2560, 40),
+    'esm2_15b':  ('esm2', 48, 5120, 40),
     'esm1b':     ('esm1b', 33, 1280, 20),
     'esm1v':     ('esm1v', 33, 1280, 20),
     'esmc_300m': ('esmc', 30, 960, 15),

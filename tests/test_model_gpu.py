@@ -172,7 +172,8 @@ def test_large_batch_properties():
 
 @pytest.mark.parametrize('kind,L,E,H,lengths', [('esm2', 1, 2560, 20, [150, 70, 33]),       # head dim 128 (the ESM2-15B head)
                                                 ('esm2', 2, 320, 20, [9, 300]),             # head dim 16 (ESM2-8M)
-                                                ('esmc', 1, 1152, 18, [40, 260])])          # ESM-C 600M width
+                                                ('esmc', 1, 1152, 18, [40, 260]),           # ESM-C 600M width
+                                                ('esm2', 1, 5120, 40, [120, 60])])          # ESM2-15B width (LN fold over 20 column blocks)
 def test_other_head_dims_vs_oracle(kind, L, E, H, lengths):
     """Model widths / head dims without a golden fixture: HIP forward vs the oracle on the same
     synthetic weights (the oracle itself is pinned by the goldens)."""
