@@ -68,3 +68,40 @@ class Fasta:
 
     def __len__(self):
         return len(self.fai)
+
+
+def index_fasta(fasta, fai=None) -> str:
+    """Write the samtools-style `.fai` index of a FASTA file (id, length, byte offset of the first residue,
+    residues per line, bytes per line) and return its path.  The reference expects `samtools faidx` to have
+    been run; this is the same five columns for files whose records use one fixed line width (the last line
+    of a record may be shorter), which is what samtools requires too."""
+    fasta = str(fasta)
+    fai = fai or fasta + '.fai'
+    rows = []
+    with open(fasta, 'rb') as f:
+        name, length, offset, bases, width, short_seen = None, 0, 0, 0, 0, False
+        pos = 0
+        for line in f:
+            if line.startswith(b'>'):
+                if name is not None:
+                    rows.append((name, length, offset, bases, width))
+                name = line[1:].split()[0].decode('ascii') if len(line) > 1 else ''
+                length, bases, width, short_seen = 0, 0, 0, False
+                offset = pos + len(line)
+            elif name is not None:
+                n = len(line.rstrip(b'\r\n'))
+                if n:
+                    if short_seen or (bases and n > bases):
+                        raise ValueError(f'{fasta}: record {name!r} has lines of different lengths (not indexable)')
+                    if not bases:
+                        bases, width = n, len(line)
+                    elif n < bases:
+                        short_seen = True
+                    length += n
+            pos += len(line)
+        if name is not None:
+            rows.append((name, length, offset, bases, width))
+    with open(fai, 'w') as out:
+        for r in rows:
+            out.write('\t'.join(str(v) for v in r) + '\n')
+    return fai

@@ -277,3 +277,20 @@ def test_learned_positional_embedding_indices():
         lpe.positions(torch.zeros(1, 34, dtype=torch.int64))
     with pytest.raises(ValueError):
         lpe.position_unpad(torch.zeros(40, dtype=torch.int64), (torch.tensor([0, 40]), 40))
+
+
+def test_index_fasta_reproduces_samtools_index(tmp_path):
+    """The .fai written by esme.fasta.index_fasta == the samtools index shipped with the reference's test data;
+    a file indexed here reads back through Fasta."""
+    from esme.fasta import Fasta, index_fasta
+    out = index_fasta(FASTA, str(tmp_path / 'test.fa.fai'))
+    assert open(out).read() == open(FASTA + '.fai').read()
+    fa = tmp_path / 'two.fa'
+    fa.write_text('>sp|P1|X desc\nMKV\nLAA\nG\n>P2\nACDEFGHIK\n')
+    index_fasta(fa)
+    f = Fasta(str(fa))
+    assert len(f) == 2 and f['sp|P1|X'] == 'MKVLAAG' and f[1] == 'ACDEFGHIK'
+    bad = tmp_path / 'bad.fa'
+    bad.write_text('>P1\nMK\nLAAG\n')
+    with pytest.raises(ValueError):
+        index_fasta(bad)

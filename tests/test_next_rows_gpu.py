@@ -313,3 +313,24 @@ def test_mask_margin_graph_path_equals_eager():
     model._graph_cache = None
     e = np.concatenate([predict_mask_margin(model, seq[i:i + 0] or seq, batch_size=64)['score'].to_numpy() for i in (0,)])
     assert np.array_equal(a, e)                                                  # batch 64 < 4 * 64 items: eager
+
+
+# --------------------------------------------------------- streamed inference
+def test_streamed_inference_equals_sequential():
+    """Three-stream pipeline (upload / forward / download) over FASTA token-budget batches: same bits and
+    same order as the plain loop, for logits, representations and pooled embeddings."""
+    from esme.data import FastaTokenDataset
+    from esme.pipeline import StreamedInference
+    from esme.pooling import partition_mean_pool
+    model = build('esmc', 2, 128, 2, 21)
+    ds = FastaTokenDataset(FASTA, token_per_batch=900, shuffle=False)
+    assert len(ds) >= 5
+    want_logits, want_pool = [], []
+    for tok, (cu, ml) in ds:
+        want_logits.append(model(tok.to(DEV), (cu.to(DEV), ml)).cpu())
+        want_pool.append(partition_mean_pool(model.forward_representation(tok.to(DEV), (cu.to(DEV), ml)), cu.to(DEV)).cpu())
+    got = [h.clone() for h in StreamedInference(model, 'forward', depth=2).run(ds)]
+    assert len(got) == len(want_logits) and all(torch.equal(a, b) for a, b in zip(got, want_logits))
+    got = [h.clone() for h in StreamedInference(model, 'forward_representation', pool='mean', depth=1).run(ds.to_dataloader())]
+    assert len(got) == len(want_pool) and all(torch.equal(a, b) for a, b in zip(got, want_pool))
+    assert got[0].shape == (len(ds.sampler[0]), 128)
