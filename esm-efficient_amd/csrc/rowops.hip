@@ -303,21 +303,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restric
 
 
 // ------------------------------------------------------- per-sequence mean
-// One workgroup per (sequence, 512-column slab): wave w walks rows w, w+4, ... of the
-// sequence with 16-byte loads (bf16: 8 columns per lane; fp32: two 16-byte halves), fp32
-// accumulation, then the four waves' partials meet in LDS.
+// One workgroup per (sequence, 64-column slab): 8 lanes cover the slab's 64 columns (8 per lane, whole
+// 128-B lines of bf16), the 32 lane groups stride the sequence's rows, fp32 accumulation, then a
+// fixed-order LDS reduction (deterministic).  B * E/64 workgroups keep the chip busy even for a few long
+// proteins (the first version used 512-column slabs: 96 workgroups for 32 proteins, 1.1 TB/s).
 template <bool F32>
 __global__ __launch_bounds__(256) void segment_mean_kernel(const void* __restrict__ xv, int64_t ldx,
                                                            const int32_t* __restrict__ cu, int E,
                                                            void* __restrict__ outv, int64_t ldo) {
-    __shared__ float part[4][512];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float part[32][64 + 4];
+    const int cg = threadIdx.x & 7, rg = threadIdx.x >> 3;
     const int seq = blockIdx.x;
-    const int col = blockIdx.y * 512 + lane * 8;
+    const int col = blockIdx.y * 64 + cg * 8;
     const int a = cu[seq], b = cu[seq + 1];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (col < E) {
-        for (int r = a + wave; r < b; r += 4) {
+        for (int r = a + rg; r < b; r += 32) {
             float f[8];
             if (F32) {
                 const float* x = (const float*)xv + (int64_t)r * ldx + col;
@@ -333,23 +334,17 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const void* __restric
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) part[rg][cg * 8 + j] = acc[j];
     __syncthreads();
-    if (wave == 0 && col < E) {
-        const float inv = b > a ? 1.0f / (float)(b - a) : 0.f;
-        float f[8];
+    if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < E) {
+        const int c = threadIdx.x;
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = lane * 8 + j;
-            f[j] = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) * inv;
-        }
-        if (F32) {
-            float* o = (float*)outv + (int64_t)seq * ldo + col;
-            *reinterpret_cast<f32x4*>(o) = f32x4{f[0], f[1], f[2], f[3]};
-            *reinterpret_cast<f32x4*>(o + 4) = f32x4{f[4], f[5], f[6], f[7]};
-        } else {
-            *reinterpret_cast<u32x4*>((u16*)outv + (int64_t)seq * ldo + col) = pack8(f);
-        }
+        for (int g = 0; g < 32; ++g) s += part[g][c];
+        s *= b > a ? 1.0f / (float)(b - a) : 0.f;
+        const int64_t o = (int64_t)seq * ldo + blockIdx.y * 64 + c;
+        if (F32) ((float*)outv)[o] = s;
+        else ((u16*)outv)[o] = f2bf(s);
     }
 }
 
@@ -477,7 +472,7 @@ extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* 
     const int vec = dtype_f32 ? 4 : 8;
     ESME_CHECK_ARG(E % 8 == 0 && ldx % vec == 0 && ldo % vec == 0 && aligned16(x) && aligned16(out),
                    "segment_mean: E %% 8 != 0 or misaligned rows");
-    const dim3 grid((unsigned int)B, (unsigned int)((E + 511) / 512));
+    const dim3 grid((unsigned int)B, (unsigned int)((E + 63) / 64));
     if (dtype_f32)
         hipLaunchKernelGGL(segment_mean_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, cu_lens, E, out, ldo);
     else
