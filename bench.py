@@ -226,7 +226,7 @@ def main():
         if 'dequant4_ms' in hbm:
             hbm['dequant4'] = round(hbm.pop('dequant4_bytes') / (hbm.pop('dequant4_ms') * 1e-3) / 1e9, 1)
         result['hbm_bound_GBps'] = hbm
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 of the single-GPU run only
             result['cpu_baseline'] = cpu_baseline(weights, H, kind, L, E, args.seq_len,
                                                   min(args.cpu_sample_tokens, T))
         print(json.dumps(result), flush=True)

@@ -110,3 +110,14 @@ def padding_mask(cu_lens: torch.Tensor, max_len: int) -> torch.Tensor:
     lengths = (cu_lens[1:] - cu_lens[:-1]).unsqueeze(1)
     cols = torch.arange(max_len, device=cu_lens.device).unsqueeze(0)
     return cols < lengths
+
+
+def pad_tokens(tokens: List[torch.Tensor], alphabet=Alphabet3) -> torch.Tensor:
+    """Right-pad a list of token tensors to a common length and stack them: 1-D items -> (B, L),
+    (1, L_i) items -> (B, L) (reference alphabet.py:186-213)."""
+    rows = [t.reshape(-1) for t in tokens]
+    width = max(r.numel() for r in rows)
+    out = torch.full((len(rows), width), alphabet.padding_idx, dtype=rows[0].dtype)
+    for i, r in enumerate(rows):
+        out[i, :r.numel()] = r
+    return out

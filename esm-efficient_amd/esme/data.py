@@ -12,7 +12,7 @@ from typing import List, Sequence
 
 from torch.utils.data import DataLoader, Dataset
 
-from esme.alphabet import Alphabet3, tokenize, tokenize_unpad
+from esme.alphabet import Alphabet3, pad_tokens, tokenize, tokenize_unpad
 from esme.fasta import Fasta
 
 
@@ -77,12 +77,7 @@ class FastaDataset(BaseFastaDataset):
         return tokenize(self.read_seq(idx), alphabet=self.alphabet)
 
     def collate_fn(self, batch):
-        import torch
-        width = max(t.shape[-1] for t in batch)
-        out = torch.full((len(batch), width), self.alphabet.padding_idx, dtype=torch.int64)
-        for i, t in enumerate(batch):
-            out[i, :t.shape[-1]] = t.reshape(-1)
-        return out
+        return pad_tokens(batch, alphabet=self.alphabet)
 
     def to_dataloader(self, batch_size, shuffle=False, num_workers=0, **kwargs):
         return DataLoader(self, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
