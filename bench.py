@@ -53,7 +53,7 @@ def parse():
     ap.add_argument('--no-gather', action='store_true', help='skip the logits all-gather when N>1')
     ap.add_argument('--graph', action='store_true',
                     help='replay the forward from a hipGraph (esme/graph.py); matters for small models / batches')
-    ap.add_argument('--quantization', choices=['none', '4bit'], default='none',
+    ap.add_argument('--quantization', choices=['none', '4bit', '8bit'], default='none',
                     help="'4bit': layer projections resident in the esme-q4 format (not the headline config)")
     return ap.parse_args()
 
@@ -171,7 +171,7 @@ def main():
                    'parallelism': f'dp{world} (protein-sharded, logits all-gather)' if world > 1 else 'single GPU',
                    'launch': 'hipGraph replay' if args.graph else 'eager (one ctypes launch per kernel)',
                    'weights': 'synthetic (numpy PCG64), reference checkpoint layout'
-                              + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme-q4 fp4)')},
+                              + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme/quantization.py)')},
         'e2e': {'algorithmic_tflop_per_step': round(flops_step / 1e12, 3),
                 'tflops_per_gpu': round(flops_step / (ms_per_step * 1e-3) / 1e12, 1),
                 'frac_bf16_mfma_peak': round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},

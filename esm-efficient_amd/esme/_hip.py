@@ -60,6 +60,8 @@ SIGNATURES = {
                                        c_void_p]),
     'esme_hip_dequantize_4bit': (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_float), c_void_p, c_void_p,
                                          c_int64, c_void_p]),
+    'esme_hip_quantize_8bit': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    'esme_hip_dequantize_8bit': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None
@@ -476,4 +478,36 @@ def dequantize_4bit(codes: torch.Tensor, absmax: torch.Tensor, codebook, col_sca
     with _Traced('dequant4', (N, K)):
         _check(load().esme_hip_dequantize_4bit(codes.data_ptr(), absmax.data_ptr(), N, K, _codebook_arg(codebook), sp,
                                                op, ldo, _stream()), 'esme_hip_dequantize_4bit')
+    return out
+
+
+def quantize_8bit(w: torch.Tensor):
+    """bf16 (N, K) -> (codes int8 (N, K), scale float32 (N,)): the reference's row-wise absmax int8."""
+    wp, ldw = _rows2d(w, 'quantize_8bit w')
+    N, K = w.shape
+    codes = torch.empty(N, K, dtype=torch.int8, device=w.device)
+    scale = torch.empty(N, dtype=torch.float32, device=w.device)
+    _check(load().esme_hip_quantize_8bit(wp, ldw, N, K, codes.data_ptr(), scale.data_ptr(), _stream()), 'esme_hip_quantize_8bit')
+    return codes, scale
+
+
+def dequantize_8bit(codes: torch.Tensor, scale: torch.Tensor, col_scale: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(N, K) bf16 = codes * scale[:, None] / 127 (* col_scale[k])."""
+    _dev(codes, 'dequantize_8bit codes', torch.int8)
+    _dev(scale, 'dequantize_8bit scale', torch.float32)
+    if codes.dim() != 2 or not codes.is_contiguous() or scale.numel() != codes.shape[0] or not scale.is_contiguous():
+        raise ValueError('dequantize_8bit: codes (N, K) and scale (N,) must be contiguous')
+    N, K = codes.shape
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=codes.device)
+    elif tuple(out.shape) != (N, K):
+        raise ValueError(f'dequantize_8bit: out shape {tuple(out.shape)} != {(N, K)}')
+    op, ldo = _rows2d(out, 'dequantize_8bit out')
+    sp = _dev(col_scale, 'dequantize_8bit col_scale', torch.float32) if col_scale is not None else None
+    if col_scale is not None and (col_scale.numel() != K or not col_scale.is_contiguous()):
+        raise ValueError('dequantize_8bit: col_scale must be a contiguous float32 (K,) tensor')
+    with _Traced('dequant8', (N, K)):
+        _check(load().esme_hip_dequantize_8bit(codes.data_ptr(), scale.data_ptr(), N, K, sp, op, ldo, _stream()),
+               'esme_hip_dequantize_8bit')
     return out

@@ -9,9 +9,9 @@ assertion/ValueError behaviour, so callers of
 edits.  Everything arithmetic runs in HIP kernels behind `esme._hip`; a tensor
 that is not on a HIP device raises (there is no CPU fallback).
 
-`quantization='4bit'` keeps the layer projections 4-bit in HBM (esme/quantization.py).
+`quantization='4bit'` / `'8bit'` keep the layer projections 4-bit / int8 in HBM (esme/quantization.py).
 ESM-1b / ESM-1v (learned positions, no rotary) run on the same kernels (`ESM1b`, `ESM1v`).
-Out of scope here: LoRA management, 8-bit loaders,
+Out of scope here: LoRA management, int8-activation matmuls,
 activation checkpointing (training only), hub download (no network).
 """
 from __future__ import annotations
@@ -253,9 +253,6 @@ class ESM2(nn.Module):
             f'load_in must be one of [None, "8bit", "4bit"] but got {quantization}'
         if quantization is not None:
             assert device != 'cpu', 'Quantized model cannot be loaded on cpu provide CUDA gpu device'
-            if quantization != '4bit':
-                raise NotImplementedError('only the 4-bit weight format is implemented on the MI355X path '
-                                          '(8-bit loaders: SURVEY.md §2, out of scope)')
         from safetensors.torch import load_file
         model = cls.create_model(path, checkpointing=checkpointing)
         dev = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
@@ -263,9 +260,9 @@ class ESM2(nn.Module):
         model.load_state_dict(state, strict=True, assign=True)
         for p in model.parameters():
             p.requires_grad_(False)
-        if quantization == '4bit':
+        if quantization is not None:                    # weight-only storage formats (esme/quantization.py)
             from esme.quantization import quantize_model_
-            quantize_model_(model, cls.quant_type_4bit)
+            quantize_model_(model, cls.quant_type_4bit if quantization == '4bit' else 'int8')
         return model.eval()
 
 

@@ -1,4 +1,4 @@
-"""4-bit weight-only quantisation of the transformer-layer projections.
+"""4-bit / 8-bit weight-only quantisation of the transformer-layer projections.
 
 Reference behaviour (`esme/esm.py:434-446,449-484,915-946`): with
 `from_pretrained(..., quantization='4bit')` the q/k/v/out projections and the FFN
@@ -9,7 +9,14 @@ here is this project's own format ("esme-q4", specified in include/esme_hip.h) a
 parity with that library is NOT pinned -- tests pin it against the oracle's
 restatement of the same format and report the drift against the bf16 model.
 
-MI355X plan: weights stay 4-bit in HBM (that is what the option is for: memory), and
+`quantization='8bit'` / `'8bitexperimental'`: the reference's own experimental scheme
+(`esme/quantization.py:20-26`: row-wise absmax int8) is restated exactly for the STORAGE
+(pinned on goldens made by the reference's `quantize` / `dequantize`); the reference's matmul
+then quantises the activations too and routes outlier columns around (`MatMul8bit`, through a
+third-party cuBLAS int8 wrapper, or bitsandbytes' LLM.int8 for `'8bit'`) -- here activations stay
+bf16 and the expanded bf16 weight feeds the ordinary GEMM, which is the more accurate of the two.
+
+MI355X plan: weights stay 4-bit (8-bit) in HBM (that is what the option is for: memory), and
 each layer expands the matrix it is about to multiply into ONE shared bf16 scratch
 buffer with a streaming HIP kernel, then runs the ordinary MFMA GEMM on it.  At the
 batch sizes this path serves (>= 10^4 residues per forward) the GEMMs are MFMA-bound,
@@ -68,16 +75,17 @@ class Q4Matrix:
 
     def __init__(self, codes, absmax, bias, quant_type: str, scratch: WeightScratch, ln=None):
         self.codes, self.absmax, self.bias = codes.contiguous(), absmax.contiguous(), bias
-        self.codebook = codebook_of(quant_type)
+        self.int8 = quant_type == 'int8'              # row-wise int8 (absmax = per-row scale) instead of 4-bit blocks
+        self.codebook = None if self.int8 else codebook_of(quant_type)
         self.scratch = scratch
-        self.rows, self.cols = codes.shape[0], codes.shape[1] * 2
+        self.rows, self.cols = codes.shape[0], codes.shape[1] * (1 if self.int8 else 2)
         self.gamma = self.c1 = self.c2 = None
         if ln is not None:
             with torch.no_grad():
                 self.gamma = ln.weight.data.float().contiguous()
-                wf = _hip.dequantize_4bit(self.codes, self.absmax, self.codebook, col_scale=self.gamma)
+                wf = self._expand(self.gamma, None)
                 self.c1 = wf.float().sum(dim=1).contiguous()
-                w = _hip.dequantize_4bit(self.codes, self.absmax, self.codebook, out=wf)
+                w = self._expand(None, wf)
                 c2 = torch.zeros(self.rows, dtype=torch.float32, device=codes.device)
                 if ln.bias is not None:
                     c2 += w.float() @ ln.bias.data.float()
@@ -85,15 +93,18 @@ class Q4Matrix:
                     c2 += bias.float()
                 self.c2 = c2.contiguous()
 
+    def _expand(self, col_scale, out):
+        if self.int8:
+            return _hip.dequantize_8bit(self.codes, self.absmax, col_scale=col_scale, out=out)
+        return _hip.dequantize_4bit(self.codes, self.absmax, self.codebook, col_scale=col_scale, out=out)
+
     def plain(self):
         """(W bf16 in scratch, bias)"""
-        out = self.scratch.view(self.rows, self.cols, self.codes.device)
-        return _hip.dequantize_4bit(self.codes, self.absmax, self.codebook, out=out), self.bias
+        return self._expand(None, self.scratch.view(self.rows, self.cols, self.codes.device)), self.bias
 
     def folded(self):
         """(W' = W diag(gamma) bf16 in scratch, c1, c2)"""
-        out = self.scratch.view(self.rows, self.cols, self.codes.device)
-        return _hip.dequantize_4bit(self.codes, self.absmax, self.codebook, col_scale=self.gamma, out=out), self.c1, self.c2
+        return self._expand(self.gamma, self.scratch.view(self.rows, self.cols, self.codes.device)), self.c1, self.c2
 
 
 class Linear4bit(nn.Module):
@@ -128,6 +139,44 @@ class Linear4bit(nn.Module):
                 f'bias={self.bias is not None}, quant_type={self.quant_type}')
 
 
+class Linear8bit(nn.Module):
+    """Row-wise int8 projection (reference `Linear8bit`, esme/quantization.py:87-108): `weight` int8 (N, K)
+    (`cweight` is an alias, the reference's buffer name), `absmax` = the per-row scale (fp32; the reference's
+    `scale`), `bias` bf16."""
+
+    def __init__(self, codes: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor]):
+        super().__init__()
+        self.out_features, self.in_features = codes.shape
+        self.quant_type = 'int8'
+        self.weight = nn.Parameter(codes, requires_grad=False)
+        self.register_buffer('absmax', scale)
+        self.bias = nn.Parameter(bias, requires_grad=False) if bias is not None else None
+
+    @property
+    def cweight(self):
+        return self.weight.data
+
+    @property
+    def scale(self):
+        return self.absmax
+
+    @classmethod
+    def from_linear(cls, linear, quant_type: str = 'int8') -> 'Linear8bit':
+        codes, scale = _hip.quantize_8bit(linear.weight.data)
+        return cls(codes, scale, linear.bias.data if linear.bias is not None else None)
+
+    def dequantize(self, out=None) -> torch.Tensor:
+        return _hip.dequantize_8bit(self.weight.data, self.absmax, out=out)
+
+    def forward(self, x, epilogue=_hip.EPI_NONE, resid=None, alpha=1.0, out=None):
+        shape = x.shape
+        y = _hip.gemm(x.reshape(-1, shape[-1]), self.dequantize(), self.bias, epilogue, resid, alpha, out)
+        return y if x.dim() == 2 else y.view(*shape[:-1], y.shape[-1])
+
+    def extra_repr(self):
+        return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, int8 rows'
+
+
 def _repoint(mods, codes, absmax):
     """Make each module's parameters row slices of the packed tensors (no duplicate storage)."""
     r = 0
@@ -144,9 +193,10 @@ def quantize_layer_(layer, quant_type: str, scratch: WeightScratch):
     gets the row-packed Q4Matrix objects its forward runs."""
     att = layer.self_attn
     if getattr(layer, 'padded', False):
-        raise NotImplementedError('4-bit weights are not implemented for padded layouts (e.g. ESM2-35M)')
+        raise NotImplementedError('quantised weights are not implemented for padded layouts (e.g. ESM2-35M)')
+    QLinear = Linear8bit if quant_type == 'int8' else Linear4bit
     with torch.no_grad():
-        q4 = [Linear4bit.from_linear(getattr(att, n), quant_type) for n in ('q', 'k', 'v', 'out')]
+        q4 = [QLinear.from_linear(getattr(att, n), quant_type) for n in ('q', 'k', 'v', 'out')]
         codes = torch.cat([m.weight.data for m in q4[:3]], dim=0).contiguous()
         absmax = torch.cat([m.absmax for m in q4[:3]], dim=0).contiguous()
         _repoint(q4[:3], codes, absmax)
@@ -159,14 +209,14 @@ def quantize_layer_(layer, quant_type: str, scratch: WeightScratch):
 
         ln = layer.final[0]
         if layer.final_activation == 'gelu':
-            up, down = Linear4bit.from_linear(layer.final[1], quant_type), Linear4bit.from_linear(layer.final[3], quant_type)
+            up, down = QLinear.from_linear(layer.final[1], quant_type), QLinear.from_linear(layer.final[3], quant_type)
             layer.final[1], layer.final[3] = up, down
             layer._q4_up = Q4Matrix(up.weight.data, up.absmax, up.bias.data if up.bias is not None else None,
                                     quant_type, scratch, ln=ln)
         else:
             sw = layer.final[1]
-            gate, fc = Linear4bit.from_linear(sw.activation, quant_type), Linear4bit.from_linear(sw.fc, quant_type)
-            down = Linear4bit.from_linear(layer.final[2], quant_type)
+            gate, fc = QLinear.from_linear(sw.activation, quant_type), QLinear.from_linear(sw.fc, quant_type)
+            down = QLinear.from_linear(layer.final[2], quant_type)
             F = gate.out_features
             assert F % 32 == 0
             # the SwiGLU GEMM wants gate / fc rows interleaved in 32-row blocks (include/esme_hip.h)
@@ -185,14 +235,15 @@ def quantize_layer_(layer, quant_type: str, scratch: WeightScratch):
 
 
 def quantize_model_(model, quant_type: str = 'fp4'):
-    """4-bit-quantise every transformer layer of an ESM2 / ESMC model in place."""
+    """Quantise every transformer layer of an ESM2 / ESMC model in place ('fp4' / 'nf4': 4-bit blocks,
+    'int8': row-wise int8)."""
     E = model.embed_dim
-    if E % BLOCK != 0:
+    if quant_type != 'int8' and E % BLOCK != 0:
         raise NotImplementedError(f'4-bit blocks of {BLOCK} need embed_dim % {BLOCK} == 0 (got {E})')
     scratch = WeightScratch()
     for layer in model.layers:
         quantize_layer_(layer, quant_type, scratch)
-    model.quantization = f'4bit-{quant_type}'
+    model.quantization = '8bit' if quant_type == 'int8' else f'4bit-{quant_type}'
     model._q4_scratch = scratch
     return model
 

@@ -220,6 +220,18 @@ int esme_hip_dequantize_4bit(const void* codes, const float* absmax, int64_t N, 
                              const float* codebook, const float* col_scale, void* out,
                              int64_t ldo, void* stream);
 
+/* 8-bit weight storage: row-wise absmax int8, the reference's OWN experimental scheme
+ * (esme/quantization.py:20-26 `quantize` / `dequantize`, used by Linear8bit :87-100), restated with
+ * its bf16 rounding points: scale[n] = max|w[n,:]|; code = trunc(bf16(bf16(w*127)/scale)) (int8);
+ * dequantize writes out[n,k] = bf16((code*scale[n])/127 * col_scale[k]).  Unlike the reference's
+ * MatMul8bit (int8 activations + outlier columns through a third-party cuBLAS wrapper,
+ * quantization.py:37-84) the GEMM then runs on bf16 activations and the expanded bf16 weight, like the
+ * 4-bit path.  w: bf16 (N, K), K % 8 == 0; codes: int8 (N, K) contiguous; scale: fp32 (N). */
+int esme_hip_quantize_8bit(const void* w, int64_t ldw, int64_t N, int K, void* codes, float* scale,
+                           void* stream);
+int esme_hip_dequantize_8bit(const void* codes, const float* scale, int64_t N, int K,
+                             const float* col_scale, void* out, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

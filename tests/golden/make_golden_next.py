@@ -143,7 +143,16 @@ def main():
             g10[f'{kind}_logits_{tag}'] = mg.f32(model(tokens, (cu, ml)))
             g10[f'{kind}_logits2d_{tag}'] = mg.f32(model(tok2d))
     np.savez_compressed(os.path.join(HERE, 'g10_esm1.npz'), **g10)
-    for fn in ('g7_variant.json', 'g8_batching.json', 'g9_pooling.npz', 'g10_esm1.npz'):
+    # ---- G11 the reference's own row-wise int8 quantize / dequantize (esme/quantization.py:20-26)
+    from esme.quantization import quantize as ref_quantize, dequantize as ref_dequantize
+    rng = np.random.Generator(np.random.PCG64(11))
+    wq = torch.from_numpy(rng.standard_normal((24, 320), dtype=np.float32) * 0.05).bfloat16()
+    wq[5] *= 40                                    # a row with a large scale
+    cq, sq = ref_quantize(wq)
+    g11 = {'w': mg.bits(wq), 'codes': cq.numpy(), 'scale': mg.bits(sq),
+           'dequant': mg.bits(ref_dequantize(cq, sq, dtype=torch.bfloat16))}
+    np.savez_compressed(os.path.join(HERE, 'g11_quant8.npz'), **g11)
+    for fn in ('g7_variant.json', 'g8_batching.json', 'g9_pooling.npz', 'g10_esm1.npz', 'g11_quant8.npz'):
         print(f'  {fn:24s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB')
 
 

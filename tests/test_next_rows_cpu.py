@@ -294,3 +294,17 @@ def test_index_fasta_reproduces_samtools_index(tmp_path):
     bad.write_text('>P1\nMK\nLAAG\n')
     with pytest.raises(ValueError):
         index_fasta(bad)
+
+
+def test_oracle_int8_rows_match_reference_functions():
+    """Row-wise int8 storage: oracle == the reference's own quantize / dequantize (esme/quantization.py:20-26)."""
+    g = load_golden('g11_quant8.npz')
+    codes, scale = O.quantize_8bit(g['w'])
+    assert codes.dtype == torch.int8 and torch.equal(codes, g['codes']) and torch.equal(scale, g['scale'])
+    assert torch.equal(O.dequantize_8bit(codes, scale), g['dequant'])
+    assert int(codes.abs().max()) == 127                      # the row maximum maps to +-127
+    w2 = {k: v.bfloat16() for k, v in syn.synthetic_state_dict('esm2', 1, 64, 5).items()}
+    q = O.quantized_weights_8bit(w2)
+    assert sorted(k for k in w2 if not torch.equal(w2[k], q[k])) == sorted(
+        f'layers.0.{s}' for s in ('self_attn.q.weight', 'self_attn.k.weight', 'self_attn.v.weight',
+                                  'self_attn.out.weight', 'final.1.weight', 'final.3.weight'))

@@ -334,3 +334,54 @@ def test_streamed_inference_equals_sequential():
     got = [h.clone() for h in StreamedInference(model, 'forward_representation', pool='mean', depth=1).run(ds.to_dataloader())]
     assert len(got) == len(want_pool) and all(torch.equal(a, b) for a, b in zip(got, want_pool))
     assert got[0].shape == (len(ds.sampler[0]), 128)
+
+
+# ------------------------------------------------------------- int8 row storage
+def test_int8_kernels_bit_exact_vs_reference_and_oracle():
+    from esme import _hip
+    g = load_golden('g11_quant8.npz')
+    codes, scale = _hip.quantize_8bit(g['w'].to(DEV))
+    assert torch.equal(codes.cpu(), g['codes']) and torch.equal(scale.cpu(), g['scale'].float())
+    assert torch.equal(_hip.dequantize_8bit(codes, scale).cpu(), g['dequant'])
+    rng = np.random.Generator(np.random.PCG64(8))
+    for shape in ((1280, 1280), (5, 64), (3840, 1280)):
+        w = torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * 0.04).bfloat16()
+        w[0] = 0
+        c, s = _hip.quantize_8bit(w.to(DEV))
+        w_ref = w.clone(); w_ref[0, 0] = 1e-30                          # the reference divides 0/0 on an all-zero row
+        oc, os_ = O.quantize_8bit(w)
+        assert torch.equal(c.cpu()[1:], oc[1:]) and torch.equal(s.cpu()[1:], os_.float()[1:])
+        assert bool((c[0] == 0).all()) and float(s[0]) == 0.0
+        sc = torch.from_numpy(rng.uniform(0.3, 1.7, shape[1]).astype(np.float32))
+        d = _hip.dequantize_8bit(c, s, col_scale=sc.to(DEV))
+        assert torch.equal(d.cpu()[1:], O.dequantize_8bit(oc, os_, sc)[1:])
+        assert rel_fro(_hip.dequantize_8bit(c, s).float().cpu()[1:], w.float()[1:]) < 1.5e-2
+
+
+@pytest.mark.parametrize('kind,L,E,H,lengths', [('esm2', 2, 64, 4, [5, 26, 61]), ('esmc', 1, 960, 15, [45, 150, 5])])
+def test_int8_model_vs_oracle_on_dequantised_weights(kind, L, E, H, lengths):
+    from esme import ESM
+    from esme.quantization import Linear8bit, weight_bytes
+    seed = 51
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), f'{kind}_test', L, E, H, seed=seed)
+        model = ESM.from_pretrained(path, quantization='8bit', device=DEV)
+        exp = ESM.from_pretrained(path, quantization='8bitexperimental', device=DEV)
+    sd = model.state_dict()
+    quant_keys = [k for k in sd if k.startswith('layers.') and k.endswith(O.QUANTISED_SUFFIXES)]
+    assert len(quant_keys) == L * (6 if kind == 'esm2' else 7) and all(sd[k].dtype == torch.int8 for k in quant_keys)
+    lin = model.layers[0].self_attn.q
+    assert isinstance(lin, Linear8bit) and lin.cweight.dtype == torch.int8 and lin.scale.shape == (E,)
+    w = {k: v.bfloat16() for k, v in syn.synthetic_state_dict(kind, L, E, seed).items()}
+    qw = O.quantized_weights_8bit(w)
+    tokens, cu, ml = syn.random_tokens(lengths, seed=seed), syn.cu_lens_of(lengths), max(lengths)
+    ref32 = O.forward_logits(qw, H, tokens, cu, ml, dtype=torch.float32)
+    refbf = O.forward_logits(qw, H, tokens, cu, ml, dtype=torch.bfloat16)
+    got = model(tokens.to(DEV), (cu.to(DEV), ml))
+    assert_parity(got, ref32, refbf, f'int8 {kind} E={E} logits vs oracle(dequantised weights)')
+    assert torch.equal(exp(tokens.to(DEV), (cu.to(DEV), ml)), got)
+    dense = build(kind, L, E, H, seed)
+    drift = rel_fro(got.float().cpu(), dense(tokens.to(DEV), (cu.to(DEV), ml)).float().cpu())
+    print(f'\n[int8 drift] {kind} E={E}: rel_fro(int8 logits, bf16 logits) = {drift:.4f}; resident bytes '
+          f'{weight_bytes(model) / weight_bytes(dense):.2f}x')
+    assert drift < 0.05
