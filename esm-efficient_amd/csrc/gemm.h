@@ -21,8 +21,8 @@ struct GemmArgs {
     // tile rasterisation: bands of gm tile-rows, inside a band groups of gn tile-columns walked
     // column-major (gm = 1, gn = tiles_n is plain row-major)
     int tiles_m, gm, gn;
-    int nt_store;                // tuning hook: 2 = skip the C stores, 3 = skip the whole epilogue (timing experiments only)
-    int stagger;                 // first-wave start skew (units of ~1024 cycles across the 256 first blocks)
+    int nt_store;                // TRACE build only: 2 = skip the C stores, 3 = skip the whole epilogue (timing experiments)
+    int stagger;                 // TRACE build only: first-round start skew (units of ~1024 cycles across the 256 first blocks)
     // LayerNorm folded into the consumer GEMM (W already scaled by gamma):
     //   y = rstd[m]*acc - (rstd*mean)[m]*c1[n] + c2[n];  mean/rstd of row m are reduced in-kernel from
     //   ln_partial (ln_nblk, M, 2): per-block (sum, sum of squares) over ln_dim features
@@ -32,6 +32,14 @@ struct GemmArgs {
     float* stats_out;
     unsigned long long* trace = nullptr;      // ESME_GEMM_TRACE builds only: per-block phase timestamps (16 per block)
 };
+
+// The tuning hooks (start skew, "no C store", "loop only") exist only in the instrumented build (`make TRACE=1`);
+// the production kernel carries none of them.
+#ifdef ESME_GEMM_TRACE
+#define ESME_TUNE_STORE_OK (a.nt_store != 2)
+#else
+#define ESME_TUNE_STORE_OK true
+#endif
 
 #ifdef ESME_GEMM_TRACE
 #define ESME_TRACE_MARK(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)

@@ -48,10 +48,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 
     // Optional start skew for the first wave of workgroups: de-synchronises the CUs so that the
     // epilogue store bursts (and the prologue fetch bursts) of different CUs do not coincide.
+#ifdef ESME_GEMM_TRACE
     if (a.stagger > 0 && blockIdx.x < 256) {
         const int n = (blockIdx.x * a.stagger) >> 8;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);       // 16 x 64 cycles
     }
+#endif
     // XCD-aware, L2-friendly tile order: each XCD (own 4 MB L2) walks a contiguous range of ids;
     // ids sweep gm x gn groups of tiles so the ~32 workgroups resident on an XCD share gm
     // activation slabs and gn weight slabs instead of 1-2 and all of them.
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     }
     __syncthreads();                          // all waves past their last LDS fragment use before the slab overwrites it
     ESME_TRACE_MARK(2);
+#ifdef ESME_GEMM_TRACE
     if (a.nt_store == 3) return;              // tuning hook: main loop only (results discarded)
+#endif
 
     // ---- epilogue.  Lane owns token row m; accumulator quad g = 4 consecutive output columns.
     // Fast path: bias / activation / residual are applied in the accumulator layout, the bf16
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
-                if (col_ok && m < a.M && a.nt_store != 2) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+                if (col_ok && m < a.M && ESME_TUNE_STORE_OK) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine

@@ -3,6 +3,8 @@
 epilogues), interleaved over several rounds; prints median / min per variant."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get('EPI_ABLATE', '0') == '1':      # the 'no C store' / 'loop only' hooks live in the TRACE=1 build
+    os.environ.setdefault('ESME_HIP_LIB', os.path.join(ROOT, 'esm-efficient_amd', 'esme', 'libesme_hip_trace.so'))
 sys.path.insert(0, os.path.join(ROOT, 'esm-efficient_amd'))
 import torch
 from esme import _hip
@@ -52,7 +54,7 @@ def dbg(v, fn):
         fn()
         _hip.load().esme_hip_debug_set_gemm_nt(0)
     return run
-if os.environ.get('EPI_ABLATE', '1') == '1':
+if os.environ.get('EPI_ABLATE', '0') == '1':
     for k in ('qkv +rot+lnf', 'out resid+stats', 'ffn1 gelu+lnf', 'ffn2 resid+stats'):
         variants[k + ' [no C store]'] = dbg(2, variants[k])
         variants[k + ' [loop only]'] = dbg(3, variants[k])

@@ -3,6 +3,7 @@
 other CUs' main loops?  Times the four production GEMMs of an ESM2-650M layer per skew value."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('ESME_HIP_LIB', os.path.join(ROOT, 'esm-efficient_amd', 'esme', 'libesme_hip_trace.so'))   # tuning hooks live in the TRACE=1 build
 sys.path.insert(0, os.path.join(ROOT, 'esm-efficient_amd'))
 import torch
 from esme import _hip
