@@ -536,7 +536,16 @@ __global__ __launch_bounds__(128 * WNW) void lab_gemm_t(const LabArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM, l31 = lane & 31, hi = lane >> 5;
     unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = pid % a.tiles_n; const int64_t tile_m = pid / a.tiles_n;
+    int tile_n; int64_t tile_m;
+    if (FLAGS & 256) {                                        // production raster: bands of 8 tile-rows, groups of 4 columns
+        const int per_band = 8 * a.tiles_n;
+        const int band = pid / per_band, lb = pid - band * per_band;
+        const int rows = min(8, a.tiles_m - band * 8);
+        const int gn = min(4, a.tiles_n);
+        const int grp_ = rows * gn;
+        const int ng = lb / grp_, rg = lb - ng * grp_;
+        tile_n = ng * gn + rg / rows; tile_m = (int64_t)band * 8 + rg % rows;
+    } else { tile_n = pid % a.tiles_n; tile_m = pid / a.tiles_n; }
     const int64_t m0 = tile_m * BM; const int n0 = tile_n * BN;
     const int64_t lm0 = (FLAGS & 1) ? 0 : m0; const int ln0 = (FLAGS & 1) ? 0 : n0;
     const u16* srcA[IA]; const u16* srcW[IW];
@@ -657,6 +666,243 @@ static void launch_t(LabArgs a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_n * a.tiles_m), dim3(128 * WNW), smem, s, a);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Variant U: 256x256 tile, 8 waves (wave tile 128 x 64), K streamed in UNITS of 32 through a ring of FOUR
+// 32 KB LDS slots (rows of 64 B, chunk swizzle (row>>2)&3), THREE units in flight: the LDS-DMA of unit u+3
+// is issued into the slot unit u-1 just left, and the wait before the per-unit barrier is a COUNTED
+// vmcnt(8) (= two younger units still in flight) instead of a drain.  One raw s_barrier per unit.
+template <int FLAGS>
+__global__ __launch_bounds__(512) void lab_gemm_u(const LabArgs a) {
+    constexpr int NW = 8, WTM = 128, WTN = 64, FM = 4, FN = 2;
+    constexpr int SLOT = 512 * 64, A_BYTES = 256 * 64, DPU = 4;          // bytes per slot, A part, DMA instrs per wave per unit
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % 2, wn = wave / 2, l31 = lane & 31, hi = lane >> 5;
+    unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
+    int tile_n; int64_t tile_m;
+    if (FLAGS & 256) {
+        const int per_band = 8 * a.tiles_n;
+        const int band = pid / per_band, lb = pid - band * per_band;
+        const int rows = min(8, a.tiles_m - band * 8);
+        const int gn = min(4, a.tiles_n);
+        const int grp_ = rows * gn;
+        const int ng = lb / grp_, rg = lb - ng * grp_;
+        tile_n = ng * gn + rg / rows; tile_m = (int64_t)band * 8 + rg % rows;
+    } else { tile_n = pid % a.tiles_n; tile_m = pid / a.tiles_n; }
+    const int64_t m0 = tile_m * 256; const int n0 = tile_n * 256;
+    const int64_t lm0 = (FLAGS & 1) ? 0 : m0; const int ln0 = (FLAGS & 1) ? 0 : n0;
+    // DMA sources: instruction j = i*8 + wave covers slot rows [j*16, j*16+16): rows < 256 are A rows, the rest W rows
+    const u16* src[DPU];
+#pragma unroll
+    for (int i = 0; i < DPU; ++i) {
+        const int j = i * NW + wave;
+        const int row = j * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < 256) { int64_t gr = lm0 + row; gr = gr < a.M ? gr : a.M - 1; src[i] = a.A + gr * a.lda + c * 8; }
+        else { int gr = ln0 + row - 256; gr = gr < a.N ? gr : a.N - 1; src[i] = a.W + (int64_t)gr * a.K + c * 8; }
+    }
+    auto dma = [&](int unit, int slot) {
+#pragma unroll
+        for (int i = 0; i < DPU; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + unit * 32), (lptr_t)(smem + slot * SLOT + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    // fragment read offsets inside a slot: row*64 + ((chunk ^ ((row>>2)&3)) << 4), chunk = ks*2 + hi
+    int offA[FM][2], offW[FN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) { const int r = wm * WTM + j * 32 + l31; offA[j][ks] = r * 64 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) << 4); }
+#pragma unroll
+        for (int i = 0; i < FN; ++i) { const int r = 256 + wn * WTN + i * 32 + l31; offW[i][ks] = r * 64 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) << 4); }
+    }
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct Frag { bf16x8 w[FN], a[FM]; };
+    auto rd = [&](Frag& f, int slot, int ks) {
+        const char* base = smem + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(base + offW[i][ks]);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(base + offA[j][ks]);
+    };
+    auto mm = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
+    };
+    const int NU = a.K / 32;                                    // units; NU >= 4 assumed in the lab
+    dma(0, 0); dma(1, 1); dma(2, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // unit 0 landed (units 1, 2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+    rd(f0, 0, 0);
+    for (int u = 0; u < NU; ++u) {
+        const int slot = u & 3;
+        rd(f1, slot, 1);
+        if (u + 3 < NU) dma(u + 3, (u + 3) & 3);                // into the slot unit u-1 left at the previous barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        // unit u+1 must have landed for everyone; units u+2, u+3 stay in flight (steady state: 8 younger DMA instructions)
+        if (u + 3 < NU) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (u + 2 < NU) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < NU) rd(f0, (u + 1) & 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(f1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((FLAGS & 2) && a.K > 0) return;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int64_t m = m0 + wm * WTM + j * 32 + l31;
+                if (m >= a.M) continue;
+                u32x2 pk = {pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+                *reinterpret_cast<u32x2*>(a.C + m * a.ldc + n) = pk;
+            }
+        }
+}
+
+template <int FLAGS>
+static void launch_u(LabArgs a, hipStream_t s) {
+    constexpr int smem = 4 * 512 * 64;
+    a.tiles_n = (a.N + 255) / 256; a.tiles_m = (int)((a.M + 255) / 256);
+    auto kern = lab_gemm_u<FLAGS>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_n * a.tiles_m), dim3(512), smem, s, a);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Variant V: U's four-slot ring with counted vmcnt (three 32-k units in flight) + P's ping-pong: wave groups
+// G0 (waves 0-3) / G1 (4-7) run one phase apart, every k-step is a load phase (6 ds_read_b128, the unit's DMA
+// issue) and a compute phase (8 MFMAs under s_setprio 1), two raw barriers per k-step.
+template <int FLAGS>
+__global__ __launch_bounds__(512) void lab_gemm_v(const LabArgs a) {
+    constexpr int NW = 8, WTM = 128, WTN = 64, FM = 4, FN = 2;
+    constexpr int SLOT = 512 * 64, DPU = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % 2, wn = wave / 2, l31 = lane & 31, hi = lane >> 5;
+    const int grp = wave >> 2;
+    unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = pid % a.tiles_n; const int64_t tile_m = pid / a.tiles_n;
+    const int64_t m0 = tile_m * 256; const int n0 = tile_n * 256;
+    const int64_t lm0 = (FLAGS & 1) ? 0 : m0; const int ln0 = (FLAGS & 1) ? 0 : n0;
+    const u16* src[DPU];
+#pragma unroll
+    for (int i = 0; i < DPU; ++i) {
+        const int j = i * NW + wave;
+        const int row = j * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        if (row < 256) { int64_t gr = lm0 + row; gr = gr < a.M ? gr : a.M - 1; src[i] = a.A + gr * a.lda + c * 8; }
+        else { int gr = ln0 + row - 256; gr = gr < a.N ? gr : a.N - 1; src[i] = a.W + (int64_t)gr * a.K + c * 8; }
+    }
+    auto dma = [&](int unit, int slot) {
+#pragma unroll
+        for (int i = 0; i < DPU; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + unit * 32), (lptr_t)(smem + slot * SLOT + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    int offA[FM][2], offW[FN][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) { const int r = wm * WTM + j * 32 + l31; offA[j][ks] = r * 64 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) << 4); }
+#pragma unroll
+        for (int i = 0; i < FN; ++i) { const int r = 256 + wn * WTN + i * 32 + l31; offW[i][ks] = r * 64 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) << 4); }
+    }
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int NU = a.K / 32;
+    dma(0, 0); dma(1, 1); dma(2, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger G1 by one phase
+    for (int u = 0; u < NU; ++u) {
+        const char* base = smem + (u & 3) * SLOT;
+        const int younger = u + 3 < NU ? 8 : (u + 3 == NU ? 4 : 0);      // DMA instructions of units u+2.. still allowed in flight
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // ---- load phase
+            bf16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(base + offW[i][ks]);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(base + offA[j][ks]);
+            if (ks == 0 && u + 3 < NU) dma(u + 3, (u + 3) & 3);
+            if (ks == 1 && grp == 1) {
+                if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- compute phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (ks == 1 && grp == 0) {
+                if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // balance the stagger barrier
+    if ((FLAGS & 2) && a.K > 0) return;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * WTN + i * 32 + 8 * g + 4 * hi;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int64_t m = m0 + wm * WTM + j * 32 + l31;
+                if (m >= a.M) continue;
+                u32x2 pk = {pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
+                *reinterpret_cast<u32x2*>(a.C + m * a.ldc + n) = pk;
+            }
+        }
+}
+
+template <int FLAGS>
+static void launch_v(LabArgs a, hipStream_t s) {
+    constexpr int smem = 4 * 512 * 64;
+    a.tiles_n = (a.N + 255) / 256; a.tiles_m = (int)((a.M + 255) / 256);
+    auto kern = lab_gemm_v<FLAGS>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_n * a.tiles_m), dim3(512), smem, s, a);
+}
+
 template <int BM, int BN, int WM, int WN, int FLAGS>
 static void launch(LabArgs a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
@@ -717,6 +963,14 @@ extern "C" int lab_run(int variant, const void* A, const void* W, void* C, int64
         case 43: launch_t<2, 3 + 8 + 16>(a, s); break;
         case 44: launch_t<2, 3 + 8 + 16 + 32>(a, s); break;
         case 45: launch_t<2, 3 + 16>(a, s); break;
+        case 60: launch_u<0>(a, s); break;
+        case 61: launch_u<2>(a, s); break;
+        case 62: launch_u<3>(a, s); break;
+        case 63: launch_v<0>(a, s); break;
+        case 64: launch_v<2>(a, s); break;
+        case 65: launch_v<3>(a, s); break;
+        case 70: launch_t<4, 2 + 256>(a, s); break;
+        case 71: launch_u<2 + 256>(a, s); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -5,7 +5,7 @@ lib.lab_run.restype = ctypes.c_int
 lib.lab_run.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 names = {0: '256x256 base', 1: '256x256 loads->tile0 (L2 hot)', 2: '256x256 no store', 3: '256x256 L2hot+nostore',
          4: '256x256 grouped raster', 5: '128x128 base', 6: '128x128 L2 hot', 7: '128x128 L2hot+nostore',
-         8: '128x256 4w', 9: '256x128 4w', 10: '256x128 4w L2hot+nostore', 11: 'pingpong 256x256', 12: 'pingpong no store', 13: 'pingpong L2hot+nostore', 14: 'dblbuf frags', 15: 'dblbuf no store', 16: 'dblbuf L2hot+nostore', 17: 'dblbuf asm-reads', 18: 'dblbuf asm no store', 19: 'dblbuf asm L2hot+nostore', 20: 'S 256x128x32 3stg 2blk/CU', 21: 'S no store', 22: 'S L2hot+nostore', 23: '256x256 4w (128x128 wave tile)', 24: '4w no store', 25: '4w L2hot+nostore', 30: 'T8 full', 31: 'T8 L2hot+nostore', 32: 'T8 hot nostore -ldsread', 33: 'T8 hot nostore -ldsread -dma', 34: 'T8 hot nostore MFMA only', 35: 'T8 hot nostore -dma', 38: 'T8 nostore (HBM)', 39: 'T8 nostore (HBM) +touch', 50: 'T8 full +touch', 36: 'T8 hot nostore no-vmwait', 37: 'T8 hot nostore -ldsread no-vmwait', 46: 'T4 hot nostore no-vmwait', 47: 'T4 hot nostore -ldsread no-vmwait', 40: 'T4 full', 41: 'T4 L2hot+nostore', 42: 'T4 hot nostore -ldsread', 43: 'T4 hot nostore -ldsread -dma', 44: 'T4 hot nostore MFMA only', 45: 'T4 hot nostore -dma'}
+         8: '128x256 4w', 9: '256x128 4w', 10: '256x128 4w L2hot+nostore', 11: 'pingpong 256x256', 12: 'pingpong no store', 13: 'pingpong L2hot+nostore', 14: 'dblbuf frags', 15: 'dblbuf no store', 16: 'dblbuf L2hot+nostore', 17: 'dblbuf asm-reads', 18: 'dblbuf asm no store', 19: 'dblbuf asm L2hot+nostore', 20: 'S 256x128x32 3stg 2blk/CU', 21: 'S no store', 22: 'S L2hot+nostore', 23: '256x256 4w (128x128 wave tile)', 24: '4w no store', 25: '4w L2hot+nostore', 30: 'T8 full', 31: 'T8 L2hot+nostore', 32: 'T8 hot nostore -ldsread', 33: 'T8 hot nostore -ldsread -dma', 34: 'T8 hot nostore MFMA only', 35: 'T8 hot nostore -dma', 38: 'T8 nostore (HBM)', 39: 'T8 nostore (HBM) +touch', 50: 'T8 full +touch', 36: 'T8 hot nostore no-vmwait', 37: 'T8 hot nostore -ldsread no-vmwait', 46: 'T4 hot nostore no-vmwait', 47: 'T4 hot nostore -ldsread no-vmwait', 60: 'U 4-slot ring, 3 units in flight (full)', 61: 'U no store (HBM)', 62: 'U L2hot+nostore', 63: 'V ring + pingpong (full)', 64: 'V no store (HBM)', 65: 'V L2hot+nostore', 70: 'T8 no store (HBM) + 8x4 raster', 71: 'U no store (HBM) + 8x4 raster', 40: 'T4 full', 41: 'T4 L2hot+nostore', 42: 'T4 hot nostore -ldsread', 43: 'T4 hot nostore -ldsread -dma', 44: 'T4 hot nostore MFMA only', 45: 'T4 hot nostore -dma'}
 names.update(eval(os.environ.get('LAB_NAMES', '{}')))
 variants = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else sorted(names)
 shapes = [(50000, 5120, 1280), (50000, 3840, 1280), (50000, 1280, 5120), (50000, 1280, 1280)]
