@@ -1,0 +1,31 @@
+"""bench.py prints ONE JSON line with the driver's contract keys (+ roofline, + cpu_baseline at N = 1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                          '--model', 'esm2_150m', '--tokens', '16384', '--seq-len', '512', '--cpu-sample-tokens', '512'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['unit'] == 'residues/s' and d['scaling'] == 'weak' and d['dtype'] == 'bf16' and d['data'] == 'synthetic'
+    assert d['vs_baseline'] is None and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 16384 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 'traffic' in r
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'residues/s' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
