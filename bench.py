@@ -143,12 +143,25 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        # one-time setup, not part of the W warm-up steps: the first two forwards pack / fold the weights into
+        # their GEMM layouts, load the kernel modules and grow the allocator pools (338 ms and ~145 ms vs 75 ms)
+        for _ in range(2):
             step()
         fence()
+        for i in range(args.warmup):
+            if os.environ.get('BENCH_DEBUG'):
+                torch.cuda.synchronize(); _t = time.perf_counter()
+            step()
+            if os.environ.get('BENCH_DEBUG'):
+                torch.cuda.synchronize(); print(f'[debug] warmup step {i}: {1e3 * (time.perf_counter() - _t):.1f} ms', file=sys.stderr)
+        fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if os.environ.get('BENCH_DEBUG'):
+                torch.cuda.synchronize(); _t = time.perf_counter()
             out = step()
+            if os.environ.get('BENCH_DEBUG'):
+                torch.cuda.synchronize(); print(f'[debug] timed step {i}: {1e3 * (time.perf_counter() - _t):.1f} ms', file=sys.stderr)
         fence()
         elapsed = time.perf_counter() - t0
     if world > 1:
@@ -170,6 +183,7 @@ def main():
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
                    'parallelism': f'dp{world} (protein-sharded, logits all-gather)' if world > 1 else 'single GPU',
                    'launch': 'hipGraph replay' if args.graph else 'eager (one ctypes launch per kernel)',
+                   'setup': '2 untimed forwards before the warm-up steps (weight packing / LN folding, module load)',
                    'weights': 'synthetic (numpy PCG64), reference checkpoint layout'
                               + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme/quantization.py)')},
         'e2e': {'algorithmic_tflop_per_step': round(flops_step / 1e12, 3),
