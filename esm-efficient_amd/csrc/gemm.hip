@@ -147,14 +147,42 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                                              (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
     };
     static_assert(IA % 2 == 0 && IW % 2 == 0, "stage_half splits the per-thread chunks in two");
-    stage(0, 0);
-    // ---- folded LayerNorm: reduce this tile's 256 row statistics from the producer's partial sums
-    // once per block, right after K-tile 0's LDS-DMA is issued (the loads overlap its latency), and park {rstd, rstd*mean} in
-    // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
     f32x2* lnst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);
     int* lpos = reinterpret_cast<int*>(smem + 2 * STAGE + BM * 8);       // rotary: position of each tile row
     f32x4* c1s = reinterpret_cast<f32x4*>(smem + 2 * STAGE + BM * 12);    // LN fold: c1 / c2 of the tile's columns
     f32x4* c2s = c1s + BN / 4;
+    // Fused rotary: the cos/sin rows of the tile's 256 positions are fetched by the LDS-DMA during the LAST K-tile
+    // into the stage buffer that is no longer being refilled, once per row group (the WN waves that share the
+    // rows split the instructions), so the epilogue finds them in LDS instead of waiting ~2 us for them.
+    // Layout per row group: [row][cos half | sin half], TB = 2*ROTD bytes per row, 16-B chunks XOR-swizzled.
+    constexpr int CPRW = ROTD > 0 ? ROTD / 8 : 1;            // 16-B chunks per table row
+    constexpr int TB = 2 * ROTD;                             // bytes per table row
+    constexpr int TAB_INSTR = WTM * CPRW / 64;               // DMA instructions per row group
+    constexpr int TAB_PER_WAVE = (TAB_INSTR + WN - 1) / WN;
+    auto rot_prefetch = [&](int fb, int h) {
+        if constexpr (ROTD > 0) {
+            if (n0 >= a.rot_cols) return;                     // block-uniform: a tile of v columns rotates nothing
+            char* tab = smem + fb * STAGE + wm * (WTM * TB);
+#pragma unroll
+            for (int it = 0; it < TAB_PER_WAVE; ++it) {
+                if ((it & 1) != h && TAB_PER_WAVE > 1) continue;
+                if (TAB_PER_WAVE == 1 && h != 0) continue;
+                const int g = wn * TAB_PER_WAVE + it;         // instruction index inside the row group
+                if (g >= TAB_INSTR) continue;
+                const int idx = g * 64 + lane;
+                const int r = idx / CPRW;
+                const int c = (idx % CPRW) ^ (r & (CPRW - 1));
+                const int p = lpos[wm * WTM + r];
+                const u16* src = (c < CPRW / 2) ? a.cosT + (int64_t)p * ROTD + c * 8
+                                                : a.sinT + (int64_t)p * ROTD + (c - CPRW / 2) * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tab + g * 1024), 16, 0, 0);
+            }
+        }
+    };
+    stage(0, 0);
+    // ---- folded LayerNorm: reduce this tile's 256 row statistics from the producer's partial sums
+    // once per block, right after K-tile 0's LDS-DMA is issued (the loads overlap its latency), and park {rstd, rstd*mean} in
+    // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
     if constexpr (ROTD > 0) {
         if (tid < BM) {
             int64_t m = m0 + tid;
@@ -210,11 +238,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const bool more = kt + 1 < KT;
         rd(f1, base, 1);
         if (more) stage_half(kt + 1, buf ^ 1, 0);
+        else rot_prefetch(buf ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         mm(f0);
         __builtin_amdgcn_sched_barrier(0);
         rd(f0, base, 2);
         if (more) stage_half(kt + 1, buf ^ 1, 1);
+        else rot_prefetch(buf ^ 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mm(f1);
         __builtin_amdgcn_sched_barrier(0);
@@ -287,29 +317,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     acc[i][j][4 * g] += b0; acc[i][j][4 * g + 1] += b1; acc[i][j][4 * g + 2] += b2; acc[i][j][4 * g + 3] += b3;
                 }
             }
+        // cos/sin rows of the tile's positions were prefetched during the last K-tile into the stage buffer that
+        // was free by then (rot_prefetch; shared by the WN waves of a row group; the main loop's last barrier
+        // published them), so the accumulator quads read them straight from LDS.
+        const char* tab = smem + ((((a.K / BK) - 1) & 1) ^ 1) * STAGE + wm * (WTM * TB);
         if (nw0 < a.rot_cols) {                               // wave-uniform: whole heads of q or k
-            // cos/sin rows of this wave's 128 positions: fetched by the LDS-DMA in whole lines into the
-            // wave's slab ([row][cos half | sin half], XOR-swizzled 16-B chunks) instead of 8-B loads
-            // scattered over 32 table rows per instruction; the accumulator quads then read LDS.
-            constexpr int CPRW = ROTD / 8;                    // 16-B chunks per slab row (cos + sin halves)
-            constexpr int TB = 2 * ROTD;                      // bytes per slab row
-            constexpr int NI = WTM * CPRW / 64;
-#pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int idx = it * 64 + lane;
-                const int r = idx / CPRW;
-                const int c = (idx % CPRW) ^ (r & (CPRW - 1));
-                const int p = lpos[wm * WTM + r];
-                const u16* src = (c < CPRW / 2) ? a.cosT + (int64_t)p * ROTD + c * 8
-                                                : a.sinT + (int64_t)p * ROTD + (c - CPRW / 2) * 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + it * 1024), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
                 const int r = j * 32 + l31;
-                const char* trow = slab + r * TB + hi * 8;
+                const char* trow = tab + r * TB + hi * 8;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {                 // q = quad index i*4+g over the 64 columns
                     constexpr int HALF = ROTD / 2;
@@ -329,8 +345,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();                  // table reads done before the slab takes results
         }
+        // the result slabs overlay the table region: every wave must be done reading tables before any slab write
+        if (n0 < a.rot_cols) __syncthreads();
     }
 
     ESME_TRACE_MARK(3);
