@@ -259,7 +259,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         mm(f1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                          // all waves past their last LDS fragment use before the slab overwrites it
+    // No barrier here: every wave finished its last LDS fragment reads before the barrier inside the final
+    // iteration (the k-step-3 fragments are read ahead of it and nothing is read after it), so the stage
+    // memory is already free for the epilogue slabs.
     ESME_TRACE_MARK(2);
 #ifdef ESME_GEMM_TRACE
     if (a.nt_store == 3) return;              // tuning hook: main loop only (results discarded)
