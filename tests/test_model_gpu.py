@@ -244,3 +244,22 @@ def test_esm2_35m_from_zoo():
     lp = model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), ml))
     assert lp.shape == (2048, 33) and torch.isfinite(lp.float()).all()
     assert torch.allclose(lp.float().exp().sum(-1).cpu(), torch.ones(2048), atol=3e-2)
+
+
+def test_empty_sequence_and_empty_batch():
+    """Degenerate packings: a zero-length sequence inside a batch changes nothing for its neighbours, and an
+    empty batch returns an empty result instead of crashing."""
+    model = build('esm2', 2, 320, 20, 5)
+    toks = syn.random_tokens([40, 25], seed=9).to(DEV)
+    cu2 = torch.tensor([0, 40, 65], dtype=torch.int32, device=DEV)
+    cu3 = torch.tensor([0, 40, 40, 65], dtype=torch.int32, device=DEV)          # an empty protein in the middle
+    assert torch.equal(model(toks, (cu2, 40)), model(toks, (cu3, 40)))
+    from esme.pooling import partition_mean_pool
+    rep = model.forward_representation(toks, (cu3, 40))
+    pooled = partition_mean_pool(rep, cu3)
+    assert pooled.shape == (3, 320) and bool((pooled[1] == 0).all())
+    empty = torch.zeros(0, dtype=torch.int64, device=DEV)
+    out = model(empty, (torch.zeros(1, dtype=torch.int32, device=DEV), 1))
+    assert out.shape == (0, 33)
+    lp = model.predict_log_prob(empty, (torch.zeros(1, dtype=torch.int32, device=DEV), 1))
+    assert lp.shape == (0, 33)
