@@ -97,3 +97,16 @@ def test_fuzz_rowops(seed):
     sums = _hip.row_sums(x.to(dev())).cpu()[0]
     assert torch.allclose(sums[:, 0], x.float().sum(1), atol=1e-3, rtol=1e-4)
     assert torch.allclose(sums[:, 1], x.float().pow(2).sum(1), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize('lengths,H,d', [([4097, 3], 2, 64), ([3500, 30, 1], 1, 32), ([2049], 1, 128)])
+def test_attention_long_sequences(lengths, H, d):
+    """Sequence lengths at / beyond the reference workflows' max_len = 3 500 (inference_on_human.py:11)."""
+    from esme import _hip
+    T, E = sum(lengths), H * d
+    qkv = rnd((T, 3 * E), 17)
+    cu = torch.tensor(np.r_[0, np.cumsum(lengths)], dtype=torch.int32)
+    x = qkv.to(dev())
+    got = _hip.attn_varlen(x[:, :E], x[:, E:2 * E], x[:, 2 * E:], cu.to(dev()), max(lengths), H)
+    q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    check(got, O.varlen_attention(q, k, v, cu).reshape(T, E), rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn {lengths}')
