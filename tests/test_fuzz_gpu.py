@@ -109,4 +109,6 @@ def test_attention_long_sequences(lengths, H, d):
     x = qkv.to(dev())
     got = _hip.attn_varlen(x[:, :E], x[:, E:2 * E], x[:, 2 * E:], cu.to(dev()), max(lengths), H)
     q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
-    check(got, O.varlen_attention(q, k, v, cu).reshape(T, E), rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn {lengths}')
+    ref = O.varlen_attention(q, k, v, cu).reshape(T, E)
+    for a, b in zip(cu[:-1].tolist(), cu[1:].tolist()):          # per sequence: output magnitudes scale with 1/sqrt(S)
+        check(got[a:b], ref[a:b], rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn {lengths} rows {a}:{b}')
