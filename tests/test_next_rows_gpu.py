@@ -385,3 +385,18 @@ def test_int8_model_vs_oracle_on_dequantised_weights(kind, L, E, H, lengths):
     print(f'\n[int8 drift] {kind} E={E}: rel_fro(int8 logits, bf16 logits) = {drift:.4f}; resident bytes '
           f'{weight_bytes(model) / weight_bytes(dense):.2f}x')
     assert drift < 0.05
+
+
+def test_mask_margin_accepts_dataset_and_dataloader():
+    """predict_mask_margin(seq) with seq a str, a MaskMarginDataset or a DataLoader of one (reference variant.py:128-136)."""
+    from torch.utils.data import DataLoader
+    from esme.variant import MaskMarginDataset, predict_mask_margin
+    model = build('esmc', 2, 128, 2, 21)
+    seq = 'MADQLTEEQIAEFKEAFSLFDKDGDGTITTKELGTV'
+    a = predict_mask_margin(model, seq, batch_size=8)
+    b = predict_mask_margin(model, MaskMarginDataset(seq), batch_size=8)
+    c = predict_mask_margin(model, DataLoader(MaskMarginDataset(seq), batch_size=8, shuffle=False))
+    assert list(a.index) == list(b.index) == list(c.index)
+    assert np.array_equal(a['score'].to_numpy(), b['score'].to_numpy()) and np.array_equal(a['score'].to_numpy(), c['score'].to_numpy())
+    with pytest.raises(ValueError):
+        predict_mask_margin(model, 123)
