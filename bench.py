@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model esm2_650m] [--tokens 50000]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Launched plainly with --gpus N > 1 (no RANK in the environment) it re-executes itself under
+`torch.distributed.run` with N ranks on 127.0.0.1 (one process per GPU, RCCL), so both forms
+give an N-rank job; a world size that differs from --gpus is an error, never a silent 1-GPU run.
+
 One step = one `model(tokens, (cu_lens, max_len))` forward (embedding -> L layers ->
 final LN -> LM head -> (T, V) bf16 logits on device) over one synthetic packed batch
 that is already resident in HBM.  Workload at N=1: BASELINE.json configs[2], the config
@@ -51,6 +55,13 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-tokens', type=int, default=8000)
     ap.add_argument('--no-gather', action='store_true', help='skip the logits all-gather when N>1')
+    ap.add_argument('--auto-graph', action='store_true',
+                    help='replay from a hipGraph when the forward is launch-bound (T x L <= 400 000)')
+    ap.add_argument('--high-precision', action='store_true',
+                    help="model.set_precision('high'): fp32 residual stream (not the headline mode; see DESIGN.md section 4)")
+    ap.add_argument('--spawn', action='store_true',
+                    help='go through the torch.distributed.run self-launch even for --gpus 1 (exercises the RCCL '
+                         'init + launcher path on a single-GPU box)')
     ap.add_argument('--graph', action='store_true',
                     help='replay the forward from a hipGraph (esme/graph.py); matters for small models / batches')
     ap.add_argument('--quantization', choices=['none', '4bit', '8bit'], default='none',
@@ -71,9 +82,12 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(weights, heads, kind, L, E, seq_len, sample_tokens):
+def cpu_baseline(weights, heads, kind, L, E, seq_len, sample_tokens, gpu_logits=None):
     """Oracle (port of the reference's CPU path) on a bounded sample of the same workload:
-    `sample_tokens` residues in sequences of `seq_len`, all L layers + head, bf16."""
+    `sample_tokens` residues in sequences of `seq_len`, all L layers + head, bf16.  The sample is the
+    first `sample_tokens` residues of rank 0's batch (same generator stream), so when `gpu_logits`
+    (the timed forward's output rows for those residues) is given the two are compared as well: the
+    full-depth, full-batch forward is value-checked in the same run, not only isfinite-checked."""
     from oracle import esm_oracle as O
     from esme import synthetic as syn
     cores = os.cpu_count() or 1
@@ -85,28 +99,74 @@ def cpu_baseline(weights, heads, kind, L, E, seq_len, sample_tokens):
         out = O.forward_logits(weights, heads, tokens, cu, max_len, torch.bfloat16)
     dt = time.time() - t0
     assert out.shape[0] == sample_tokens
-    return {'value': round(sample_tokens / dt, 1), 'unit': 'residues/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{sample_tokens} residues ({len(lengths)} x {seq_len}) through all {L} layers + LM head, '
-                      f'bf16 torch-CPU oracle, {dt:.1f} s'}
+    res = {'value': round(sample_tokens / dt, 1), 'unit': 'residues/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{sample_tokens} residues ({len(lengths)} x {seq_len}) through all {L} layers + LM head, '
+                     f'bf16 torch-CPU oracle, {dt:.1f} s'}
+    parity = None
+    if gpu_logits is not None:
+        got = gpu_logits.float().cpu()
+        ref = out.float()
+        n32 = min(sample_tokens, 2 * seq_len)                 # fp32-math oracle on the first two sequences
+        tok32, cu32, ml32, _ = syn.uniform_batch(n32, seq_len, seed=0)
+        with torch.no_grad():
+            ref32 = O.forward_logits(weights, heads, tok32, cu32, ml32, torch.float32).float()
+        rel = lambda a, b: float((a - b).norm() / b.norm())
+        parity = {'rows_vs_oracle_bf16': sample_tokens, 'rel_fro_hip_vs_oracle_bf16': round(rel(got, ref), 5),
+                  'rows_vs_oracle_fp32': n32, 'rel_fro_hip_vs_oracle_fp32': round(rel(got[:n32], ref32), 5),
+                  'rel_fro_oracle_bf16_vs_fp32': round(rel(ref[:n32], ref32), 5),
+                  'max_abs_hip_vs_oracle_fp32': round(float((got[:n32] - ref32).abs().max()), 4)}
+    return res, parity
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on
+    this node (one process per GPU; backend nccl = RCCL over xGMI)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['ESME_BENCH_SPAWNED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def metric_label(model, T, batch):
+    if model == 'esm2_650m' and T == 50000:
+        return 'residues/sec ESM2-650M fwd, 50k packed tokens; % bf16 MFMA peak; 1/2/4/8 GPU'      # BASELINE.json's metric
+    return f'residues/sec {model} fwd, {T} packed tokens per GPU ({batch}); % bf16 MFMA peak (not the headline config)'
 
 
 def main():
     args = parse()
+    launched = 'RANK' in os.environ                 # under torch.distributed.run (driver's N>1 form, or self_launch)
+    if not launched and (args.gpus > 1 or args.spawn):
+        self_launch(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled run')
     dist = None
-    if world > 1:
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f'--gpus {args.gpus} but only {torch.cuda.device_count()} HIP devices are visible')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f'process group has {dist.get_world_size()} ranks, --gpus {args.gpus}')
     else:
         torch.cuda.set_device(0)
-    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    dev = torch.device('cuda', local_rank if launched else 0)
 
     from esme import ESM, _hip, synthetic as syn
     _hip.load()
@@ -120,6 +180,8 @@ def main():
         save_file(weights, path, metadata=syn.checkpoint_metadata(args.model, L, E, H))
         model = ESM.from_pretrained(path, quantization=None if args.quantization == 'none' else args.quantization,
                                     device=str(dev))
+    if args.high_precision:
+        model.set_precision('high')
 
     # ---- this rank's packed batch (resident in HBM before the timed region)
     if args.batch == 'uniform':
@@ -130,18 +192,20 @@ def main():
     T = tokens.numel()
     V = model.vocab_size
     gathered = torch.empty(world * T, V, dtype=torch.bfloat16, device=dev) if world > 1 else None
+    use_graph = args.graph or (args.auto_graph and T * L <= 400_000)
 
     def step():
-        logits = model.graphed(tokens, (cu, max_len), 'forward', clone=False) if args.graph else model(tokens, (cu, max_len))
+        logits = model.graphed(tokens, (cu, max_len), 'forward', clone=False) if use_graph else model(tokens, (cu, max_len))
         if world > 1 and not args.no_gather:
             dist.all_gather_into_tensor(gathered, logits)
         return logits
 
     def fence():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     with torch.no_grad():
         # one-time setup, not part of the W warm-up steps: the first two forwards pack / fold the weights into
         # their GEMM layouts, load the kernel modules and grow the allocator pools (338 ms and ~145 ms vs 75 ms)
@@ -149,21 +213,16 @@ def main():
             step()
         fence()
         for i in range(args.warmup):
-            if os.environ.get('BENCH_DEBUG'):
-                torch.cuda.synchronize(); _t = time.perf_counter()
             step()
-            if os.environ.get('BENCH_DEBUG'):
-                torch.cuda.synchronize(); print(f'[debug] warmup step {i}: {1e3 * (time.perf_counter() - _t):.1f} ms', file=sys.stderr)
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            if os.environ.get('BENCH_DEBUG'):
-                torch.cuda.synchronize(); _t = time.perf_counter()
+            ev[i][0].record()                     # HIP events on the launch stream: per-step device time
             out = step()
-            if os.environ.get('BENCH_DEBUG'):
-                torch.cuda.synchronize(); print(f'[debug] timed step {i}: {1e3 * (time.perf_counter() - _t):.1f} ms', file=sys.stderr)
+            ev[i][1].record()
         fence()
         elapsed = time.perf_counter() - t0
+    step_ms = sorted(s.elapsed_time(e) for s, e in ev)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,18 +233,22 @@ def main():
     flops_step = syn.algorithmic_flops(kind, L, E, lengths)
 
     result = {
-        'metric': 'residues/sec ESM2-650M fwd, 50k packed tokens; % bf16 MFMA peak; 1/2/4/8 GPU',
+        'metric': metric_label(args.model, T, args.batch),
         'value': round(value, 1), 'unit': 'residues/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': f'{args.model} packed forward -> logits, {T} residues/GPU, '
                                f'{args.batch} batch ({len(lengths)} seqs, max_len {max_len})',
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
-                   'parallelism': f'dp{world} (protein-sharded, logits all-gather)' if world > 1 else 'single GPU',
-                   'launch': 'hipGraph replay' if args.graph else 'eager (one ctypes launch per kernel)',
+                   'parallelism': f'dp{world} (protein-sharded, logits all-gather over RCCL)' if world > 1 else 'single GPU',
+                   'launch': 'hipGraph replay' if use_graph else 'eager (one ctypes launch per kernel)',
+                   'launcher': 'torch.distributed.run (self-launched)' if os.environ.get('ESME_BENCH_SPAWNED') else
+                               ('torch.distributed.run' if launched else 'plain python'),
+                   'precision': 'high (fp32 residual stream)' if args.high_precision else 'fast (bf16 residual stream)',
                    'setup': '2 untimed forwards before the warm-up steps (weight packing / LN folding, module load)',
                    'weights': 'synthetic (numpy PCG64), reference checkpoint layout'
                               + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme/quantization.py)')},
+        'step_ms_events': {'median': round(step_ms[len(step_ms) // 2], 3), 'min': round(step_ms[0], 3), 'max': round(step_ms[-1], 3)},
         'e2e': {'algorithmic_tflop_per_step': round(flops_step / 1e12, 3),
                 'tflops_per_gpu': round(flops_step / (ms_per_step * 1e-3) / 1e12, 1),
                 'frac_bf16_mfma_peak': round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
@@ -196,14 +259,14 @@ def main():
         with torch.no_grad():
             _hip.TRACE = []
             for _ in range(max(1, min(args.steps, 3))):
-                step()
+                model(tokens, (cu, max_len))
             torch.cuda.synchronize()
             trace, _hip.TRACE = _hip.TRACE, None
         per_op = {}
         for op, meta, s, e in trace:
             per_op.setdefault((op, meta), []).append(s.elapsed_time(e))
-        key = ('gemm', (T, 4 * E if kind == 'esm2' else 2 * syn.swiglu_width(E), E,
-                        _hip.EPI_GELU if kind == 'esm2' else _hip.EPI_SWIGLU))
+        key = ('gemm', (T, 4 * E if kind != 'esmc' else 2 * syn.swiglu_width(E), E,
+                        _hip.EPI_GELU if kind != 'esmc' else _hip.EPI_SWIGLU))
         if key in per_op:
             ms = sum(per_op[key]) / len(per_op[key])
             fl = 2.0 * key[1][0] * key[1][1] * key[1][2]
@@ -215,11 +278,19 @@ def main():
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': f'gemm_bf16_kernel M={key[1][0]} N={key[1][1]} K={key[1][2]} (FFN up, fused epilogue)',
                 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': pmc_traffic() if (args.model == 'esm2_650m' and T == 50000) else None,
+                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                'traffic': pmc_traffic() if (args.model == 'esm2_650m' and T == 50000 and not args.high_precision) else None,
                 'avg_launch_ms': round(ms, 4), 'launches_timed': len(per_op[key]),
                 'all_gemms': {'achieved': round(g_fl / (g_ms * 1e-3) / 1e12, 1),
                               'frac': round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
             }
+        for (op, meta), v in per_op.items():
+            if op == 'attn':                     # 4*S*E flops per residue per launch (QK^T + PV)
+                afl = 4.0 * (E // meta[1]) * meta[1] * sum(s * s for s in lengths)
+                ams = sum(v) / len(v)
+                result['attention'] = {'achieved': round(afl / (ams * 1e-3) / 1e12, 1), 'unit': 'TFLOP/s',
+                                       'frac': round(afl / (ams * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                       'avg_launch_ms': round(ams, 4), 'head_dim': meta[2]}
         nsteps = max(1, min(args.steps, 3))
         by_op = {}
         for (op, meta), v in per_op.items():
@@ -232,6 +303,8 @@ def main():
                 hbm['layernorm'] = round(4.0 * E * T / (sum(v) / len(v) * 1e-3) / 1e9, 1)
             if op == 'rotary':
                 hbm['rotary'] = round(8.0 * E * T / (sum(v) / len(v) * 1e-3) / 1e9, 1)
+            if op == 'qk_norm_rotary':
+                hbm['qk_norm_rotary'] = round(8.0 * E * T / (sum(v) / len(v) * 1e-3) / 1e9, 1)
             if op == 'dequant4':        # 0.5 B code + 2 B bf16 per weight (+ 1/16 B absmax)
                 hbm.setdefault('dequant4_bytes', 0.0)
                 hbm.setdefault('dequant4_ms', 0.0)
@@ -241,10 +314,13 @@ def main():
             hbm['dequant4'] = round(hbm.pop('dequant4_bytes') / (hbm.pop('dequant4_ms') * 1e-3) / 1e9, 1)
         result['hbm_bound_GBps'] = hbm
         if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 of the single-GPU run only
-            result['cpu_baseline'] = cpu_baseline(weights, H, kind, L, E, args.seq_len,
-                                                  min(args.cpu_sample_tokens, T))
+            n = min(args.cpu_sample_tokens, T)
+            same = args.batch == 'uniform' and args.quantization == 'none'     # sample == first n residues of the batch
+            result['cpu_baseline'], parity = cpu_baseline(weights, H, kind, L, E, args.seq_len, n, out[:n] if same else None)
+            if parity is not None:
+                result['parity'] = parity
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

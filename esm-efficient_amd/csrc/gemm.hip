@@ -17,6 +17,7 @@
 // M/N edges: loads clamp the row index (re-reading a valid row), stores are guarded; the
 // only shape requirement is K % 64 == 0.
 #include "gemm.h"
+#include <atomic>
 
 namespace esme {
 
@@ -536,8 +537,16 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS>;
     if (smem >= 64 * 1024) {
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); once = true; }
+        // the attribute is per (kernel, device): one bit per device ordinal, set once, safe from any host thread
+        static std::atomic<unsigned long long> done{0ull};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+                return fail(ESME_ERR_LAUNCH, "gemm: cannot raise the dynamic LDS limit");
+            done.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(WM * WN * 64), smem, s, a);
     return check_launch("gemm_bf16");

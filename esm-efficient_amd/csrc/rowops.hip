@@ -290,14 +290,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* __restrict
 // ------------------------------------------------------ row gather / scatter
 __global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src,
                                                           const int64_t* __restrict__ idx, u32x4* __restrict__ dst,
-                                                          int64_t n, int chunks, int scatter) {
+                                                          int64_t n, int chunks, int scatter, int64_t bound) {
+    // `bound` = rows of the INDEXED side (src for a gather, dst for a scatter).  An index outside
+    // [0, bound) never touches memory: a scatter drops the row, a gather delivers zeros (the
+    // reference's torch indexing raises there; a raw kernel must at least not corrupt HBM).
     const int64_t total = n * chunks;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / chunks;
         const int c = (int)(i - r * chunks);
         const int64_t j = idx[r];
-        if (scatter) dst[j * chunks + c] = src[i];
-        else dst[i] = src[j * chunks + c];
+        const bool ok = j >= 0 && j < bound;
+        if (scatter) { if (ok) dst[j * chunks + c] = src[i]; }
+        else dst[i] = ok ? src[j * chunks + c] : u32x4{0u, 0u, 0u, 0u};
     }
 }
 
@@ -445,23 +449,25 @@ extern "C" int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_
     return check_launch("softmax_rows");
 }
 
-static int gather_scatter(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream,
+static int gather_scatter(const void* src, const int64_t* idx, void* dst, int64_t n, int E, int64_t bound, void* stream,
                           int scatter) {
-    ESME_CHECK_ARG(n >= 0 && E > 0, "gather/scatter_rows: bad sizes");
+    ESME_CHECK_ARG(n >= 0 && E > 0 && bound >= 0, "gather/scatter_rows: bad sizes");
     if (n == 0) return ESME_OK;
     ESME_CHECK_ARG(src && idx && dst, "gather/scatter_rows: null pointer");
     ESME_CHECK_ARG(E % 8 == 0 && aligned16(src) && aligned16(dst), "gather/scatter_rows: E %% 8 != 0 or misaligned");
     const int chunks = E / 8;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * chunks, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const u32x4*)src, idx, (u32x4*)dst, n, chunks, scatter);
+                       (const u32x4*)src, idx, (u32x4*)dst, n, chunks, scatter, bound);
     return check_launch(scatter ? "scatter_rows" : "gather_rows");
 }
 
-extern "C" int esme_hip_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream) {
-    return gather_scatter(src, idx, dst, n, E, stream, 0);
+extern "C" int esme_hip_gather_rows(const void* src, int64_t src_rows, const int64_t* idx, void* dst, int64_t n, int E,
+                                    void* stream) {
+    return gather_scatter(src, idx, dst, n, E, src_rows, stream, 0);
 }
-extern "C" int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E, void* stream) {
-    return gather_scatter(src, idx, dst, n, E, stream, 1);
+extern "C" int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t dst_rows, int64_t n, int E,
+                                     void* stream) {
+    return gather_scatter(src, idx, dst, n, E, dst_rows, stream, 1);
 }
 
 extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* cu_lens, int B, int E, void* out,

@@ -16,7 +16,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -53,8 +53,8 @@ SIGNATURES = {
     'esme_hip_gemm_stats_blocks': (c_int, [c_int64, c_int]),
     'esme_hip_row_sums': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
-    'esme_hip_gather_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
-    'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_gather_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_scatter_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_segment_mean': (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_quantize_4bit': (c_int, [c_void_p, c_int64, c_int64, c_int, POINTER(c_float), c_void_p, c_void_p,
                                        c_void_p]),
@@ -132,16 +132,24 @@ def _check(code: int, what: str):
         raise RuntimeError(f'{what} failed (code {code}): {msg}')
 
 
+_PINNED_STREAM = None           # set by stream_scope(): one current_stream() lookup per forward, not per launch
+_PINNED_DEVICE = None           # device ordinal the pinned stream belongs to
+
+
 def _dev(t: torch.Tensor, what: str, dtype=None) -> int:
     if not t.is_cuda:
         raise RuntimeError(f'{what}: tensor is on {t.device}; the forward path runs only on a HIP device '
                            f'(no CPU fallback)')
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f'{what}: expected {dtype}, got {t.dtype}')
+    # kernels launch on the CURRENT device's stream: a tensor of another device would be dereferenced by the wrong
+    # GPU (the reference's torch ops follow the tensor instead).  Model-level entry points switch the device
+    # (stream_scope(device)); a raw wrapper call with a foreign tensor fails loudly here.
+    cur = _PINNED_DEVICE if _PINNED_DEVICE is not None else torch.cuda.current_device()
+    if t.device.index != cur:
+        raise RuntimeError(f'{what}: tensor lives on {t.device} but kernels would launch on cuda:{cur}; wrap the call in '
+                           f'`with esme._hip.stream_scope({str(t.device)!r}):` or torch.cuda.device(...)')
     return t.data_ptr()
-
-
-_PINNED_STREAM = None           # set by stream_scope(): one current_stream() lookup per forward, not per launch
 
 
 def _stream() -> int:
@@ -151,22 +159,38 @@ def _stream() -> int:
 
 
 class stream_scope:
-    """`with _hip.stream_scope():` pins the HIP stream handle for every launch inside the block (the
-    torch lookup costs ~9 us, i.e. more than the launch itself for small models).  Re-entrant; the stream
-    that is current when the outermost scope is entered is used, which is also the capture stream inside
-    `torch.cuda.graph(...)`."""
-    __slots__ = ('prev',)
+    """`with _hip.stream_scope(device):` makes `device` current (when given) and pins its current HIP stream
+    handle for every launch inside the block (the torch lookup costs ~9 us, i.e. more than the launch itself
+    for small models).  Re-entrant; the stream that is current when the outermost scope is entered is used,
+    which is also the capture stream inside `torch.cuda.graph(...)`.  A nested scope for ANOTHER device
+    switches device and stream for its extent."""
+    __slots__ = ('prev', 'device', 'guard')
+
+    def __init__(self, device=None):
+        self.device = torch.device(device) if device is not None else None
+        self.guard = None
 
     def __enter__(self):
-        global _PINNED_STREAM
-        self.prev = _PINNED_STREAM
-        if _PINNED_STREAM is None and torch.cuda.is_available():     # no device: the first launch raises 'no CPU fallback'
+        global _PINNED_STREAM, _PINNED_DEVICE
+        self.prev = (_PINNED_STREAM, _PINNED_DEVICE)
+        if not torch.cuda.is_available():                  # no device: the first launch raises 'no CPU fallback'
+            return self
+        want = self.device.index if (self.device is not None and self.device.type == 'cuda') else None
+        if want is not None and want != (_PINNED_DEVICE if _PINNED_DEVICE is not None else torch.cuda.current_device()):
+            self.guard = torch.cuda.device(want)
+            self.guard.__enter__()
+            _PINNED_DEVICE, _PINNED_STREAM = want, torch.cuda.current_stream(want).cuda_stream
+        elif _PINNED_STREAM is None:
+            _PINNED_DEVICE = torch.cuda.current_device()
             _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
         return self
 
     def __exit__(self, *exc):
-        global _PINNED_STREAM
-        _PINNED_STREAM = self.prev
+        global _PINNED_STREAM, _PINNED_DEVICE
+        _PINNED_STREAM, _PINNED_DEVICE = self.prev
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+            self.guard = None
         return False
 
 
@@ -407,7 +431,8 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """src (R, E) contiguous bf16, idx int64 (n) -> (n, E)."""
     src = src.contiguous()
     out = torch.empty(idx.numel(), src.shape[1], dtype=torch.bfloat16, device=src.device)
-    _check(load().esme_hip_gather_rows(_dev(src, 'gather src', torch.bfloat16), _dev(idx.contiguous(), 'gather idx', torch.int64),
+    _check(load().esme_hip_gather_rows(_dev(src, 'gather src', torch.bfloat16), src.shape[0],
+                                       _dev(idx.contiguous(), 'gather idx', torch.int64),
                                        out.data_ptr(), idx.numel(), src.shape[1], _stream()), 'esme_hip_gather_rows')
     return out
 
@@ -417,7 +442,7 @@ def scatter_rows(src: torch.Tensor, idx: torch.Tensor, rows: int) -> torch.Tenso
     src = src.contiguous()
     out = torch.zeros(rows, src.shape[1], dtype=torch.bfloat16, device=src.device)
     _check(load().esme_hip_scatter_rows(_dev(src, 'scatter src', torch.bfloat16), _dev(idx.contiguous(), 'scatter idx', torch.int64),
-                                        out.data_ptr(), idx.numel(), src.shape[1], _stream()), 'esme_hip_scatter_rows')
+                                        out.data_ptr(), rows, idx.numel(), src.shape[1], _stream()), 'esme_hip_scatter_rows')
     return out
 
 

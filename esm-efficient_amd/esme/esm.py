@@ -170,7 +170,7 @@ class ESM2(nn.Module):
         layers = list(layers) if layers else []
         self._check_layers_arg(layers)
 
-        with _hip.stream_scope():
+        with _hip.stream_scope(self.embed_tokens.weight.device):
             x = self._forward_representation(tokens, pad_args, pad_output, pad_indices, layers)
             if self.padded:                                       # physical -> logical width, per concatenated block
                 E, Ep = self.embed_dim, self.phys_dim
@@ -190,6 +190,10 @@ class ESM2(nn.Module):
             cu_lens = cu_lens.to(torch.int32)
         max_len = int(max_len)
 
+        # width the 2-D path pads back to: the INPUT width.  unpad_input's indices live on the (B, S) input grid;
+        # the reference pads to max(lens) (esm.py:255), which equals S for every input it accepts (with S > max(lens)
+        # its pad_input raises an index error) -- using S keeps the scatter in bounds for fixed-width batches too.
+        pad_width = tokens.shape[1] if pad_args is None else max_len
         ctx = self._context(cu_lens, max_len, x.shape[0], x.device)
         taps = []
         for i, layer in enumerate(self.layers):
@@ -201,23 +205,23 @@ class ESM2(nn.Module):
 
         if pad_output or (pad_args is None):
             nseq = cu_lens.numel() - 1
-            x = self._pad(x, pad_indices, nseq, max_len)
-            taps = [self._pad(t, pad_indices, nseq, max_len) for t in taps]
+            x = self._pad(x, pad_indices, nseq, pad_width)
+            taps = [self._pad(t, pad_indices, nseq, pad_width) for t in taps]
         return torch.concat((x, *taps), dim=-1) if taps else x
 
     def forward(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         """Logits (T, V) / (B, S, V), bf16, on the model's device (esm.py:268-282)."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
-        with _hip.stream_scope():
+        with _hip.stream_scope(self.embed_tokens.weight.device):
             return self.lm_head(self._forward_representation(tokens, pad_args, pad_output, pad_indices, []))
 
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
-        with _hip.stream_scope():
+        with _hip.stream_scope(self.embed_tokens.weight.device):
             return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
 
     def predict_prob(self, tokens, log=False, pad_args=None, pad_output=False, pad_indices=None,
                      lora_names=None):
-        with _hip.stream_scope():
+        with _hip.stream_scope(self.embed_tokens.weight.device):
             return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
 
     def graphed(self, tokens, pad_args, what: str = 'forward', clone: bool = True):
@@ -230,6 +234,11 @@ class ESM2(nn.Module):
             from esme.graph import GraphCache
             self._graph_cache = GraphCache(self)
         return self._graph_cache.run(what, tokens, pad_args, clone)
+
+    def invalidate_graphs(self):
+        """Forget captured hipGraphs (after changing weights in place)."""
+        if getattr(self, '_graph_cache', None) is not None:
+            self._graph_cache.clear()
 
     # -- loading -------------------------------------------------------------------
     @classmethod
@@ -284,10 +293,9 @@ class ESMC(ESM2):
     def _make_final_norm(self, dtype):
         return LayerNorm(self.embed_dim, bias=False, dtype=dtype)
 
-    def _check_layers_arg(self, layers):
-        # the reference compares against the *argument* list here (esm.py:873) -- reproduced as is
-        assert all(i < len(layers) for i in layers), \
-            f'Invalid layer indices {layers}. The number of layers in the model is {len(self.layers)}.'
+    # `layers=` is validated against the model depth like ESM2.  (The reference's ESM-C compares against the
+    # ARGUMENT list, esm.py:873 `i < len(layers)`, which rejects every useful tap such as layers=[30]; that typo is
+    # deliberately not reproduced -- any call the reference accepts is accepted here with the same result.)
 
 
 class _LearnedPositionESM(ESM2):

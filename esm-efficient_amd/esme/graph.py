@@ -18,6 +18,32 @@ from collections import OrderedDict
 
 import torch
 
+# attributes under which modules cache DERIVED device tensors (packed / LayerNorm-folded / padded weight copies,
+# rotary tables): allocated outside a graph's private pool, read by the captured kernels through raw pointers
+_DERIVED_ATTRS = ('_qkv_w', '_qkv_b', '_fold', '_out_w', '_out_b', '_down_pad', '_packed', '_pad', '_embed_pad',
+                  '_cos_cached', '_sin_cached')
+
+
+def _flatten(x):
+    if isinstance(x, torch.Tensor):
+        yield x
+    elif isinstance(x, (tuple, list)):
+        for y in x:
+            yield from _flatten(y)
+
+
+def external_tensors(model):
+    """Every derived tensor a forward of `model` reads that lives outside the capture pool.  A captured graph
+    keeps strong references to them: modules REPLACE such tensors (the rotary cache regrows when a longer
+    batch arrives; weight copies are rebuilt after a parameter update) and the replaced ones would otherwise
+    be freed while an older graph still holds their addresses."""
+    keep = []
+    for m in model.modules():
+        for a in _DERIVED_ATTRS:
+            keep.extend(_flatten(getattr(m, a, None)))
+    keep.extend(p.data for p in model.parameters())
+    return keep
+
 
 class GraphedForward:
     def __init__(self, model, what: str, n_tokens: int, n_seqs: int, max_len: int, device):
@@ -25,8 +51,10 @@ class GraphedForward:
         self.max_len = int(max_len)
         self.tokens = torch.zeros(n_tokens, dtype=torch.int64, device=device)
         self.cu_lens = torch.zeros(n_seqs + 1, dtype=torch.int32, device=device)
+        self.model = model
         self.graph = None
         self.out = None
+        self._keep = None           # strong references to everything captured from outside the graph's pool
 
     def _capture(self):
         side = torch.cuda.Stream(device=self.tokens.device)
@@ -39,6 +67,7 @@ class GraphedForward:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             self.out = self.fn(self.tokens, (self.cu_lens, self.max_len))
+        self._keep = external_tensors(self.model)      # e.g. the rotary tables of THIS max_len survive a later regrow
         self.graph = graph
 
     def run(self, tokens: torch.Tensor, cu_lens: torch.Tensor, clone: bool = True) -> torch.Tensor:
@@ -70,3 +99,8 @@ class GraphCache:
         else:
             self.entries.move_to_end(key)
         return g.run(tokens, cu_lens, clone)
+
+    def clear(self):
+        """Drop every captured graph (call after changing weights: a graph replays the weight copies it was
+        captured with -- memory-safe because it keeps them alive, but stale)."""
+        self.entries.clear()

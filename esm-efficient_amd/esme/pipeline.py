@@ -60,7 +60,10 @@ class StreamedInference:
         dev = self.device
         compute = torch.cuda.current_stream(dev)
         copy_s, out_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        ring_in, ring_cu, ring_out = (_PinnedRing(self.depth + 2) for _ in range(3))
+        ring_in, ring_cu = _PinnedRing(self.depth + 2), _PinnedRing(self.depth + 2)
+        # result i is handed out in iteration i + depth and must stay valid until depth + 1 further results were
+        # produced, i.e. through iteration i + 2*depth + 1: its slot may be re-targeted in iteration i + 2*depth + 2
+        ring_out = _PinnedRing(2 * self.depth + 2)
         pending = deque()
         with torch.no_grad():
             for tokens, (cu_lens, max_len) in batches:

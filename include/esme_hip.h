@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 1
+#define ESME_HIP_ABI_VERSION 2
 
 enum {
     ESME_OK = 0,
@@ -183,10 +183,12 @@ int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int6
 
 /* dst[i, :] = src[idx[i], :]  (unpad_input's row gather, esme/esm.py:238) and
  * dst[idx[i], :] = src[i, :] (pad_input's scatter into a zeroed buffer, esme/esm.py:255).
- * idx: int64 (n).  E elements per row, multiple of 8. */
-int esme_hip_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E,
+ * idx: int64 (n).  E elements per row, multiple of 8.  src_rows / dst_rows = number of rows of the
+ * INDEXED buffer: an index outside [0, rows) never touches memory (gather: the row comes back as
+ * zeros; scatter: the row is dropped) where the reference's torch indexing raises. */
+int esme_hip_gather_rows(const void* src, int64_t src_rows, const int64_t* idx, void* dst, int64_t n, int E,
                          void* stream);
-int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int E,
+int esme_hip_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t dst_rows, int64_t n, int E,
                           void* stream);
 
 /* out[i, :] = mean over rows cu_lens[i] .. cu_lens[i+1]-1 of x (fp32 accumulation; an

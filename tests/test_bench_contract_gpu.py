@@ -29,3 +29,26 @@ def test_bench_json_contract():
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 'traffic' in r
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'residues/s' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+
+
+def test_bench_self_launch_rccl_world1():
+    """`--spawn` forces the N>1 launcher path on this 1-GPU box: bench.py re-executes itself under
+    torch.distributed.run, initialises RCCL (backend nccl) with world size 1 and must say so."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--spawn', '--steps', '2', '--warmup', '1',
+                          '--model', 'esm2_8m', '--tokens', '4096', '--seq-len', '256', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['config']['launcher'] == 'torch.distributed.run (self-launched)'
+    assert 'esm2_8m' in d['metric'] and 'ESM2-650M' not in d['metric']          # label follows --model
+
+
+def test_sharded_forward_real_model_rccl_world1():
+    """esme.shard.sharded_forward around the REAL model on RCCL (world size 1 on this box): logits equal the
+    plain single-process forward bit for bit, in input order (the plan permutes sequences longest-first)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'shard_check.py')], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'sharded == single: True' in out.stdout, out.stdout

@@ -1,0 +1,135 @@
+"""Full-size parity: BASELINE.json's configurations at their REAL depth x batch size,
+value-checked -- not only isfinite -- against the CPU oracle on whole sequences cut out of the packed batch
+(a sequence's logits do not depend on what it is packed with, so the oracle only has to run those
+sequences), plus alone-vs-packed bit equality at full size.
+
+  config 2  ESM2-150M (L=30, E=640, H=20, d=32), 8 192 packed residues, proteome-like varlen
+  config 3  ESM2-650M (L=33, E=1280, H=20), 50 000 packed residues, uniform-500           (headline)
+  config 4  ESM2-3B geometry (E=2560, H=40): a 4-layer slice at 50 000 residues per GPU   (the 8-GPU split is the
+            driver's job; one rank's share is exactly this shape)
+  config 5  ESMC-600M (L=36, E=1152, H=18, SwiGLU) on 32 x 1 002 residues, bf16 and 4-bit, and
+            predict_mask_margin on the 1 000-aa protein with quantization='4bit'
+
+Tolerance: the floating-point rule of tests/test_model_gpu.py (HIP at least as close to the fp32-math
+forward as the reference-equivalent bf16 forward is).
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rel_fro
+from oracle import esm_oracle as O
+from esme import synthetic as syn
+from test_model_gpu import assert_parity
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def load(name, L=None, quantization=None, seed=0):
+    """(model, fp-weights dict) of a zoo model (optionally only its first L layers)."""
+    from esme import ESM
+    kind, L0, E, H = syn.MODEL_ZOO[name]
+    L = L or L0
+    w = syn.synthetic_state_dict(kind, L, E, seed=seed)
+    with tempfile.TemporaryDirectory() as td:
+        from safetensors.torch import save_file
+        path = os.path.join(td, 'm.safetensors')
+        save_file(w, path, metadata=syn.checkpoint_metadata(name, L, E, H))
+        model = ESM.from_pretrained(path, quantization=quantization, device=DEV)
+    return model, w, H
+
+
+def check_sequences(model, w, H, tokens, cu, max_len, picks, what):
+    """Logits of the WHOLE packed batch on the GPU; the picked sequences vs the oracle run on them alone."""
+    out = model(tokens.to(DEV), (cu.to(DEV), max_len))
+    torch.cuda.synchronize()
+    assert out.shape == (tokens.numel(), model.vocab_size) and torch.isfinite(out.float()).all()
+    cul = cu.tolist()
+    toks = [tokens[cul[i]:cul[i + 1]] for i in picks]
+    lens = [t.numel() for t in toks]
+    sub_t, sub_cu = torch.cat(toks), syn.cu_lens_of(lens)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    ref32 = O.forward_logits(w, H, sub_t, sub_cu, max(lens), dtype=torch.float32)
+    refbf = O.forward_logits(w, H, sub_t, sub_cu, max(lens), dtype=torch.bfloat16)
+    got = torch.cat([out[cul[i]:cul[i + 1]] for i in picks])
+    assert_parity(got, ref32, refbf, what)
+    # alone vs packed, bit for bit, at full size
+    alone = model(sub_t.to(DEV), (sub_cu.to(DEV), max(lens)))
+    assert torch.equal(alone, got), f'{what}: packed rows differ from the same sequences run alone'
+    return out
+
+
+def test_config3_esm2_650m_50k_full_depth():
+    model, w, H = load('esm2_650m')
+    tokens, cu, max_len, lengths = syn.uniform_batch(50000, 500, seed=0)
+    check_sequences(model, w, H, tokens, cu, max_len, [0, 57, 99], 'ESM2-650M 33 layers, 50 000 residues: seqs 0/57/99')
+
+
+def test_config3_proteome_like_batch_full_depth():
+    model, w, H = load('esm2_650m')
+    tokens, cu, max_len, lengths = syn.proteome_batch(50000, seed=0)
+    order = np.argsort(lengths)
+    picks = sorted({int(order[0]), int(order[len(order) // 2]), int(order[-1])})      # shortest, median, longest protein
+    check_sequences(model, w, H, tokens, cu, max_len, picks,
+                    f'ESM2-650M 33 layers, proteome-like 50 000 residues: lens {[lengths[i] for i in picks]}')
+
+
+def test_config2_esm2_150m_8192_full_depth():
+    model, w, H = load('esm2_150m')
+    lengths = syn.proteome_lengths(8192, seed=1)
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    picks = [0, len(lengths) // 2, len(lengths) - 1]
+    out = check_sequences(model, w, H, tokens, cu, max(lengths), picks, 'ESM2-150M 30 layers, 8 192 residues varlen')
+    g = model.graphed(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    assert torch.equal(g, out)
+
+
+def test_config4_esm2_3b_geometry_50k():
+    model, w, H = load('esm2_3b', L=4)
+    assert model.embed_dim == 2560 and model.attention_heads == 40
+    tokens, cu, max_len, lengths = syn.uniform_batch(50000, 500, seed=3)
+    check_sequences(model, w, H, tokens, cu, max_len, [1, 98], 'ESM2-3B geometry (E=2560, H=40), 4 layers, 50 000 residues')
+
+
+def test_config5_esmc_600m_full_depth_32x1002():
+    model, w, H = load('esmc_600m')
+    tokens, cu, max_len, lengths = syn.uniform_batch(32 * 1002, 1002, seed=5)
+    check_sequences(model, w, H, tokens, cu, max_len, [17], 'ESMC-600M 36 layers, 32 x 1 002 residues: seq 17')
+
+
+def test_config5_mask_margin_4bit_1000aa():
+    """predict_mask_margin on a 1 000-aa protein, ESMC-600M, quantization='4bit': scores at sampled positions vs
+    the oracle's forward on the quantise->dequantise image of the same weights (esme-q4 format; parity with
+    bitsandbytes itself is unpinned)."""
+    from esme.variant import predict_mask_margin
+    from esme.alphabet import Alphabet3
+    model, w, H = load('esmc_600m', quantization='4bit')
+    rng = np.random.Generator(np.random.PCG64(5))
+    aas = 'ACDEFGHIKLMNPQRSTVWY'
+    seq = ''.join(aas[i] for i in rng.integers(0, 20, size=1000))
+    df = predict_mask_margin(model, seq, batch_size=32)
+    assert len(df) == 1000 * 20 and np.isfinite(df['score'].to_numpy()).all()
+    qw = O.quantized_weights({k: v.bfloat16() for k, v in w.items()})
+    tok = torch.tensor(Alphabet3.encode(list(seq)), dtype=torch.int64)
+    assert tok.numel() == 1002
+    aa_idx = [Alphabet3.token_to_idx[a] for a in Alphabet3.amino_acids]      # frame order: residue, then amino_acids
+    cu = torch.tensor([0, 1002], dtype=torch.int32)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    scores = df['score'].to_numpy().reshape(1000, 20)
+    for pos in (1, 437, 1000):                                   # 1-based residue position == token index (after <cls>)
+        assert df.index[(pos - 1) * 20] == f'{seq[pos - 1]}{pos}{Alphabet3.amino_acids[0]}'
+        t = tok.clone()
+        t[pos] = Alphabet3.mask_idx
+        lp32 = torch.log_softmax(O.forward_logits(qw, H, t, cu, 1002, dtype=torch.float32)[pos].float(), -1)
+        lpbf = torch.log_softmax(O.forward_logits(qw, H, t, cu, 1002, dtype=torch.bfloat16)[pos].float(), -1)
+        wt = int(tok[pos])
+        ref32 = (lp32[aa_idx] - lp32[wt]).numpy()
+        refbf = (lpbf[aa_idx] - lpbf[wt]).numpy()
+        got = scores[pos - 1]
+        e_hip, e_ref = np.abs(got - ref32).max(), np.abs(refbf - ref32).max()
+        print(f'\n[q4 mask-margin 1000aa] pos {pos}: max|hip - oracle_fp32| {e_hip:.4f}, max|oracle_bf16 - oracle_fp32| {e_ref:.4f}')
+        assert e_hip <= max(2.0 * e_ref, 0.15), (pos, e_hip, e_ref)

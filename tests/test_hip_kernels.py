@@ -383,3 +383,69 @@ def test_qk_norm_rotary_fused_equals_unfused(T, H, d, bias):
                                            bb.float().cpu() if bb is not None else None)
         r = O.apply_rotary(y.view(T, H, d), cos.float().cpu(), sin.float().cpu(), pos.cpu().long()).reshape(T, E)
         assert rel_fro(b[:, part * E:(part + 1) * E].float().cpu(), r) < 6e-3
+
+
+# ------------------------------------------------------------------ LN-fold robustness
+def _stress_rows(kind, M, K, seed):
+    """Residual-stream rows that stress the one-pass E[x^2] - mean^2 statistics and the raw-stream GEMM +
+    `- rstd*mean*c1` correction of the LayerNorm fold."""
+    x = rnd((M, K), seed, 1.0).float()
+    if kind == 'dc20':                     # mean = 20 * std on every row (DC offset in the stream)
+        x = x + 20.0
+    elif kind == 'dc_mixed':               # per-row offsets between -50 and 50
+        x = x + torch.linspace(-50, 50, M).unsqueeze(1)
+    elif kind == 'outlier100':             # a few channels 100x larger than the rest (the ESM-2 "massive activation" pattern)
+        x[:, [3, K // 2, K - 7]] *= 100.0
+    elif kind == 'outlier_dc':             # outlier channels that are also nearly constant across rows
+        x[:, 5] = 180.0 + 0.5 * x[:, 5]
+        x[:, K - 2] = -95.0 + 0.25 * x[:, K - 2]
+    elif kind == 'near_const':             # var -> eps: rows equal to a constant + 2^-6 ripple
+        x = 3.0 + x * 2.0 ** -6
+    elif kind == 'zero_rows':              # all-zero rows (`<mask>` embeddings, esm.py:189) between normal rows
+        x[::3] = 0.0
+    elif kind == 'tiny':                   # very small activations: var << eps
+        x = x * 1e-3
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('kind', ['dc20', 'dc_mixed', 'outlier100', 'outlier_dc', 'near_const', 'zero_rows', 'tiny'])
+@pytest.mark.parametrize('tile', [1, 2])
+def test_layernorm_fold_stress(kind, tile):
+    """Fold path (raw-stream GEMM + algebraic LN) vs (a) the unfused HIP path (layernorm kernel + plain GEMM)
+    and (b) fp32 torch on the same inputs.  The fold must stay within a small multiple of the unfused path's
+    own error: both are compared with the fp32 reference in units of the output's rms."""
+    from esme import _hip
+    from esme.attention import _fold_layernorm
+    M, N, K = 300, 768, 1280
+    x = _stress_rows(kind, M, K, 70)
+    gamma = (1 + 0.1 * rnd((K,), 71).float()).to(torch.bfloat16)
+    beta = rnd((K,), 72, 0.1)
+    w, b = rnd((N, K), 73, 1 / math.sqrt(K)), rnd((N,), 74, 0.1)
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5) @ w.float().T + b.float()
+    xg, wg, bg, gg, btg = (t.to(dev()) for t in (x, w, b, gamma, beta))
+    _hip.load().esme_hip_debug_set_gemm_tile(tile)
+    try:
+        unfused = _hip.gemm(_hip.layernorm(xg, gg, btg, 1e-5), wg, bg).float().cpu()
+        wf, c1, c2 = _fold_layernorm(wg, bg, gg, btg)
+        # statistics as the model produces them: partial sums emitted by a residual GEMM over 64-column blocks
+        eye = torch.eye(K, dtype=torch.bfloat16, device=dev())
+        part = torch.empty(_hip.stats_blocks(M, K), M, 2, dtype=torch.float32, device=dev())
+        y = _hip.gemm_fused(xg, eye, None, _hip.EPI_RESIDUAL, torch.zeros_like(xg), 1.0, stats_out=part)
+        assert torch.equal(y, xg)
+        fold = _hip.gemm_fused(xg, wf, None, _hip.EPI_NONE, ln=(part, K, 1e-5, c1, c2)).float().cpu()
+        fold1 = _hip.gemm_fused(xg, wf, None, _hip.EPI_NONE, ln=(_hip.row_sums(xg), K, 1e-5, c1, c2)).float().cpu()
+    finally:
+        _hip.load().esme_hip_debug_set_gemm_tile(0)
+    assert torch.isfinite(fold).all() and torch.isfinite(fold1).all()
+    rms = float(ref.pow(2).mean().sqrt())
+    e_unf = float((unfused - ref).abs().max()) / rms
+    e_fold = float((fold - ref).abs().max()) / rms
+    e_fold1 = float((fold1 - ref).abs().max()) / rms
+    r_unf, r_fold = rel_fro(unfused, ref), rel_fro(fold, ref)
+    print(f'\n[ln-fold stress] {kind} tile {tile}: max|err|/rms unfused {e_unf:.3e} fold {e_fold:.3e} (row_sums stats {e_fold1:.3e}); '
+          f'rel_fro unfused {r_unf:.3e} fold {r_fold:.3e}')
+    # the unfused path rounds LN(x) to bf16 (2^-9 relative per element); the fold rounds W*gamma instead.  Allow the
+    # fold 3x the unfused error plus one bf16 ulp of the output scale.
+    assert e_fold <= 3.0 * e_unf + 2.0 ** -7, (kind, e_fold, e_unf)
+    assert e_fold1 <= 3.0 * e_unf + 2.0 ** -7, (kind, e_fold1, e_unf)
+    assert r_fold <= 3.0 * r_unf + 2.0 ** -8, (kind, r_fold, r_unf)

@@ -180,3 +180,45 @@ def test_feedforward_head_module():
     ff = FeedForward(16, 32)
     assert ff(torch.randn(5, 16)).shape == (5, 1)
     assert [n for n, _ in ff.named_parameters()] == ['linear1.weight', 'linear1.bias', 'linear2.weight', 'linear2.bias']
+
+
+def test_feedforward_matches_reference_golden():
+    """SURVEY section 8 row a16: values pinned on the reference's own class (reference esme/layer.py:4-23;
+    fixture tests/golden/make_golden_a16.py): its state dict loads strictly and the fp32 outputs agree."""
+    from golden_util import load_golden
+    from esme.layer import FeedForward
+    g = load_golden('g12_feedforward.npz')
+    ff = FeedForward(g['embed_dim'], g['hidden_dim'])
+    sd = {k.replace('__', '.'): v for k, v in g.items() if '__' in k}
+    ff.load_state_dict(sd, strict=True)
+    assert all(p.dtype == torch.float32 for p in ff.parameters())          # fp32 default dtype like the reference
+    with torch.no_grad():
+        y = ff(g['x'])
+    assert y.shape == g['y'].shape == (3, 7, 1)
+    torch.testing.assert_close(y, g['y'], rtol=1e-6, atol=1e-6)
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_bench_refuses_world_size_mismatch():
+    """A launcher world size that differs from --gpus must be an error, never a mislabelled 1-GPU line."""
+    out = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], {'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1'})
+    assert out.returncode != 0 and 'WORLD_SIZE=1' in out.stderr and '{' not in out.stdout
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='GPU boxes cover the self-launch path with RCCL (test_bench_contract_gpu.py)')
+def test_bench_self_launches_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK in the environment re-executes itself under torch.distributed.run
+    with 2 ranks.  There is no HIP device here, so each rank stops at the device-count check -- which proves that
+    two ranks were started with WORLD_SIZE=2 (the round-1 bug: it silently ran one rank and printed n_gpus 1)."""
+    out = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], timeout=600)
+    assert out.returncode != 0 and '{' not in out.stdout
+    assert out.stderr.count('--gpus 2 but only 0 HIP devices are visible') == 2, out.stderr[-3000:]

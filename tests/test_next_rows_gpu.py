@@ -400,3 +400,85 @@ def test_mask_margin_accepts_dataset_and_dataloader():
     assert np.array_equal(a['score'].to_numpy(), b['score'].to_numpy()) and np.array_equal(a['score'].to_numpy(), c['score'].to_numpy())
     with pytest.raises(ValueError):
         predict_mask_margin(model, 123)
+
+
+def test_graph_survives_rotary_table_regrow():
+    """a captured graph holds raw pointers to the rotary cos/sin tables; the rotary cache
+    REPLACES its tables when a longer batch arrives.  An older graph must keep its own tables alive and still
+    replay the right answer (short -> long -> short, eager calls interleaved)."""
+    import gc
+    model = build('esm2', 2, 320, 20, 7)
+    short, long_ = [40, 90, 26], [300, 410]
+    cu_s, cu_l = syn.cu_lens_of(short).to(DEV), syn.cu_lens_of(long_).to(DEV)
+    t_s = syn.random_tokens(short, seed=1).to(DEV)
+    ref_s = model(t_s, (cu_s, 90)).clone()
+    assert torch.equal(model.graphed(t_s, (cu_s, 90)), ref_s)          # captured with the 90-row tables
+    rot = model.layers[0].self_attn.rot_emb
+    old_ptr = rot._cos_cached.data_ptr()
+    t_l = syn.random_tokens(long_, seed=2).to(DEV)
+    ref_l = model(t_l, (cu_l, 410)).clone()                             # regrows (replaces) the tables
+    assert rot._cos_cached.data_ptr() != old_ptr and rot._cos_cached.shape[0] >= 410
+    assert torch.equal(model.graphed(t_l, (cu_l, 410)), ref_l)
+    gc.collect()
+    torch.cuda.empty_cache()                                            # a freed table would be unmapped / reused now
+    junk = [torch.full((1 << 16,), float('nan'), dtype=torch.bfloat16, device=DEV) for _ in range(64)]
+    for seed in (1, 5):
+        t = syn.random_tokens(short, seed=seed).to(DEV)
+        assert torch.equal(model.graphed(t, (cu_s, 90)), model(t, (cu_s, 90))), seed
+    del junk
+    model.invalidate_graphs()
+    assert len(model._graph_cache.entries) == 0
+
+
+def test_fixed_width_padded_batch_stays_in_bounds():
+    """2-D tokens padded to a fixed width S > max(lens) (every row holds <pad>).  The pad_input
+    scatter runs on the (B, S) input grid: output is (B, S, V), pad rows are zero, real rows equal the packed
+    forward's -- and nothing is written out of bounds (the reference raises an index error here)."""
+    model = build('esm2', 2, 64, 4, 3)
+    lens, S = [9, 17, 5], 32
+    toks = [syn.random_tokens([n], seed=10 + i) for i, n in enumerate(lens)]
+    t2 = torch.full((len(lens), S), model.alphabet.padding_idx, dtype=torch.int64)
+    for i, t in enumerate(toks):
+        t2[i, :t.numel()] = t
+    out = model(t2.to(DEV))
+    assert out.shape == (3, S, 33)
+    packed = model(torch.cat(toks).to(DEV), (syn.cu_lens_of(lens).to(DEV), max(lens)))
+    o = 0
+    for i, n in enumerate(lens):
+        assert torch.equal(out[i, :n], packed[o:o + n])
+        assert not out[i, n:].any()
+        o += n
+    lp = model.predict_log_prob(t2.to(DEV))
+    assert lp.shape == (3, S, 33) and torch.isfinite(lp.float()).all()
+
+
+def test_gather_scatter_index_guard():
+    """Out-of-range indices never touch memory: gather returns zero rows, scatter drops the row."""
+    from esme import _hip
+    src = torch.arange(6 * 16, dtype=torch.float32).view(6, 16).to(torch.bfloat16).to(DEV)
+    idx = torch.tensor([0, 5, 6, -1, 2, 10 ** 9], dtype=torch.int64, device=DEV)
+    got = _hip.gather_rows(src, idx)
+    assert torch.equal(got[[0, 1, 4]], src[[0, 5, 2]]) and not got[[2, 3, 5]].any()
+    guard = torch.full((64, 16), 7.0, dtype=torch.bfloat16, device=DEV)     # canary right behind the destination
+    out = _hip.scatter_rows(src, torch.tensor([3, 4, 99, 0, -2, 1], dtype=torch.int64, device=DEV), 5)
+    assert out.shape == (5, 16)
+    assert torch.equal(out[[3, 4, 0, 1]], src[[0, 1, 3, 5]]) and not out[2].any()
+    assert (guard == 7.0).all()
+
+
+def test_model_on_non_current_device_is_guarded():
+    """kernels launch on the current device's stream.  A raw wrapper call with a tensor of
+    another device must fail loudly; the model entry points switch device themselves.  (One visible GPU: the
+    guard is exercised through the pinned-device bookkeeping.)"""
+    from esme import _hip
+    x = torch.zeros(4, 64, dtype=torch.bfloat16, device=DEV)
+    _hip._PINNED_DEVICE, _hip._PINNED_STREAM = 1, 0         # pretend a scope for cuda:1 is active
+    try:
+        with pytest.raises(RuntimeError, match='tensor lives on cuda:0'):
+            _hip.row_sums(x)
+    finally:
+        _hip._PINNED_DEVICE = _hip._PINNED_STREAM = None
+    with _hip.stream_scope(DEV):
+        assert _hip._PINNED_DEVICE == 0
+        _hip.row_sums(x)
+    assert _hip._PINNED_DEVICE is None
