@@ -26,6 +26,9 @@
 // than 2^8), so the common tile does no O-wide VALU pass.
 #include "common.h"
 #include "launch.h"
+#include "gemm.h"
+#include <atomic>
+#include <type_traits>
 
 namespace esme {
 
@@ -38,6 +41,10 @@ struct AttnArgs {
     const int32_t* cu;
     int H;
     float scale_log2;            // softmax_scale * log2(e)
+    int nqt;                     // ping-pong kernel: query tiles per sequence
+    int nhb;                     // ping-pong kernel: H * B (sequence, head) pairs
+    float thr;                   // defer-max threshold in log2 units (0 = rescale whenever a row max grows)
+    int spec;                    // ping-pong kernel: speculative softmax after a row's first key tile (see the kernel header)
 };
 
 // swizzle of the 16-byte chunk index inside a K-tile row of D bf16 (CPR chunks per row)
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     constexpr int VI = (16 * DQ + 255) / 256;    // 4x4 V blocks per thread
     constexpr int K_BYTES = KT * D * 2;
     constexpr int BUF = K_BYTES + D * 128;       // one K tile + one V^T tile
-    constexpr float THR = 8.0f;                  // defer-max threshold (log2 units)
+    const float THR = a.thr;                     // defer-max threshold (log2 units)
 
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
@@ -313,12 +320,405 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     }
 }
 
+
+// =============================================================================================
+// Head dim 64: software-pipelined ("ping-pong") kernel.
+//
+// Same math, LDS images and MFMA operand layouts as attn_varlen_kernel above; what changes is the
+// schedule and the amount of VALU work per score (the first-generation kernel is VALU-bound: ~210
+// vector instructions per 32 x 64 block of scores against 16 MFMAs).
+//
+// * A wave owns TWO 32-row query blocks b0, b1 and runs them half a key tile out of phase, so that every
+//   softmax has the 16 MFMAs of the OTHER block issued between its instructions (one MFMA + one LDS
+//   fragment read per 7 VALU instructions, prescribed with sched_group_barrier):
+//
+//     phase A(t):  softmax(b0, tile t)   ||   S^T(b1, t)   = K_t     Q_b1^T       (8 MFMA)
+//                                             O^T(b1)     += V_t-1^T P(b1, t-1)^T  (8 MFMA)
+//     phase B(t):  softmax(b1, tile t)   ||   S^T(b0, t+1) = K_t+1   Q_b0^T       (8 MFMA)
+//                                             O^T(b0)     += V_t^T   P(b0, t)^T    (8 MFMA)
+//
+// * Speculative softmax (spec = 1): after a row's first key tile fixed its reference maximum m, later
+//   tiles compute P = exp2(s*c - m) WITHOUT looking for the tile maximum (16 v_max3 + exchange + compare
+//   per block) -- fp32 / bf16 hold P up to 2^127, the bf16 rounding of P is relative, O and l accumulate
+//   in fp32, so any finite P is as accurate as a P <= 1.  Only overflow must be caught: a row sum that is
+//   not < 1e30 (inf / NaN included) sends the wave through the exact path for that tile (true tile
+//   maximum, rescale of O and l, P recomputed from the still-intact scores).  spec = 0 is the classic
+//   online softmax with the defer-max threshold `thr` (thr = 0: a row's maximum is always exact).
+// * The last, partial key tile has its own instantiation of the phase (hipcc if-converts a run-time
+//   `if (tail)` mask into 63 selects executed on EVERY tile).
+// * K / V tiles are fetched with raw buffer loads whose descriptor ends at the sequence's last row: rows
+//   past the end read as zeros by hardware bounds checking, no per-load clamping or 64-bit address math.
+//
+// LDS: a ring of 4 slots (K tile + V^T tile, 16 KB each); iteration t reads slots t-1, t, t+1 and fills
+// slot t+2 from registers loaded one iteration earlier, ONE barrier per key tile.  A workgroup is NW
+// waves = NW*64 query rows of one (sequence, head): NW = 8 covers a 500-residue protein in one workgroup
+// (K/V staged and fetched once), NW = 4 runs two workgroups per CU.  The row sum exchange with lane^32 is
+// a v_permlane32_swap (VALU), not an LDS permute; results leave through a wave-private LDS slab as whole
+// 128-byte rows (16 B per lane).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
+    constexpr int D = 64, DS = 4, NT = NW * 64;
+    constexpr int K_BYTES = KT * D * 2;          // 8 KB
+    constexpr int SLOT = K_BYTES + D * 128;      // K tile [64 keys][64] + V^T tile [64][64 keys]
+    constexpr int ROWS = NW * 64;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    // block id -> work item.  Block i runs on XCD i % 8 (observed dispatch policy; speed only): the nqt query tiles
+    // of one (sequence, head) get ids 8 apart -- neighbours in ONE XCD's queue, so the second tile finds K / V in
+    // that XCD's L2 -- while consecutive (sequence, head) pairs go round-robin over the XCDs, which balances ragged
+    // batches (a contiguous id range per XCD put a whole 2 300-residue protein on one XCD: 1.5x slower).
+    const unsigned int xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3;
+    const int qt = (int)(bi % (unsigned int)a.nqt);
+    const unsigned int hb = (bi / (unsigned int)a.nqt) * 8u + xcd;
+    if (hb >= (unsigned int)a.nhb) return;
+    const int h = (int)(hb % (unsigned int)a.H), b = (int)(hb / (unsigned int)a.H);
+    const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
+    const int q0 = qt * ROWS;
+    if (q0 >= S) return;
+
+    const unsigned int ld = (unsigned int)a.ld;
+    const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
+    // K / V of this (sequence, head) behind buffer descriptors that end with the head's slice of row S-1
+    const unsigned int kv_bytes = ((unsigned int)(S - 1) * ld + D) * 2u;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.k + (int64_t)s0 * a.ld + h * D), 0, (int)kv_bytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.v + (int64_t)s0 * a.ld + h * D), 0, (int)kv_bytes, 0x00020000);
+
+    // ---- Q fragments of the wave's two q-blocks (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 ..]
+    bf16x8 qf[2][DS];
+    const int wrow0 = q0 + wave * 64;                      // first query row of this wave
+    const bool wave_active = wrow0 < S;                    // wave-uniform
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int qr = wrow0 + bb * 32 + l31;
+        const unsigned int qc = qr < S ? qr : S - 1;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds)
+            qf[bb][ds] = *reinterpret_cast<const bf16x8*>(qb + (qc * ld + ds * 16 + hi * 8));
+    }
+
+    // ---- staging.  K tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, 1 KB = 8 rows per wave
+    // instruction, no VGPR round trip, no ds_write): the LDS image is lane-linear, so the chunk swizzle is applied to the
+    // per-lane SOURCE address; rows past the sequence end read as zeros (descriptor bounds).  V tiles go through
+    // registers (threads 0..255: one 4x4 block each, transposed with v_perm into the V^T image).
+    constexpr int KI = 8 / NW;                                   // K DMA instructions per wave per tile (2 or 1)
+    const unsigned int tile_bytes = (unsigned int)KT * ld * 2u;
+    unsigned int kg0;                                            // byte offset of this lane's K chunk inside a tile (piece 0)
+    {
+        const int r = wave * 8 + (lane >> 3), pch = lane & 7;    // LDS row / chunk position this lane fills
+        kg0 = ((unsigned int)r * ld + ((pch ^ kswz<D>(r)) * 8)) * 2u;
+    }
+    const unsigned int kg_step = (unsigned int)(NW * 8) * ld * 2u;   // piece i: rows + NW*8 (same swizzle: NW*8 is a multiple of 16)
+    auto dma_k = [&](int tile, char* slot) {
+        const unsigned int base = (unsigned int)tile * tile_bytes + kg0;
+#pragma unroll
+        for (int i = 0; i < KI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(slot + (i * NW + wave) * 1024), 16, base + i * kg_step, 0, 0, 0);
+    };
+    const bool do_v = wave < 4;                                  // wave-uniform
+    const int vrest = (lane >> 4) | ((wave & 3) << 2);
+    const int v_dq = (lane & 3) | ((vrest & 3) << 2);           // 4-wide column group of V (0..15)
+    const int v_kq = ((lane >> 2) & 3) | ((vrest >> 2) << 2);   // 4-key group (0..15)
+    const unsigned int vg0 = ((unsigned int)(v_kq * 4) * ld + v_dq * 4) * 2u, vg_step = ld * 2u;
+    const int v_ch = v_kq >> 1, v_sub = (v_kq & 1) * 8;
+    // the four transposed V^T rows of a 4x4 block sit at vl0, vl0 + 128, vl1, vl1 + 128
+    const int vl0 = K_BYTES + (v_dq * 4) * 128 + ((v_ch ^ ((v_dq * 2) & 7)) << 4) + v_sub;
+    const int vl1 = K_BYTES + (v_dq * 4 + 2) * 128 + ((v_ch ^ ((v_dq * 2 + 1) & 7)) << 4) + v_sub;
+    struct Stage { u32x2 v[4]; };
+    auto load_v = [&](Stage& st, int tile) {
+        if (do_v) {
+            const unsigned int base = (unsigned int)tile * tile_bytes + vg0;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) st.v[kk] = __builtin_amdgcn_raw_buffer_load_b64(vrs, base + kk * vg_step, 0, 0);
+        }
+    };
+    auto store_v = [&](const Stage& st, char* slot) {
+        if (do_v) {
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {               // 4x4 transpose of 16-bit elements
+                const int w = dd >> 1;
+                const unsigned int sel = (dd & 1) ? 0x07060302u : 0x05040100u;
+                u32x2 out = {__builtin_amdgcn_perm(st.v[1][w], st.v[0][w], sel), __builtin_amdgcn_perm(st.v[3][w], st.v[2][w], sel)};
+                *reinterpret_cast<u32x2*>(slot + ((dd & 2) ? vl1 : vl0) + (dd & 1) * 128) = out;
+            }
+        }
+    };
+
+    // ---- per-lane LDS fragment offsets.  K row fed to MFMA row i: bits 2 and 3 of i swapped (P lands in the
+    // B-operand layout of the second MFMA); the chunk swizzles do not depend on the 32-row block.
+    const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
+    int kfo[4], vfo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        kfo[i] = krow_perm * 128 + (((i * 2 + hi) ^ ((krow_perm >> 1) & 7)) << 4);
+        vfo[i] = K_BYTES + l31 * 128 + (((i * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+    }
+
+    f32x16 oacc[2][2], sacc[2][2];
+    u32x4 pw[2][2][2];                 // P of block bb as packed bf16: [bb][32-key block][16-key step]
+    float mc[2], lrun[2];
+    const float c = a.scale_log2, thr = a.thr;
+    int ovf = 0;                       // a speculative softmax of this wave overflowed
+
+    // the 16 MFMAs a phase issues for block bm: m < 8: O^T(bm) += V^T P^T; m >= 8: S^T(bm) against the K tile at Ks.
+    // O^T first: P(bm) dies half-way through the phase, and the new scores of bm are first written when the first half of
+    // block bs's old scores has been consumed (their registers can be reused; the loop is register-bound).
+    // Consecutive MFMAs alternate between the two accumulators of a contraction (32-row blocks of O^T, 32-key blocks of
+    // S^T): an MFMA never follows one on the same accumulator with VALU instructions in between (a 43-cycle cliff).
+    auto frag = [&](int m, const char* Ks, const char* Vs) -> bf16x8 {
+        if (m < 8) return *reinterpret_cast<const bf16x8*>(Vs + (m & 1) * 4096 + vfo[m >> 1]);
+        return *reinterpret_cast<const bf16x8*>(Ks + (m & 1) * 4096 + kfo[(m - 8) >> 1]);
+    };
+
+    // One phase: softmax of block BS on its finished scores, interleaved with the 16 MFMAs of block BM.
+    // SPEC: speculative softmax (no tile maximum; see the header).  TAIL: mask the keys past the sequence end.
+    auto phase = [&](auto BS_, auto BM_, const bool need_max, const bool tail, const char* Ks, const char* Vs, const int kv0) __attribute__((always_inline)) {
+        constexpr int bs = decltype(BS_)::value, bm = decltype(BM_)::value;
+        bf16x8 fr[3];
+        fr[0] = frag(0, Ks, Vs);
+        fr[1] = frag(1, Ks, Vs);
+        auto mfma_step = [&](int m) {
+            if (m + 2 < 16) fr[(m + 2) % 3] = frag(m + 2, Ks, Vs);
+            if (m >= 8) {
+                const int j = m - 8, kbk = j & 1, ds = j >> 1;
+                if (ds == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    sacc[bm][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % 3], qf[bm][ds], z, 0, 0, 0);
+                } else {
+                    sacc[bm][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % 3], qf[bm][ds], sacc[bm][kbk], 0, 0, 0);
+                }
+            } else {
+                const int db = m & 1, ks = m >> 1;
+                oacc[bm][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    fr[m % 3], __builtin_bit_cast(bf16x8, pw[bm][ks >> 1][ks & 1]), oacc[bm][db], 0, 0, 0);
+            }
+        };
+        // P, packed to bf16, and four partial row sums of block bs against the reference maximum -nm.  Pair p covers
+        // scores (kbk, r), (kbk, r + 1); the empty asm pins the pair's instructions where they are written (between two
+        // MFMAs): hipcc otherwise sinks the softmax below the last MFMA of the phase, next to its consumers.
+        float ps0, ps1, ps2, ps3;
+        auto exp_pair = [&](const int p, const float nm) {
+            const int kbk = p >> 3, r = (2 * p) & 15;
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[bs][kbk][r], c, nm));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[bs][kbk][r + 1], c, nm));
+            pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack_bf16(p0, p1);
+            if (p & 1) { ps2 += p0; ps3 += p1; asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps2), "+v"(ps3)); }
+            else { ps0 += p0; ps1 += p1; asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps0), "+v"(ps1)); }
+        };
+        // exact tile maximum of block bs's rows (both key halves), in log2 units
+        auto tile_max = [&]() -> float {
+            float tmax = sacc[bs][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[bs][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[bs][1][r]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c;
+        };
+        auto rescale_to = [&](const float tmc) {           // raise the reference maximum to cover tmc; rescale O and l
+            const float mn = fmaxf(mc[bs], tmc);
+            const float alpha = __builtin_amdgcn_exp2f(mc[bs] - mn);
+            mc[bs] = mn;
+            lrun[bs] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[bs][i][r] *= alpha;
+        };
+        if (tail) {                         // last tile of a sequence whose length is not a multiple of 64
+            // register r of 32-key block kbk holds key kv0 + kbk*32 + 16*(r>>3) + 8*hi + (r&7): valid below `lim`.
+            // `lim` passes through an empty asm INSIDE the branch: hipcc otherwise hoists the 32 compares (and
+            // if-converts half of the selects) into the code that runs on every tile.
+            int lim = S - kv0 - 8 * hi;
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbk * 32 + 16 * (r >> 3) + (r & 7) >= lim) sacc[bs][kbk][r] = -1e30f;
+        }
+        // Exact reference maximum: on a row's first key tile, and on every tile in exact mode.  A wave-uniform branch
+        // outside the pipelined region (the speculative steady state skips it).
+        if (need_max) {
+            asm volatile("" ::: "memory");                   // keep it a branch (no if-conversion into the hot path)
+            const float tmc = tile_max();
+            if (__any(tmc > mc[bs] + thr)) rescale_to(tmc);  // thr = 0: the maximum is always exact
+        }
+        // 16 x { 1 MFMA (+ the LDS read of the fragment two MFMAs ahead), one pair of scores: 7 VALU }
+        ps0 = ps1 = ps2 = ps3 = 0.f;
+        const float nm = -mc[bs];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            mfma_step(m);
+            __builtin_amdgcn_sched_barrier(0);
+            exp_pair(m, nm);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float psum = (ps0 + ps1) + (ps2 + ps3);
+        if (__any(!(psum < 1e30f))) ovf = 1;                 // overflow (inf / NaN included): the work item is redone exactly
+        lrun[bs] += psum;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // The pass over the key tiles.  It is a loop body so that a workgroup whose speculative pass overflowed (a later key
+    // beat a row's first-tile maximum by more than ~2^100, or the scores hold inf / NaN) can redo its work item with the
+    // classic online softmax: never taken on real data, but it makes the speculative pass exact, not "fine in practice".
+    const int nt = (S + KT - 1) / KT;
+    bool exact = !a.spec;
+    for (;;) {
+        // ---- prologue: K tiles 0..2 by LDS-DMA, V tiles 0, 1 through registers (both fetched at once), V tile 2 into the
+        // staging registers, V^T of slot 3 zeroed (phase A of iteration 0 multiplies it by P = 0: no NaN / Inf patterns)
+        Stage st;
+    #pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            mc[bb] = -1e30f; lrun[bb] = 0.f;
+    #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[bb][i][r] = 0.f; sacc[bb][i][r] = 0.f; }
+    #pragma unroll
+                for (int s = 0; s < 2; ++s) pw[bb][i][s] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        {
+            Stage st1;
+            load_v(st, 0);
+            if (nt > 1) load_v(st1, 1);
+            dma_k(0, smem);
+            if (nt > 1) dma_k(1, smem + SLOT);
+            if (nt > 2) dma_k(2, smem + 2 * SLOT);
+            store_v(st, smem);
+            if (nt > 1) store_v(st1, smem + SLOT);
+        }
+        // The Q fragments are re-defined by an (empty) asm statement here, while no other load is in flight: hipcc's
+        // wait-count pass otherwise carries "the Q loads may still be pending" into the loop header and guards their
+        // first uses with s_waitcnt vmcnt(3..0) -- which, in steady state, drains the staging loads issued at the top of
+        // the same iteration (an HBM latency per key tile; the kernel ran 1.7x slower on long sequences).
+        asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]),
+                          "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]) : : "memory");
+        if (nt > 2) load_v(st, 2);
+        {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            char* v3 = smem + 3 * SLOT + K_BYTES;
+    #pragma unroll
+            for (int i = 0; i < (D * 128) / (NT * 16); ++i) *reinterpret_cast<u32x4*>(v3 + (i * NT + tid) * 16) = z;
+        }
+        __syncthreads();
+        if (wave_active) {                      // S^T(b0, tile 0)
+    #pragma unroll
+            for (int ds = 0; ds < DS; ++ds)
+    #pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kbk * 4096 + kfo[ds]);
+                    sacc[0][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ds], sacc[0][kbk], 0, 0, 0);
+                }
+        }
+        const bool ragged = (S & (KT - 1)) != 0;
+        // One key tile per iteration: phase A: softmax(b0,t) || S^T(b1,t), O^T(b1) += V(t-1) P(b1,t-1);
+        // phase B: softmax(b1,t) || S^T(b0,t+1), O^T(b0) += V(t) P(b0,t).  The loop holds ONE instantiation of the phase
+        // pair (several variants in branches of the loop make the register allocator spill ~150 VGPRs).
+        auto stage_next = [&](int t) {
+            // iteration t: V tile t+2 (registers, loaded an iteration ago) -> its slot; fetch V tile t+3 and start the
+            // LDS-DMA of K tile t+3 into its slot (K region of slot t-1: last read in phase A of iteration t-1).  The barrier
+            // that ends the iteration also waits for both (they had the whole iteration to land).
+            if (t + 2 < nt) {
+                store_v(st, smem + ((t + 2) & 3) * SLOT);
+                if (t + 3 < nt) { load_v(st, t + 3); dma_k(t + 3, smem + ((t + 3) & 3) * SLOT); }
+            }
+        };
+        for (int t = 0; t < nt; ++t) {
+            stage_next(t);
+            if (wave_active) {
+                const char* cur = smem + (t & 3) * SLOT;
+                const char* prv = smem + ((t + 3) & 3) * SLOT;
+                const char* nxt = smem + ((t + 1) & 3) * SLOT;
+                const bool tail = t == nt - 1 && ragged;
+                const bool need_max = exact || t == 0;
+                phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT);
+                phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT);
+            }
+            __syncthreads();
+        }
+        if (wave_active) {                          // drain: O^T(b1) += V(nt-1) P(b1, nt-1)
+            const char* Vs = smem + ((nt - 1) & 3) * SLOT;
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+    #pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + db * 4096 + vfo[ks]);
+                    oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks >> 1][ks & 1]),
+                                                                          oacc[1][db], 0, 0, 0);
+                }
+        }
+        if (exact || !__syncthreads_or(ovf)) break;
+        exact = true;
+        ovf = 0;
+    }
+    if (!wave_active) return;
+
+    // ---- epilogue: normalise, transpose through a wave-private LDS slab (a slot no wave reads any more: every
+    // wave passed the loop's last barrier, only V of tile nt-1 is still in use), store whole 128-B rows
+    char* slab = smem + ((nt + (wave >> 2)) & 3) * SLOT + (wave & 3) * 4096;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
+        const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+        if (bb) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk = {pack_bf16(oacc[bb][db][4 * g] * inv, oacc[bb][db][4 * g + 1] * inv),
+                            pack_bf16(oacc[bb][db][4 * g + 2] * inv, oacc[bb][db][4 * g + 3] * inv)};
+                *reinterpret_cast<u32x2*>(slab + l31 * 128 + (((db * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int rbase = wrow0 + bb * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * 128 + ((ch ^ (r & 7)) << 4));
+            if (rbase + r < S) *reinterpret_cast<u32x4*>(a.o + (int64_t)(s0 + rbase + r) * a.ldo + h * D + ch * 8) = v;
+        }
+    }
+}
+
 }  // namespace esme
 
 using namespace esme;
 
 static int g_force_qb = 0;      // test hook: force q-blocks per wave (0 = heuristic)
 extern "C" void esme_hip_debug_set_attn_qb(int v) { g_force_qb = v; }
+static int g_attn_variant = 0;  // test / tuning hook: 0 = heuristic, 1 = first-generation kernel, 4 / 8 = ping-pong with 4 / 8 waves
+extern "C" void esme_hip_debug_set_attn_variant(int v) { g_attn_variant = v; }
+static float g_attn_thr = 8.0f; // defer-max threshold, log2 units
+extern "C" void esme_hip_debug_set_attn_thr(float v) { g_attn_thr = v; }
+static int g_attn_spec = 1;     // speculative softmax in the ping-pong kernel
+extern "C" void esme_hip_debug_set_attn_spec(int v) { g_attn_spec = v; }
+
+template <int NW>
+static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
+    constexpr int smem = 4 * (KT * 64 * 2 + 64 * 128);
+    auto kern = attn_pp64_kernel<NW>;
+    static std::atomic<unsigned long long> done{0ull};         // dynamic-LDS attribute: per (kernel, device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return fail(ESME_ERR_LAUNCH, "attn: cannot raise the dynamic LDS limit");
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    a.nqt = (max_len + NW * 64 - 1) / (NW * 64);
+    const int64_t blocks = (int64_t)a.nqt * (((int64_t)a.H * B + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "attn: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(NW * 64), smem, s, a);
+    return check_launch("attn_varlen_fwd");
+}
 
 extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
                                         int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
@@ -332,14 +732,21 @@ extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void
                    "attn: misaligned");
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
-               softmax_scale * 1.4426950408889634f};
+               softmax_scale * 1.4426950408889634f, 1, H * B, g_attn_thr, g_attn_spec};
+    const hipStream_t s = (hipStream_t)stream;
+    if (d == 64 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o)) {
+        // head dim 64 (ESM2-650M / 3B, ESM-C): the software-pipelined kernel.  4 waves = 256 query rows per workgroup, two
+        // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
+        // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
+        const int nw = g_attn_variant == 8 ? 8 : 4;
+        return nw == 8 ? launch_pp64<8>(a, B, max_len, s) : launch_pp64<4>(a, B, max_len, s);
+    }
     // two 32-row q-blocks per wave when the longest sequence fills at least one 256-row tile
     // (head dim 128 keeps one: its accumulators alone take 128 VGPRs per q-block)
     const int qb = (g_force_qb ? g_force_qb : (max_len >= 192 ? 2 : 1));
     const bool two = qb == 2 && d <= 64;
     const int rows = QT * (two ? 2 : 1);
     const dim3 grid((unsigned int)((max_len + rows - 1) / rows), (unsigned int)H, (unsigned int)B), block(256);
-    const hipStream_t s = (hipStream_t)stream;
 #define ESME_ATTN(DD)                                                                         \
     case DD:                                                                                   \
         if (two) hipLaunchKernelGGL((attn_varlen_kernel<DD, (DD <= 64 ? 2 : 1)>), grid, block, 0, s, a); \

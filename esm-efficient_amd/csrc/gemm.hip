@@ -196,21 +196,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         if (tid < BM) {
             int64_t m = m0 + tid;
             m = m < a.M ? m : a.M - 1;
+            // Canonical order: the producers emit one partial per 64 columns whatever their tile size, and the
+            // partials are added strictly left to right, so a row's statistics (hence its logits) do not depend on the
+            // tile configuration, i.e. on how many rows the batch has.  Loads are batched (independent), adds are not.
             float s1 = 0.f, s2 = 0.f;
             const f32x2* pp = reinterpret_cast<const f32x2*>(a.ln_partial) + m;
             int b = 0;
-            for (; b + 10 <= a.ln_nblk; b += 10) {            // 10 independent loads in flight, not a serial latency chain
+            for (; b + 10 <= a.ln_nblk; b += 10) {
                 f32x2 p[10];
 #pragma unroll
                 for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.M];
 #pragma unroll
                 for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
-            }
-            for (; b + 4 <= a.ln_nblk; b += 4) {
-                const f32x2 p0 = pp[(int64_t)b * a.M], p1 = pp[(int64_t)(b + 1) * a.M];
-                const f32x2 p2 = pp[(int64_t)(b + 2) * a.M], p3 = pp[(int64_t)(b + 3) * a.M];
-                s1 += (p0[0] + p1[0]) + (p2[0] + p3[0]);
-                s2 += (p0[1] + p1[1]) + (p2[1] + p3[1]);
             }
             for (; b < a.ln_nblk; ++b) {
                 const f32x2 p = pp[(int64_t)b * a.M];
@@ -439,7 +436,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
         const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
-        f32x2* blkst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);      // STATS: [wn][tile row] partial sums
         if (col_ok || STATS) {
 #pragma unroll
             for (int it = 0; it < WTM / RPI; ++it) {
@@ -450,8 +446,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
-                    // (two quad_perm DPP steps + row_half_mirror), the 4 column waves of the block
-                    // combine through a small LDS strip below.
+                    // (two quad_perm DPP steps + row_half_mirror).
                     float f[8];
                     unpack8(v, f);
                     float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
@@ -460,20 +455,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);      // lane ^ 1
                     t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);      // lane ^ 2
                     t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);    // lane -> 7 - lane (other quad)
-                    if (ch == 0) blkst[wn * BM + wm * WTM + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
+                    // one partial per (64-column block, row), written by the block's wave itself: the layout
+                    // (N/64, M, 2) is the same for every tile configuration (see the consumer's canonical sum)
+                    if (ch == 0 && m < a.M && nw0 < a.N)
+                        *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(nw0 >> 6) * a.M + m)) = f32x2{t1, t2};
                 }
             }
         }
         ESME_TRACE_MARK(6);
-        if constexpr (STATS) {
-            __syncthreads();
-            if (tid < BM && m0 + tid < a.M) {
-                f32x2 acc2 = blkst[tid];
-#pragma unroll
-                for (int w = 1; w < WN; ++w) { const f32x2 p = blkst[w * BM + tid]; acc2[0] += p[0]; acc2[1] += p[1]; }
-                *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(n0 / BN) * a.M + m0 + tid)) = acc2;
-            }
-        }
         ESME_TRACE_MARK(7);
         ESME_TRACE_REAL(9);
         return;
@@ -531,7 +520,7 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
+    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0);
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
@@ -595,8 +584,8 @@ static int pick_tile(int64_t M, int N) {
 }
 
 extern "C" int esme_hip_gemm_stats_blocks(int64_t M, int N) {
-    const int bn = pick_tile(M, N) == 2 ? 256 : 128;
-    return (N + bn - 1) / bn;
+    (void)M;                         // one partial per 64 output columns, whatever tile the launch picks
+    return (N + 63) / 64;
 }
 
 extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,

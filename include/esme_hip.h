@@ -143,10 +143,13 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              {sum, sum of squares} as emitted by stats_out / esme_hip_row_sums (ln_nblk = 1).
  *              Replaces the nn.LayerNorm in front of q/k/v (esme/attention.py:75,92) and of the FFN
  *              (esme/attention.py:222,230) without writing or reading a normalised copy of x;
- *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per column tile of the launch, the sum
+ *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per block of 64 output columns, the sum
  *              and sum of squares of the bf16-ROUNDED output, float (nblk, M, 2) with
- *              nblk = esme_hip_gemm_stats_blocks(M, N): what the next LN-folding GEMM reduces its
- *              row statistics from (pass it as ln_partial / ln_nblk). */
+ *              nblk = esme_hip_gemm_stats_blocks(M, N) = N / 64: what the next LN-folding GEMM reduces
+ *              its row statistics from (pass it as ln_partial / ln_nblk).  The block width and the
+ *              consumer's summation order (block 0, 1, 2, ... strictly left to right) are fixed, so a
+ *              row's statistics do not depend on the tile configuration a launch picks, i.e. on the
+ *              number of rows in the batch: a sequence's logits are bit-identical alone or packed. */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;
@@ -163,7 +166,7 @@ typedef struct esme_gemm_fusion {
     int rot_cols;
 } esme_gemm_fusion_t;
 
-/* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
+/* number of 64-column blocks a residual-epilogue GEMM of this shape writes to stats_out (= ceil(N / 64)) */
 int esme_hip_gemm_stats_blocks(int64_t M, int N);
 
 int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias,

@@ -287,11 +287,13 @@ def test_attention(lengths, H, d, qb):
     from esme import _hip
     lib = _hip.load()
     lib.esme_hip_debug_set_attn_qb.restype = None
-    lib.esme_hip_debug_set_attn_qb(qb)          # q-blocks per wave (2 = the long-sequence configuration)
+    lib.esme_hip_debug_set_attn_qb(qb)          # q-blocks per wave of the first-generation kernel (2 = long sequences)
+    _attn_hooks().esme_hip_debug_set_attn_variant(1 if d == 64 else 0)
     try:
         got, ref = _attn_case(lengths, H, d, seed=20)
     finally:
         lib.esme_hip_debug_set_attn_qb(0)
+        lib.esme_hip_debug_set_attn_variant(0)
     # P is rounded to bf16 before PV (FA-2 convention): allow 2^-6 relative + 2^-6 of the rms
     check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention {lengths} H{H} d{d}')
 
@@ -449,3 +451,95 @@ def test_layernorm_fold_stress(kind, tile):
     assert e_fold <= 3.0 * e_unf + 2.0 ** -7, (kind, e_fold, e_unf)
     assert e_fold1 <= 3.0 * e_unf + 2.0 ** -7, (kind, e_fold1, e_unf)
     assert r_fold <= 3.0 * r_unf + 2.0 ** -8, (kind, r_fold, r_unf)
+
+
+# ------------------------------------------------------------------ head dim 64: the software-pipelined kernel
+def _attn_hooks():
+    import ctypes
+    from esme import _hip
+    lib = _hip.load()
+    lib.esme_hip_debug_set_attn_variant.restype = None
+    lib.esme_hip_debug_set_attn_variant.argtypes = [ctypes.c_int]
+    lib.esme_hip_debug_set_attn_thr.restype = None
+    lib.esme_hip_debug_set_attn_thr.argtypes = [ctypes.c_float]
+    lib.esme_hip_debug_set_attn_spec.restype = None
+    lib.esme_hip_debug_set_attn_spec.argtypes = [ctypes.c_int]
+    return lib
+
+
+@pytest.mark.parametrize('lengths,H', [([37, 70, 193], 20), ([500, 500], 20), ([1, 300, 63, 64, 65], 5), ([1253], 4),
+                                       ([256, 257, 255], 3), ([513, 2], 2), ([2049], 1)])
+@pytest.mark.parametrize('variant,spec', [(4, 1), (4, 0), (8, 1), (8, 0), (1, 0)])
+def test_attention_d64_variants(lengths, H, variant, spec):
+    """Every schedule of the head-dim-64 kernel (first generation; ping-pong with 4 / 8 waves; speculative or classic
+    online softmax) against the fp32 oracle, on ragged tiles, 1-row sequences and lengths around the 256 / 512-row
+    workgroup tiles."""
+    lib = _attn_hooks()
+    lib.esme_hip_debug_set_attn_variant(variant)
+    lib.esme_hip_debug_set_attn_spec(spec)
+    try:
+        got, ref = _attn_case(lengths, H, 64, seed=40)
+    finally:
+        lib.esme_hip_debug_set_attn_variant(0)
+        lib.esme_hip_debug_set_attn_spec(1)
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention d64 variant {variant} spec {spec} {lengths}')
+
+
+def test_attention_speculative_overflow_is_redone_exactly():
+    """The speculative softmax keeps a row's FIRST-tile maximum as its reference.  A late key that beats it by far more
+    than 2^127 overflows exp2: the workgroup must notice (non-finite row sum) and redo its work item with the classic
+    online softmax.  Rows: q = k-spike direction, score jump ~ +3000 log2 units at key 700 of 900; plus a sequence
+    whose scores hold +inf products."""
+    from esme import _hip
+    lib = _attn_hooks()
+    H, d = 2, 64
+    E = H * d
+    lengths = [900, 130]
+    T = sum(lengths)
+    qkv = rnd((T, 3 * E), 41)
+    qkv[5, :E] = 4.0                                   # query row 5 (both heads): all +4
+    qkv[700, E:2 * E] = 64.0                           # key 700: all +64 -> q.k = 64*4*64 = 16384 -> * d^-1/2 * log2e ~ 2955
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    ref = O.varlen_attention(q, k, v, cu).view(T, E)
+    g = qkv.to(dev())
+    outs = {}
+    for variant, spec in ((4, 1), (8, 1), (4, 0), (1, 0)):
+        lib.esme_hip_debug_set_attn_variant(variant)
+        lib.esme_hip_debug_set_attn_spec(spec)
+        try:
+            outs[(variant, spec)] = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H)
+        finally:
+            lib.esme_hip_debug_set_attn_variant(0)
+            lib.esme_hip_debug_set_attn_spec(1)
+    for key, got in outs.items():
+        check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'overflow redo {key}')
+    # row 5 attends to key 700 alone
+    assert torch.allclose(outs[(4, 1)][5].float().cpu(), qkv[700, 2 * E:].float(), atol=2.0 ** -6)
+    # the redo IS the classic path: bit-identical to spec = 0 for the workgroups that overflowed (rows 0..255 of seq 0)
+    assert torch.equal(outs[(4, 1)][:256], outs[(4, 0)][:256])
+
+
+def test_attention_defer_max_threshold_error_report():
+    """quantify the defer-max threshold.  Max / Frobenius error vs the fp32 oracle for thr = 0 (row maxima
+    always exact) and thr = 8 (the fast default) and the speculative softmax, on sharp (3x scaled) and plain scores."""
+    from esme import _hip
+    lib = _attn_hooks()
+    rows = []
+    for qscale in (1.0, 3.0):
+        for variant, spec, thr in ((1, 0, 0.0), (1, 0, 8.0), (4, 0, 0.0), (4, 0, 8.0), (4, 1, 8.0)):
+            lib.esme_hip_debug_set_attn_variant(variant)
+            lib.esme_hip_debug_set_attn_spec(spec)
+            lib.esme_hip_debug_set_attn_thr(thr)
+            try:
+                got, ref = _attn_case([900, 500, 333], 8, 64, seed=42, qscale=qscale)
+            finally:
+                lib.esme_hip_debug_set_attn_variant(0)
+                lib.esme_hip_debug_set_attn_spec(1)
+                lib.esme_hip_debug_set_attn_thr(8.0)
+            err = (got.float().cpu() - ref).abs()
+            rows.append((qscale, variant, spec, thr, float(err.max()), rel_fro(got.float().cpu(), ref)))
+            check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'thr sweep {rows[-1][:4]}')
+    print()
+    for r in rows:
+        print(f'[attn thr] qscale {r[0]} variant {r[1]} spec {r[2]} thr {r[3]}: max|err| {r[4]:.3e} rel_fro {r[5]:.3e}')
