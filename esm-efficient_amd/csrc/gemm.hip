@@ -340,8 +340,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = acc[q >> 2][j][4 * (q & 3) + e], up = acc[q2 >> 2][j][4 * (q2 & 3) + e];
-                        acc[q >> 2][j][4 * (q & 3) + e] = lo * cv[e] - up * sv[e];
-                        acc[q2 >> 2][j][4 * (q2 & 3) + e] = up * cv[e] + lo * sv[e];
+                        // one product rounded, one fused: spelled out so that every tile configuration contracts the
+                        // same way (hipcc chose different fma pairings per instantiation: 1-ulp differences between a
+                        // sequence run alone and the same sequence inside a 50 000-residue batch)
+                        acc[q >> 2][j][4 * (q & 3) + e] = fmaf(lo, cv[e], -__fmul_rn(up, sv[e]));
+                        acc[q2 >> 2][j][4 * (q2 & 3) + e] = fmaf(up, cv[e], __fmul_rn(lo, sv[e]));
                     }
                 }
             }

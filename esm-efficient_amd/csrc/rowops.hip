@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* _
         unpack8(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc * 8), s);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            olo[j] = lo[j] * c[j] - hi[j] * s[j];
-            ohi[j] = hi[j] * c[j] + lo[j] * s[j];
+            // one product rounded, one fused, spelled out: the same contraction in every kernel that rotates
+            olo[j] = fmaf(lo[j], c[j], -__fmul_rn(hi[j], s[j]));
+            ohi[j] = fmaf(hi[j], c[j], __fmul_rn(lo[j], s[j]));
         }
         *reinterpret_cast<u32x4*>(xp) = pack8(olo);
         *reinterpret_cast<u32x4*>(xp + (d >> 1)) = pack8(ohi);
@@ -266,7 +267,10 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
             unpack8(*reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc), cs);
             unpack8(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc), sn);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = lower ? a[j] * cs[j] - o2[j] * sn[j] : a[j] * cs[j] + o2[j] * sn[j];
+            for (int j = 0; j < 8; ++j) {
+                const float t = __fmul_rn(o2[j], sn[j]);
+                r[j] = fmaf(a[j], cs[j], lower ? -t : t);
+            }
             *reinterpret_cast<u32x4*>(xr + e0) = pack8(r);
         }
     }
