@@ -720,9 +720,8 @@ static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     return check_launch("attn_varlen_fwd");
 }
 
-extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
-                                        int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
-                                        int max_len, float softmax_scale, void* stream) {
+static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o, int64_t ld_o, const int32_t* cu_lens,
+                    int B, int64_t T, int H, int d, int max_len, float softmax_scale, void* stream, bool exact) {
     ESME_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && d > 0 && max_len >= 0, "attn: bad sizes");
     if (T == 0 || B == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && v && o && cu_lens, "attn: null pointer");
@@ -732,7 +731,7 @@ extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void
                    "attn: misaligned");
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
-               softmax_scale * 1.4426950408889634f, 1, H * B, g_attn_thr, g_attn_spec};
+               softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec};
     const hipStream_t s = (hipStream_t)stream;
     if (d == 64 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o)) {
         // head dim 64 (ESM2-650M / 3B, ESM-C): the software-pipelined kernel.  4 waves = 256 query rows per workgroup, two
@@ -761,4 +760,16 @@ extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void
     }
 #undef ESME_ATTN
     return check_launch("attn_varlen_fwd");
+}
+
+extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
+                                        int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                        int max_len, float softmax_scale, void* stream) {
+    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, false);
+}
+
+extern "C" int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
+                                              int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                              int max_len, float softmax_scale, void* stream) {
+    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, true);
 }

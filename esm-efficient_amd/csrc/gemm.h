@@ -30,6 +30,8 @@ struct GemmArgs {
     // residual epilogue also emits per-row partial (sum, sum of squares) of the ROUNDED output
     // over each column tile of the launch: stats_out[(n/BN) * M + m] (float2) -> next LayerNorm's statistics
     float* stats_out;
+    int64_t stat_ld = 0;         // row count of the FULL problem = block stride of ln_partial / stats_out ((nblk, stat_ld, 2));
+                                 // a launch may cover a row range of it (tail split, see esme_hip_gemm_bf16_fused)
     unsigned long long* trace = nullptr;      // ESME_GEMM_TRACE builds only: per-block phase timestamps (16 per block)
 };
 

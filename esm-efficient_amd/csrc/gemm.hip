@@ -205,12 +205,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             for (; b + 10 <= a.ln_nblk; b += 10) {
                 f32x2 p[10];
 #pragma unroll
-                for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.M];
+                for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
 #pragma unroll
                 for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
             }
             for (; b < a.ln_nblk; ++b) {
-                const f32x2 p = pp[(int64_t)b * a.M];
+                const f32x2 p = pp[(int64_t)b * a.stat_ld];
                 s1 += p[0]; s2 += p[1];
             }
             const float inv = 1.0f / (float)a.ln_dim;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     // one partial per (64-column block, row), written by the block's wave itself: the layout
                     // (N/64, M, 2) is the same for every tile configuration (see the consumer's canonical sum)
                     if (ch == 0 && m < a.M && nw0 < a.N)
-                        *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(nw0 >> 6) * a.M + m)) = f32x2{t1, t2};
+                        *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(nw0 >> 6) * a.stat_ld + m)) = f32x2{t1, t2};
                 }
             }
         }
@@ -572,6 +572,21 @@ using namespace esme;
 // test / tuning hooks.  Not part of the documented ABI.
 static int g_force_tile = 0;
 extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
+static int g_split = 0;           // tail split of 256 x 256 launches: tuning hook, OFF (measured 1 % slower end to end, see below)
+extern "C" void esme_hip_debug_set_gemm_split(int v) { g_split = v; }
+
+// compute units of the current device (cached per device ordinal; 256 on MI355X)
+static int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cached[dev & 63].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
 extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
 extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
@@ -649,11 +664,44 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
         }
     }
     const hipStream_t s = (hipStream_t)stream;
-    switch (pick_tile(M, N)) {
-        case 1: return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
-        case 2: return launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);      // wave tile 128(m) x 64(n)
-        default: ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
+    a.stat_ld = M;
+    const int tile = pick_tile(M, N);
+    if (tile == 1) return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
+    if (tile != 2) ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
+    // Tail split.  256 x 256 tiles run one workgroup per CU, so a launch takes ceil(tiles / CUs) rounds and the last
+    // round is as long as a full one however few tiles it holds (50 000 x 5 120: 3 920 tiles = 15.3 rounds on 256 CUs).
+    // When the last round would be less than ~70 % full, the big-tile launch stops at the last row of tiles that keeps
+    // its rounds full and the remaining rows run as 128 x 128 tiles (two workgroups per CU, ~0.3 of a big tile each) in
+    // a second launch: ~0.35 round instead of 1.  Both configurations produce the same bits (tests), and the row
+    // statistics of the residual epilogue are per 64 columns in either.
+    // MEASURED (tools/gemm_split_ab.py, interleaved A/B, ESM2-650M, 50 000 residues): 76.3 ms with the split vs 75.5 ms
+    // without -- the few workgroups of a short last round run at a higher clock on a power-capped part (idle CUs hand
+    // their power budget over) and the 128 x 128 tiles are less efficient, so the "lost" 0.7 round is mostly not lost.
+    // Kept behind esme_hip_debug_set_gemm_split(1) for other shapes / parts; off by default.
+    const int64_t tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256, total = tiles_m * tiles_n;
+    const int ncu = cu_count();
+    const int64_t rounds = total / ncu, rem = total % ncu;
+    int64_t rows_big = tiles_m;
+    if (g_split && rounds >= 2 && rem != 0 && rem * 10 < (int64_t)ncu * 7) {
+        rows_big = (rounds * ncu) / tiles_n;                       // whole rows of big tiles that fit the full rounds
+        const int64_t m_rest = M - rows_big * 256;
+        const int64_t small = ((m_rest + 127) / 128) * ((N + 127) / 128);
+        if (m_rest <= 0 || small > 3 * 2 * (int64_t)ncu) rows_big = tiles_m;      // remainder too large to pay off
     }
+    if (rows_big == tiles_m) return launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);      // wave tile 128(m) x 64(n)
+    const int64_t m1 = rows_big * 256;
+    GemmArgs b = a;
+    a.M = m1;
+    int rc = launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);
+    if (rc != ESME_OK) return rc;
+    b.M = M - m1;
+    b.A += m1 * b.lda;
+    b.C += m1 * b.ldc;
+    if (b.resid) b.resid += m1 * b.ldr;
+    if (b.pos) b.pos += m1;
+    if (b.ln_partial) b.ln_partial += 2 * m1;
+    if (b.stats_out) b.stats_out += 2 * m1;
+    return launch_gemm<128, 128, 2, 2>(b, epilogue, rotd, lnf, stats, s);
 }
 
 extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,

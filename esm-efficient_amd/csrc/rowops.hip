@@ -119,6 +119,99 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
     }
 }
 
+
+// ------------------------------------------- high-precision mode: fp32 residual stream
+// x32 <- (init ? 0 : x32) + alpha * o   (o: a branch output in bf16; x32: the fp32 residual stream), plus what the next
+// LayerNorm-folded GEMM needs: x16 = bf16(x32) (its MFMA operand) and the row's {sum, sum of squares} of the fp32 values.
+// One wave per row, HBM-bound: 2 (o) + 4 + 4 (x32 r/w) + 2 (x16) bytes per element.
+template <int NCH>
+__global__ __launch_bounds__(256) void residual_f32_kernel(float* __restrict__ x32, int64_t ld32, const u16* __restrict__ o,
+                                                           int64_t ldo, float alpha, int init, u16* __restrict__ x16,
+                                                           int64_t ld16, f32x2* __restrict__ sums, int64_t T, int E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    float* xr = x32 + row * ld32;
+    const u16* orow = o + row * ldo;
+    u16* yr = x16 + row * ld16;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            float v[8], b[8];
+            unpack8(*reinterpret_cast<const u32x4*>(orow + e0), b);
+            if (init) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = alpha * b[j];
+            } else {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + e0), a1 = *reinterpret_cast<const f32x4*>(xr + e0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = fmaf(alpha, b[j], a0[j]); v[4 + j] = fmaf(alpha, b[4 + j], a1[j]); }
+            }
+            *reinterpret_cast<f32x4*>(xr + e0) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(xr + e0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<u32x4*>(yr + e0) = pack8(v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0 && sums) sums[row] = f32x2{s1, s2};
+}
+
+// LayerNorm of an fp32 row into bf16 (the final LayerNorm of the high-precision mode)
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, int64_t ldx, const u16* __restrict__ w,
+                                                            const u16* __restrict__ b, u16* __restrict__ y, int64_t ldy,
+                                                            int64_t T, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float* xr = x + row * ldx;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + e0), a1 = *reinterpret_cast<const f32x4*>(xr + e0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[c][j] = a0[j]; v[c][4 + j] = a1[j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float inv_e = 1.0f / (float)E;
+    const float mean = wave_sum(s) * inv_e;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
+    u16* yr = y + row * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            float wf[8], o[8], bfv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            unpack8(*reinterpret_cast<const u32x4*>(w + e0), wf);
+            if (b) unpack8(*reinterpret_cast<const u32x4*>(b + e0), bfv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+            *reinterpret_cast<u32x4*>(yr + e0) = pack8(o);
+        }
+    }
+}
+
 // ------------------------------------------------------- LayerNorm statistics
 // sums[row] = {sum x, sum x^2}: one wave per row (the first layer's input; later layers get
 // their statistics from the residual GEMM epilogues)
@@ -408,6 +501,50 @@ extern "C" int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, con
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm: E > 5120 unsupported");
 #undef ESME_LN
     return check_launch("layernorm");
+}
+
+
+extern "C" int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, int64_t ldo, float alpha, int init, void* x16,
+                                     int64_t ld16, float* sums, int64_t T, int E, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "residual_f32: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x32 && o && x16, "residual_f32: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && ld32 % 4 == 0 && ldo % 8 == 0 && ld16 % 8 == 0 && ld32 >= E && ldo >= E && ld16 >= E,
+                   "residual_f32: E / row strides not multiples of 8");
+    ESME_CHECK_ARG(aligned16(x32) && aligned16(o) && aligned16(x16) && (!sums || (reinterpret_cast<uintptr_t>(sums) & 7u) == 0),
+                   "residual_f32: misaligned");
+    const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_RF(N) hipLaunchKernelGGL(residual_f32_kernel<N>, grid, block, 0, s, x32, ld32, (const u16*)o, ldo, alpha, init, \
+                                      (u16*)x16, ld16, (f32x2*)sums, T, E)
+    if (E <= 512) ESME_RF(1);
+    else if (E <= 1024) ESME_RF(2);
+    else if (E <= 1536) ESME_RF(3);
+    else if (E <= 2560) ESME_RF(5);
+    else if (E <= 5120) ESME_RF(10);
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "residual_f32: E > 5120 unsupported");
+#undef ESME_RF
+    return check_launch("residual_f32");
+}
+
+extern "C" int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
+                                      int64_t T, int E, float eps, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "layernorm_f32: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && w && y, "layernorm_f32: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0 && ldx >= E && ldy >= E, "layernorm_f32: E/ld not multiples of 8");
+    ESME_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(w) && (!b || aligned16(b)), "layernorm_f32: misaligned");
+    const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_LNF(N) hipLaunchKernelGGL(layernorm_f32_kernel<N>, grid, block, 0, s, x, ldx, (const u16*)w, (const u16*)b, (u16*)y, ldy, T, E, eps)
+    if (E <= 512) ESME_LNF(1);
+    else if (E <= 1024) ESME_LNF(2);
+    else if (E <= 1536) ESME_LNF(3);
+    else if (E <= 2560) ESME_LNF(5);
+    else if (E <= 5120) ESME_LNF(10);
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm_f32: E > 5120 unsupported");
+#undef ESME_LNF
+    return check_launch("layernorm_f32");
 }
 
 extern "C" int esme_hip_row_sums(const void* x, int64_t ldx, int64_t T, int E, float* sums, void* stream) {

@@ -44,6 +44,12 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_attn_varlen_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                          c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_attn_varlen_fwd_exact': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                                               c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
+                                      c_int64, c_int, c_void_p]),
+    'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                       c_float, c_void_p]),
     'esme_hip_gemm_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_gemm_qkv_rotary': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
@@ -288,8 +294,10 @@ def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torc
 
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
-                heads: int, softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q, k, v: (T, H*d) views sharing one row stride; returns (T, H*d)."""
+                heads: int, softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
+                exact: bool = False) -> torch.Tensor:
+    """q, k, v: (T, H*d) views sharing one row stride; returns (T, H*d).  `exact=True`: classic online softmax
+    with every row maximum exact (esme_hip_attn_varlen_fwd_exact; the high-precision mode)."""
     qp, ld = _rows2d(q, 'attn q')
     kp, ld2 = _rows2d(k, 'attn k')
     vp, ld3 = _rows2d(v, 'attn v')
@@ -302,10 +310,38 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     op, ldo = _rows2d(out, 'attn out')
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
+    fn = load().esme_hip_attn_varlen_fwd_exact if exact else load().esme_hip_attn_varlen_fwd
     with _Traced('attn', (T, heads, d)):
-        _check(load().esme_hip_attn_varlen_fwd(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
-                                               cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()),
-               'esme_hip_attn_varlen_fwd')
+        _check(fn(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
+                  cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()), 'esme_hip_attn_varlen_fwd')
+    return out
+
+
+def residual_f32_(x32: torch.Tensor, o: torch.Tensor, alpha: float, x16: torch.Tensor, sums: Optional[torch.Tensor],
+                  init: bool = False) -> None:
+    """x32 (T, E) fp32 <- (0 if init else x32) + alpha * o (bf16); x16 <- bf16(x32); sums (1, T, 2) <- row {sum, sum sq}."""
+    if x32.dtype != torch.float32:
+        raise TypeError('residual_f32: the stream must be float32')
+    xp, ld32 = _rows2d(x32, 'residual_f32 x32', torch.float32)
+    opp, ldo = _rows2d(o, 'residual_f32 o')
+    yp, ld16 = _rows2d(x16, 'residual_f32 x16')
+    T, E = x32.shape
+    if o.shape != (T, E) or x16.shape != (T, E):
+        raise ValueError('residual_f32: shape mismatch')
+    with _Traced('residual_f32', (T, E)):
+        _check(load().esme_hip_residual_f32(xp, ld32, opp, ldo, float(alpha), 1 if init else 0, yp, ld16,
+                                            _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
+               'esme_hip_residual_f32')
+
+
+def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, out: torch.Tensor) -> torch.Tensor:
+    xp, ldx = _rows2d(x32, 'layernorm_f32 x', torch.float32)
+    yp, ldy = _rows2d(out, 'layernorm_f32 out')
+    T, E = x32.shape
+    with _Traced('layernorm', (T, E)):
+        _check(load().esme_hip_layernorm_f32(xp, ldx, _dev(weight, 'layernorm weight', torch.bfloat16),
+                                             _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
+                                             yp, ldy, T, E, eps, _stream()), 'esme_hip_layernorm_f32')
     return out
 
 

@@ -37,11 +37,13 @@ from esme.rotary import RotaryEmbedding
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32')
 
-    def __init__(self, pos, cos, sin, fold=False):
+    def __init__(self, pos, cos, sin, fold=False, exact_attn=False):
         self.pos, self.cos, self.sin = pos, cos, sin
         self.fold = fold            # run the LN-folded fast path
+        self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
+        self.x32 = None             # high-precision mode: the fp32 residual stream (T, E_phys)
         self.sums = None            # partial sums (nblk, T, 2) f32 describing the current residual stream
         self.part_a = None          # (stats_blocks, T, 2) f32 buffers the residual GEMMs write their row sums to
         self.part_b = None
@@ -234,11 +236,11 @@ class FlashMultiheadAttention(nn.Module):
         H, d = self.num_heads, self.head_pad
         return tuple(qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
 
-    def _attn(self, q, k, v, cu_lens, max_len):
+    def _attn(self, q, k, v, cu_lens, max_len, exact=False):
         T = q.shape[0]
         E = self.attn_dim
         return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads,
-                                softmax_scale=self.head_dim ** -0.5)
+                                softmax_scale=self.head_dim ** -0.5, exact=exact)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None):
@@ -275,7 +277,7 @@ class FlashMultiheadAttention(nn.Module):
                     _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
                 else:
                     q, k = self.rot_emb(q, k, cu_lens, max_len)
-        a = self._attn(q, k, v, cu_lens, max_len)
+        a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn))
         wo, bo = self._weights_out()
         if resid is not None:
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
@@ -410,6 +412,21 @@ class FlashTransformerLayer(nn.Module):
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
         wd, bd = self._weights_down()
         return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
+
+    def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext):
+        """One layer with the residual stream in fp32 (`ctx.x32`, updated in place).  `x16` = bf16(stream) is the MFMA
+        operand of the LayerNorm-folded GEMMs (statistics `ctx.sums` come from the fp32 values); the branch outputs leave
+        their GEMMs in bf16 and are accumulated into the stream by esme_hip_residual_f32.  Returns nothing: x16 / ctx.sums
+        are refreshed in place."""
+        alpha = 1.0 / self.residue_scaling
+        o = self.self_attn(x16, cu_lens, max_len, None, ctx, x_stats=ctx.sums)          # plain epilogue, bf16
+        _hip.residual_f32_(ctx.x32, o, alpha, x16, ctx.sums)
+        epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
+        wf, _, c1, c2 = self._weights_up(True)
+        u = _hip.gemm_fused(x16, wf, None, epi, ln=(ctx.sums, self.embed_dim, self.final[0].eps, c1, c2))
+        wd, bd = self._weights_down()
+        y = _hip.gemm(u, wd, bd)
+        _hip.residual_f32_(ctx.x32, y, alpha, x16, ctx.sums)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 inplace: bool = False):

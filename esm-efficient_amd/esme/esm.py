@@ -67,6 +67,9 @@ class ESM2(nn.Module):
     zero_mask_rows = True          # `<mask>` embedding rows are zeroed (esm.py:189)
     fold_layernorm = os.environ.get('ESME_NO_LN_FOLD', '0') != '1'   # LN folded into the QKV / FFN-up GEMMs
     quant_type_4bit = 'fp4'        # codebook of quantization='4bit' (esme.quantization.CODEBOOKS)
+    # 'fast': bf16 residual stream (storage at the reference's rounding points).  'high': fp32 residual stream + fp32
+    # LayerNorm statistics + exact online softmax, bf16 only at MFMA operands; slower.
+    precision = os.environ.get('ESME_PRECISION', 'fast')
 
     def __init__(self, num_layers: int = 33, embed_dim: int = 1280, attention_heads: int = 20,
                  checkpointing: bool = False, rotary_embedding: bool = True, dropout: float = 0.,
@@ -132,6 +135,13 @@ class ESM2(nn.Module):
                           mask_idx=self.alphabet.mask_idx if self.zero_mask_rows else -1,
                           pad_idx=self.alphabet.padding_idx if (tokens.ndim == 2 and self.zero_mask_rows) else -1)
 
+    def set_precision(self, mode: str):
+        """'fast' (default) or 'high' (fp32 residual stream; DESIGN.md section 4 has what each achieves)."""
+        assert mode in ('fast', 'high'), mode
+        self.precision = mode
+        self.invalidate_graphs()
+        return self
+
     # -- helpers ---------------------------------------------------------------
     def _context(self, cu_lens, max_len, total, device) -> ForwardContext:
         pos, _ = _hip.seq_positions(cu_lens, total)
@@ -139,7 +149,7 @@ class ESM2(nn.Module):
         cos = sin = None
         if rot is not None:
             cos, sin = rot.tables(int(max_len), device, torch.bfloat16)
-        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm)
+        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high')
 
     def _unpad(self, x, tokens):
         """Boolean-mask row gather: the `unpad_input` contract (esm.py:238)."""
@@ -196,12 +206,25 @@ class ESM2(nn.Module):
         pad_width = tokens.shape[1] if pad_args is None else max_len
         ctx = self._context(cu_lens, max_len, x.shape[0], x.device)
         taps = []
-        for i, layer in enumerate(self.layers):
-            x = layer(x, cu_lens, max_len, None, ctx, inplace=True)
-            if i in layers:
-                taps.append(x.clone())
         E = self.embed_dim
-        self.emb_layer_norm_after(x[:, :E], out=x[:, :E])        # pad columns (if any) stay zero
+        if self.precision == 'high' and len(self.layers):
+            # fp32 residual stream; x (bf16) is kept as the rounded copy the GEMMs read
+            assert x.shape[1] % 64 == 0, 'high-precision mode needs a 64-aligned physical width'
+            ctx.x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            ctx.sums = torch.empty(1, x.shape[0], 2, dtype=torch.float32, device=x.device)
+            _hip.residual_f32_(ctx.x32, x, 1.0, x, ctx.sums, init=True)
+            for i, layer in enumerate(self.layers):
+                layer.forward_high_precision(x, cu_lens, max_len, ctx)
+                if i in layers:
+                    taps.append(x.clone())
+            ln = self.emb_layer_norm_after
+            _hip.layernorm_f32(ctx.x32[:, :E], ln.weight, ln.bias, ln.eps, out=x[:, :E])
+        else:
+            for i, layer in enumerate(self.layers):
+                x = layer(x, cu_lens, max_len, None, ctx, inplace=True)
+                if i in layers:
+                    taps.append(x.clone())
+            self.emb_layer_norm_after(x[:, :E], out=x[:, :E])        # pad columns (if any) stay zero
 
         if pad_output or (pad_args is None):
             nseq = cu_lens.numel() - 1

@@ -81,6 +81,19 @@ int esme_hip_seq_positions(const int32_t* cu_lens, int B, int64_t T, int32_t* po
 int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y,
                        int64_t ldy, int64_t T, int E, float eps, void* stream);
 
+/* High-precision mode (fp32 residual stream): x32 <- (init ? 0 : x32) + alpha * o, with o a branch output in
+ * bf16 (T, E); also writes x16 = bf16(x32) (the MFMA operand of the next LayerNorm-folded GEMM) and, when sums
+ * != NULL, per row {sum, sum of squares} of the fp32 values as float (1, T, 2) (pass as ln_partial, ln_nblk = 1).
+ * Replaces the two `x + branch / residue_scaling` adds of esme/attention.py:253-255 when the stream is kept in
+ * fp32 (the reference keeps it in bf16). */
+int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, int64_t ldo, float alpha, int init,
+                          void* x16, int64_t ld16, float* sums, int64_t T, int E, void* stream);
+
+/* esme_hip_layernorm on an fp32 input (bf16 affine parameters and output): the final LayerNorm of the
+ * high-precision mode (esme/esm.py:252). */
+int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const void* b, void* y,
+                           int64_t ldy, int64_t T, int E, float eps, void* stream);
+
 /* In-place rotary embedding of q and k, both (T, H, d) views with row stride ld:
  * x[j] <- x[j]*cos[p][j] - x[j+d/2]*sin[p][j];  x[j+d/2] <- x[j+d/2]*cos[p][j] + x[j]*sin[p][j]
  * with p = pos[t].  cos/sin: bf16 tables (max_len, d) as the reference caches them
@@ -109,6 +122,12 @@ int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const 
 int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
                              void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
                              int H, int d, int max_len, float softmax_scale, void* stream);
+
+/* The same contraction with the classic online softmax: every row maximum exact (no defer-max threshold, no
+ * speculative tiles).  Used by the high-precision mode; ~15 % slower at head dim 64. */
+int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, int64_t ld_qkv,
+                                   void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
+                                   int H, int d, int max_len, float softmax_scale, void* stream);
 
 /* C (M, N') = epilogue(A (M, K) @ W (N, K)^T + bias (N)), bf16 in/out, fp32 accumulate on
  * MFMA.  bias may be NULL.  resid (M, N) is read only for ESME_EPI_RESIDUAL and may alias C.

@@ -133,3 +133,35 @@ def test_config5_mask_margin_4bit_1000aa():
         e_hip, e_ref = np.abs(got - ref32).max(), np.abs(refbf - ref32).max()
         print(f'\n[q4 mask-margin 1000aa] pos {pos}: max|hip - oracle_fp32| {e_hip:.4f}, max|oracle_bf16 - oracle_fp32| {e_ref:.4f}')
         assert e_hip <= max(2.0 * e_ref, 0.15), (pos, e_hip, e_ref)
+
+
+def test_high_precision_mode_full_depth():
+    """VERDICT r1 item 5 / SURVEY section 7 (iii): the fp32-residual-stream mode (`model.set_precision('high')`).
+    ESM2-650M, 33 layers, 50 000 residues; three whole sequences vs the fp32-math oracle.  What it achieves is
+    asserted as measured: it must beat the fast mode clearly, but the north star's 1e-3 stays out of reach for ANY
+    forward whose GEMM operands are bf16 (the operand rounding alone leaves ~5e-3 at this depth; DESIGN.md section 4
+    has the numbers and the CPU emulation that separates the two error sources)."""
+    model, w, H = load('esm2_650m')
+    tokens, cu, max_len, lengths = syn.uniform_batch(50000, 500, seed=0)
+    picks = [0, 57, 99]
+    cul = cu.tolist()
+    sub_t = torch.cat([tokens[cul[i]:cul[i + 1]] for i in picks])
+    sub_cu = syn.cu_lens_of([500] * 3)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    ref32 = O.forward_logits(w, H, sub_t, sub_cu, 500, dtype=torch.float32).float()
+    refbf = O.forward_logits(w, H, sub_t, sub_cu, 500, dtype=torch.bfloat16).float()
+    rows = lambda out: torch.cat([out[cul[i]:cul[i + 1]] for i in picks]).float().cpu()
+    fast = rows(model(tokens.to(DEV), (cu.to(DEV), max_len)))
+    model.set_precision('high')
+    out_hp = model(tokens.to(DEV), (cu.to(DEV), max_len))
+    high = rows(out_hp)
+    alone = model(sub_t.to(DEV), (sub_cu.to(DEV), 500))
+    assert torch.equal(alone.float().cpu(), high), 'high-precision mode: packed rows differ from the sequences run alone'
+    model.set_precision('fast')
+    e_fast, e_high, e_ref = rel_fro(fast, ref32), rel_fro(high, ref32), rel_fro(refbf, ref32)
+    print(f'\n[precision] ESM2-650M x 33 layers, 50 000 residues: rel_fro vs fp32 oracle: fast {e_fast:.3e} | high {e_high:.3e} | '
+          f'reference-equivalent bf16 forward {e_ref:.3e}; max|err| fast {float((fast - ref32).abs().max()):.3e} high '
+          f'{float((high - ref32).abs().max()):.3e}')
+    assert torch.isfinite(high).all()
+    assert e_high <= 0.6 * e_fast, (e_high, e_fast)          # measured 0.45x at this depth
+    assert e_high <= 7.5e-3, e_high                           # measured 5.5-6e-3: bf16 MFMA operands, not the stream, bound it

@@ -7,7 +7,9 @@ bf16; its own bf16 forward differs from its fp32-math forward on the same weight
 the same points but does all arithmetic in fp32 with a single rounding per fused
 stage, so it must be at least as close to the fp32 forward as the reference's bf16
 forward is:   rel_fro(hip, ref_fp32) <= max(1.25 * rel_fro(ref_bf16, ref_fp32), 4e-3)
-and           rel_fro(hip, ref_bf16) <= 2e-2,  per-row cosine >= 0.999.
+and           rel_fro(hip, ref_bf16) <= max(2e-2, 1.6 * rel_fro(ref_bf16, ref_fp32))   (two bf16 forwards that are
+              each e away from the fp32 forward with independent roundings sit ~sqrt(2) e apart: at full depth,
+              36 layers, e is 1.9e-2 for the reference's own arithmetic),  per-row cosine >= 0.999.
 """
 import os
 import tempfile
@@ -43,7 +45,7 @@ def assert_parity(got, ref32, refbf, what):
     print(f'\n[parity] {what}: hip-vs-fp32 {e_hip:.3e} | ref_bf16-vs-fp32 {e_ref:.3e} | hip-vs-ref_bf16 {e_bf:.3e} '
           f'| min row cosine {float(cos):.6f}')
     assert e_hip <= max(1.25 * e_ref, 4e-3), (what, e_hip, e_ref)
-    assert e_bf <= 2e-2, (what, e_bf)
+    assert e_bf <= max(2e-2, 1.6 * e_ref), (what, e_bf, e_ref)
     assert cos >= 0.999, (what, float(cos))
 
 
@@ -263,3 +265,30 @@ def test_empty_sequence_and_empty_batch():
     assert out.shape == (0, 33)
     lp = model.predict_log_prob(empty, (torch.zeros(1, dtype=torch.int32, device=DEV), 1))
     assert lp.shape == (0, 33)
+
+
+@pytest.mark.parametrize('kind,L,E,H,lengths', [('esm2', 4, 320, 20, [33, 150, 70]), ('esmc', 3, 960, 15, [45, 150, 5]),
+                                                ('esm2', 2, 480, 20, [9, 130, 61]), ('esm1b', 2, 320, 20, [40, 17])])
+def test_high_precision_mode_small_models(kind, L, E, H, lengths):
+    """`set_precision('high')` (fp32 residual stream, exact online softmax) on every model family, incl. the padded
+    ESM2-35M layout and learned positions: closer to the fp32 oracle than the fast mode (or within the bf16 noise of a
+    shallow model), same API, taps and the 2-D path work, graphs are re-captured."""
+    model = build(kind, L, E, H, 17)
+    w = syn.synthetic_state_dict(kind, L, E, 17)
+    tokens, cu, ml = syn.random_tokens(lengths, seed=2), syn.cu_lens_of(lengths), max(lengths)
+    ref32 = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.float32)
+    refbf = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.bfloat16)
+    fast = model(tokens.to(DEV), (cu.to(DEV), ml))
+    model.set_precision('high')
+    high = model(tokens.to(DEV), (cu.to(DEV), ml))
+    assert_parity(high, ref32, refbf, f'{kind} E={E} high-precision logits')
+    e_fast, e_high = rel_fro(fast.float().cpu(), ref32), rel_fro(high.float().cpu(), ref32)
+    print(f'\n[precision] {kind} L={L} E={E}: fast {e_fast:.3e} high {e_high:.3e}')
+    assert e_high <= 1.1 * e_fast
+    rep = model.forward_representation(tokens.to(DEV), (cu.to(DEV), ml), layers=[0])
+    r32 = O.forward_representation(w, H, tokens, cu, ml, dtype=torch.float32, layers=[0])
+    assert rep.shape == r32.shape and rel_fro(rep.float().cpu(), r32) < 1e-2
+    if kind != 'esm1b':
+        assert torch.equal(model.graphed(tokens.to(DEV), (cu.to(DEV), ml)), high)
+    model.set_precision('fast')
+    assert torch.equal(model(tokens.to(DEV), (cu.to(DEV), ml)), fast)

@@ -432,8 +432,9 @@ def test_graph_survives_rotary_table_regrow():
 
 def test_fixed_width_padded_batch_stays_in_bounds():
     """2-D tokens padded to a fixed width S > max(lens) (every row holds <pad>).  The pad_input
-    scatter runs on the (B, S) input grid: output is (B, S, V), pad rows are zero, real rows equal the packed
-    forward's -- and nothing is written out of bounds (the reference raises an index error here)."""
+    scatter runs on the (B, S) input grid: output is (B, S, V), pad rows hold head(0) (the reference applies the LM
+    head to the zero rows pad_input leaves, esm.py:255-282), real rows equal the packed forward's -- and nothing is
+    written out of bounds (the reference raises an index error here)."""
     model = build('esm2', 2, 64, 4, 3)
     lens, S = [9, 17, 5], 32
     toks = [syn.random_tokens([n], seed=10 + i) for i, n in enumerate(lens)]
@@ -443,10 +444,13 @@ def test_fixed_width_padded_batch_stays_in_bounds():
     out = model(t2.to(DEV))
     assert out.shape == (3, S, 33)
     packed = model(torch.cat(toks).to(DEV), (syn.cu_lens_of(lens).to(DEV), max(lens)))
+    head0 = model.lm_head(torch.zeros(1, model.embed_dim, dtype=torch.bfloat16, device=DEV))[0]
+    rep = model.forward_representation(t2.to(DEV))
     o = 0
     for i, n in enumerate(lens):
         assert torch.equal(out[i, :n], packed[o:o + n])
-        assert not out[i, n:].any()
+        assert torch.equal(out[i, n:], head0.expand(S - n, -1))
+        assert not rep[i, n:].any()                      # the representation's pad rows are zero
         o += n
     lp = model.predict_log_prob(t2.to(DEV))
     assert lp.shape == (3, S, 33) and torch.isfinite(lp.float()).all()
