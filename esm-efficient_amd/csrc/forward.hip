@@ -1,0 +1,107 @@
+// esme_hip_forward: the whole packed forward (L transformer layers, final LayerNorm, LM head) enqueued by ONE call.
+//
+// Host-only code: it issues exactly the launches the Python modules issue (esme/attention.py, esme/esm.py, esme/head.py
+// in this repository, which mirror the reference's esme/attention.py:241-255, esme/esm.py:243-252, esme/head.py:25-27),
+// through this library's own C entry points, so results are bit-identical to the module-by-module path.  What it
+// removes is the host: ~160 ctypes calls (3-10 ms of Python per forward) become one, which is what a small model
+// (ESM2-8M / 150M at a few thousand residues: less GPU work than that) needs when it is not replayed from a hipGraph.
+#include "launch.h"
+
+using namespace esme;
+
+namespace {
+
+struct Ws {                        // carve-up of the caller's workspace
+    char* qkv; char* attn; char* mid; char* head; float* sums; float* part_a; float* part_b;
+};
+
+inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
+
+int64_t carve(const esme_model_desc_t* m, int64_t T, Ws* w, char* base) {
+    const int64_t Ea = (int64_t)m->heads * m->head_pad, Ep = m->phys_dim;
+    const int64_t mid_cols = m->ffn_dim;                    // output columns of the FFN up-projection (F)
+    const int64_t nblk = (Ep + 63) / 64;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off += align256(bytes); return base ? base + o : (char*)nullptr; };
+    char* qkv = take(T * 3 * Ea * 2);
+    char* attn = take(T * Ea * 2);
+    char* mid = take(T * mid_cols * 2);
+    char* head = take(T * Ep * 2);
+    char* sums = take(T * 2 * 4);
+    char* pa = take(nblk * T * 2 * 4);
+    char* pb = take(nblk * T * 2 * 4);
+    if (w) *w = Ws{qkv, attn, mid, head, (float*)sums, (float*)pa, (float*)pb};
+    return off;
+}
+
+}  // namespace
+
+extern "C" int64_t esme_hip_forward_workspace_bytes(const esme_model_desc_t* m, int64_t T) {
+    if (!m || T < 0) return -1;
+    return carve(m, T, nullptr, nullptr);
+}
+
+extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx, const int32_t* cu_lens, int B, int64_t T,
+                                int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes, void* logits,
+                                int64_t ld_logits, void* stream) {
+    ESME_CHECK_ARG(m && m->struct_bytes == (int)sizeof(esme_model_desc_t), "forward: descriptor missing or of another ABI");
+    ESME_CHECK_ARG(T >= 0 && B >= 0 && max_len >= 0, "forward: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && cu_lens && workspace && m->layers && m->n_layers >= 0, "forward: null pointer");
+    ESME_CHECK_ARG(m->phys_dim % 64 == 0 && m->embed_dim > 0 && m->embed_dim <= m->phys_dim && ldx >= m->phys_dim,
+                   "forward: the physical width must be a multiple of 64 (LayerNorm-folded path)");
+    ESME_CHECK_ARG(ws_bytes >= carve(m, T, nullptr, nullptr) && aligned16(workspace), "forward: workspace too small or misaligned");
+    ESME_CHECK_ARG(!m->rotary || (m->cos && m->sin && pos), "forward: rotary models need cos, sin and pos");
+    Ws w;
+    carve(m, T, &w, (char*)workspace);
+    const int Ep = m->phys_dim, E = m->embed_dim, H = m->heads, dp = m->head_pad;
+    const int64_t Ea = (int64_t)H * dp;
+    const int nblk = (Ep + 63) / 64;
+    const float scale = m->softmax_scale;
+    const bool rot_fused = m->rotary && !m->qk_norm && (dp == 16 || dp == 32 || dp == 64) && Ea % 32 == 0;
+    int rc;
+#define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
+    const float* stats = w.sums;            // statistics describing the current residual stream
+    int stats_nblk = 1;
+    if (m->n_layers > 0) ESME_TRY(esme_hip_row_sums(x, ldx, T, Ep, w.sums, stream));
+    for (int i = 0; i < m->n_layers; ++i) {
+        const esme_layer_weights_t& L = m->layers[i];
+        // ---- attention branch: LN-folded fused QKV (+ rotary), varlen attention, out-projection + residual + statistics
+        esme_gemm_fusion_t fu{};
+        fu.ln_partial = stats; fu.ln_nblk = stats_nblk; fu.ln_dim = E; fu.ln_eps = m->ln_eps; fu.ln_c1 = L.qkv_c1; fu.ln_c2 = L.qkv_c2;
+        if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
+        ESME_TRY(esme_hip_gemm_bf16_fused(x, ldx, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Ep, ESME_EPI_NONE, 1.0f, &fu, stream));
+        char* q = w.qkv; char* k = w.qkv + Ea * 2; char* v = w.qkv + 2 * Ea * 2;
+        if (m->qk_norm) {
+            ESME_TRY(esme_hip_qk_norm_rotary(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp,
+                                             m->table_len, stream));
+        } else if (m->rotary && !rot_fused) {
+            ESME_TRY(esme_hip_rotary_varlen(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+        }
+        ESME_TRY(esme_hip_attn_varlen_fwd(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, scale, stream));
+        esme_gemm_fusion_t fo{};
+        fo.stats_out = w.part_b;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, x, ldx, x, ldx, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
+        // ---- FFN branch: LN-folded up-projection with GELU / SiLU*mul, down-projection + residual + statistics
+        esme_gemm_fusion_t fup{};
+        fup.ln_partial = w.part_b; fup.ln_nblk = nblk; fup.ln_dim = E; fup.ln_eps = m->ln_eps; fup.ln_c1 = L.up_c1; fup.ln_c2 = L.up_c2;
+        const int up_rows = m->swiglu ? 2 * m->ffn_dim : m->ffn_dim;
+        ESME_TRY(esme_hip_gemm_bf16_fused(x, ldx, L.up_w, nullptr, nullptr, 0, w.mid, m->ffn_dim, T, up_rows, Ep,
+                                          m->swiglu ? ESME_EPI_SWIGLU : ESME_EPI_GELU, 1.0f, &fup, stream));
+        esme_gemm_fusion_t fd{};
+        fd.stats_out = w.part_a;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, x, ldx, x, ldx, T, Ep, m->ffn_dim, ESME_EPI_RESIDUAL, m->alpha,
+                                          &fd, stream));
+        stats = w.part_a; stats_nblk = nblk;
+    }
+    // ---- final LayerNorm over the logical width (pad columns stay zero), in place
+    ESME_TRY(esme_hip_layernorm(x, ldx, m->final_ln_w, m->final_ln_b, x, ldx, T, E, m->ln_eps, stream));
+    if (!logits) return ESME_OK;
+    // ---- RobertaLMHead: dense + GELU, LayerNorm, vocab projection
+    ESME_CHECK_ARG(m->head_dense_w && m->head_ln_w && m->head_final_w && m->vocab > 0 && ld_logits >= m->vocab, "forward: LM head weights missing");
+    ESME_TRY(esme_hip_gemm_bf16(x, ldx, m->head_dense_w, m->head_dense_b, nullptr, 0, w.head, Ep, T, Ep, Ep, ESME_EPI_GELU, 1.0f, stream));
+    ESME_TRY(esme_hip_layernorm(w.head, Ep, m->head_ln_w, m->head_ln_b, w.head, Ep, T, E, m->ln_eps, stream));
+    ESME_TRY(esme_hip_gemm_bf16(w.head, Ep, m->head_final_w, m->head_final_b, nullptr, 0, logits, ld_logits, T, m->vocab, Ep, ESME_EPI_NONE, 1.0f, stream));
+#undef ESME_TRY
+    return ESME_OK;
+}

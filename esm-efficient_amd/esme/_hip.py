@@ -28,6 +28,21 @@ class GemmFusion(Structure):
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int)]
 
 
+class LayerWeights(Structure):
+    """esme_layer_weights_t (include/esme_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ('qkv_w', 'qkv_c1', 'qkv_c2', 'out_w', 'out_b', 'up_w', 'up_c1', 'up_c2',
+                                        'down_w', 'down_b', 'lnq_w', 'lnk_w', 'lnq_b', 'lnk_b')]
+
+
+class ModelDesc(Structure):
+    """esme_model_desc_t (include/esme_hip.h)."""
+    _fields_ = ([(n, c_int) for n in ('struct_bytes', 'n_layers', 'embed_dim', 'phys_dim', 'heads', 'head_dim', 'head_pad',
+                                      'ffn_dim', 'vocab', 'swiglu', 'rotary', 'qk_norm', 'table_len')]
+                + [('ln_eps', c_float), ('alpha', c_float), ('softmax_scale', c_float), ('layers', POINTER(LayerWeights))]
+                + [(n, c_void_p) for n in ('final_ln_w', 'final_ln_b', 'head_dense_w', 'head_dense_b', 'head_ln_w',
+                                           'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')])
+
+
 # name -> (restype, argtypes); must list every symbol include/esme_hip.h declares
 SIGNATURES = {
     'esme_hip_abi_version': (c_int, []),
@@ -57,6 +72,9 @@ SIGNATURES = {
     'esme_hip_gemm_bf16_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, POINTER(GemmFusion), c_void_p]),
     'esme_hip_gemm_stats_blocks': (c_int, [c_int64, c_int]),
+    'esme_hip_forward_workspace_bytes': (c_int64, [POINTER(ModelDesc), c_int64]),
+    'esme_hip_forward': (c_int, [POINTER(ModelDesc), c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                 c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     'esme_hip_row_sums': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -1,0 +1,105 @@
+"""Binding of the whole-model C entry `esme_hip_forward` (include/esme_hip.h).
+
+One ctypes call enqueues all transformer layers + the final LayerNorm: the same launches the modules in
+`esme.attention` issue one by one (bit-identical results), minus ~160 trips through Python.  The descriptor
+holds raw pointers to the DERIVED weight copies of the LayerNorm-folded fast path; the tensors are kept alive
+by the modules that own them and by `ModelDescriptor.keep`, and the descriptor is rebuilt whenever a parameter
+version changes.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+from esme import _hip
+
+
+from esme._hip import LayerWeights, ModelDesc
+
+
+def _bind():
+    return _hip.load()
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class ModelDescriptor:
+    """esme_model_desc_t of one model instance + the tensors it points to."""
+
+    def __init__(self, model):
+        from esme.attention import _version_key
+        self.key = self.signature(model)
+        layers = model.layers
+        first = layers[0]
+        att0 = first.self_attn
+        self.keep = []
+        arr = (LayerWeights * len(layers))()
+        for i, layer in enumerate(layers):
+            att = layer.self_attn
+            wq, _, c1, c2 = att._weights_qkv(True)
+            wo, bo = att._weights_out()
+            wu, _, u1, u2 = layer._weights_up(True)
+            wd, bd = layer._weights_down()
+            lw = arr[i]
+            lw.qkv_w, lw.qkv_c1, lw.qkv_c2 = _ptr(wq), _ptr(c1), _ptr(c2)
+            lw.out_w, lw.out_b = _ptr(wo), _ptr(bo)
+            lw.up_w, lw.up_c1, lw.up_c2 = _ptr(wu), _ptr(u1), _ptr(u2)
+            lw.down_w, lw.down_b = _ptr(wd), _ptr(bd)
+            if att.pre_layernorm:
+                lw.lnq_w, lw.lnk_w = _ptr(att.layernorm_q.weight), _ptr(att.layernorm_k.weight)
+                lw.lnq_b, lw.lnk_b = _ptr(att.layernorm_q.bias), _ptr(att.layernorm_k.bias)
+            self.keep += [wq, c1, c2, wo, bo, wu, u1, u2, wd, bd]
+        d = ModelDesc()
+        d.struct_bytes = ctypes.sizeof(ModelDesc)
+        d.n_layers, d.embed_dim, d.phys_dim = len(layers), model.embed_dim, model.phys_dim
+        d.heads, d.head_dim, d.head_pad = att0.num_heads, att0.head_dim, att0.head_pad
+        swiglu = first.final_activation == 'swiglu'
+        d.ffn_dim = first.final[1].out_features if swiglu else first.final[1].out_features
+        d.vocab = model.vocab_size
+        d.swiglu, d.rotary, d.qk_norm = int(swiglu), int(att0.rot_emb is not None), int(att0.pre_layernorm)
+        d.ln_eps, d.alpha = float(att0.norm.eps), 1.0 / float(first.residue_scaling)
+        d.softmax_scale = att0.head_dim ** -0.5
+        d.layers = arr
+        ln = model.emb_layer_norm_after
+        d.final_ln_w, d.final_ln_b = _ptr(ln.weight), _ptr(ln.bias)
+        self.layer_array = arr
+        self.desc = d
+
+    @staticmethod
+    def signature(model):
+        return tuple((p.data_ptr(), p._version) for p in model.parameters())
+
+    @staticmethod
+    def supported(model) -> bool:
+        if not len(model.layers) or not model.fold_layernorm or model.precision != 'fast' or model.phys_dim % 64:
+            return False
+        for layer in model.layers:
+            att = layer.self_attn
+            if att._q4_qkv is not None or att._q4_out is not None or layer._q4_up is not None or layer._q4_down is not None:
+                return False
+            if att.pre_layernorm and (att.rot_emb is None or att.head_pad not in (16, 32, 64, 128) or att.attn_dim > 5120):
+                return False
+        return True
+
+
+def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
+    """In place on x (T, phys_dim): all layers + final LayerNorm through ONE C call."""
+    lib = _bind()
+    md = getattr(model, '_cdesc', None)
+    if md is None or md.key != ModelDescriptor.signature(model):
+        md = ModelDescriptor(model)
+        model._cdesc = md
+    d = md.desc
+    d.cos, d.sin = _ptr(cos), _ptr(sin)
+    d.table_len = int(cos.shape[0]) if cos is not None else 0
+    T = x.shape[0]
+    nbytes = int(lib.esme_hip_forward_workspace_bytes(ctypes.byref(d), T))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    _hip._check(lib.esme_hip_forward(ctypes.byref(d), _hip._dev(x, 'forward x', torch.bfloat16), x.stride(0),
+                                     _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
+                                     _ptr(pos), ws.data_ptr(), nbytes, None, 0, _hip._stream()), 'esme_hip_forward')
+    return x

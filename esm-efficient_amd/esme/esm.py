@@ -70,6 +70,8 @@ class ESM2(nn.Module):
     # 'fast': bf16 residual stream (storage at the reference's rounding points).  'high': fp32 residual stream + fp32
     # LayerNorm statistics + exact online softmax, bf16 only at MFMA operands; slower.
     precision = os.environ.get('ESME_PRECISION', 'fast')
+    # all layers + final LayerNorm through ONE C call (esme_hip_forward) instead of ~5 Python-issued launches per layer
+    c_forward = os.environ.get('ESME_NO_C_FORWARD', '0') != '1'
 
     def __init__(self, num_layers: int = 33, embed_dim: int = 1280, attention_heads: int = 20,
                  checkpointing: bool = False, rotary_embedding: bool = True, dropout: float = 0.,
@@ -134,6 +136,10 @@ class ESM2(nn.Module):
         return _hip.embed(tokens, self._embed_table(),
                           mask_idx=self.alphabet.mask_idx if self.zero_mask_rows else -1,
                           pad_idx=self.alphabet.padding_idx if (tokens.ndim == 2 and self.zero_mask_rows) else -1)
+
+    def _c_forward_ok(self) -> bool:
+        from esme.cforward import ModelDescriptor
+        return ModelDescriptor.supported(self)
 
     def set_precision(self, mode: str):
         """'fast' (default) or 'high' (fp32 residual stream; DESIGN.md section 4 has what each achieves)."""
@@ -219,6 +225,9 @@ class ESM2(nn.Module):
                     taps.append(x.clone())
             ln = self.emb_layer_norm_after
             _hip.layernorm_f32(ctx.x32[:, :E], ln.weight, ln.bias, ln.eps, out=x[:, :E])
+        elif self.c_forward and not layers and _hip.TRACE is None and self._c_forward_ok():
+            from esme import cforward
+            cforward.forward_layers(self, x, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin)
         else:
             for i, layer in enumerate(self.layers):
                 x = layer(x, cu_lens, max_len, None, ctx, inplace=True)

@@ -256,6 +256,50 @@ int esme_hip_quantize_8bit(const void* w, int64_t ldw, int64_t N, int K, void* c
 int esme_hip_dequantize_8bit(const void* codes, const float* scale, int64_t N, int K,
                              const float* col_scale, void* out, int64_t ldo, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Whole-model entry (optional export): ONE call enqueues the L transformer layers, the final
+ * LayerNorm and (logits != NULL) the LM head of the packed forward -- esme/esm.py:243-252,268-282 in the reference --
+ * on the LayerNorm-folded fast path.  It issues the same launches as the module-by-module path (bit-identical
+ * results); what it removes is ~160 host calls per forward.  All pointers are device pointers the caller keeps alive;
+ * the descriptor itself lives in host memory.
+ *
+ *  x:       (T, phys_dim) bf16, row stride ldx: the embedded tokens on entry (esme_hip_embed), the final-LayerNorm
+ *           representation on exit (pad columns, if any, stay zero);
+ *  pos:     int32 (T) in-sequence positions (esme_hip_seq_positions); cos / sin: (table_len, head_pad) bf16 tables;
+ *  workspace: esme_hip_forward_workspace_bytes(desc, T) bytes, 16-byte aligned;
+ *  logits:  (T, vocab) bf16 with row stride ld_logits, or NULL for representations only.
+ * Layer weights are the DERIVED copies the fast path uses: the fused (3*H*head_pad, phys_dim) q/k/v weight and the FFN
+ * up weight scaled by the LayerNorm gain (W' = W diag(gamma), bf16) with c1 = rowsum(W'), c2 = W beta + bias (fp32);
+ * SwiGLU up weights gate / fc interleaved in 32-row blocks (ESME_EPI_SWIGLU). */
+typedef struct esme_layer_weights {
+    const void* qkv_w; const float* qkv_c1; const float* qkv_c2;
+    const void* out_w; const void* out_b;                 /* (phys_dim, H*head_pad), bias or NULL */
+    const void* up_w; const float* up_c1; const float* up_c2;
+    const void* down_w; const void* down_b;               /* (phys_dim, ffn_dim), bias or NULL */
+    const void* lnq_w; const void* lnk_w; const void* lnq_b; const void* lnk_b;   /* ESM-C q/k LayerNorm (qk_norm) */
+} esme_layer_weights_t;
+
+typedef struct esme_model_desc {
+    int struct_bytes;            /* sizeof(esme_model_desc_t): guards against ABI drift */
+    int n_layers, embed_dim, phys_dim, heads, head_dim, head_pad, ffn_dim, vocab;
+    int swiglu;                  /* 0: GELU FFN with biases (ESM-2 / ESM-1), 1: SwiGLU (ESM-C) */
+    int rotary;                  /* 0: none (ESM-1b / 1v: learned positions are part of the embedding) */
+    int qk_norm;                 /* 1: ESM-C LayerNorm over the full width of q and of k before rotary */
+    int table_len;               /* rows of the cos / sin tables */
+    float ln_eps, alpha;         /* alpha = 1 / residue_scaling */
+    float softmax_scale;         /* head_dim^-1/2 of the LOGICAL head dim (esme/attention.py:115-123 leaves it to flash-attn) */
+    const esme_layer_weights_t* layers;
+    const void* final_ln_w; const void* final_ln_b;
+    const void* head_dense_w; const void* head_dense_b; const void* head_ln_w; const void* head_ln_b;
+    const void* head_final_w; const void* head_final_b;
+    const void* cos; const void* sin;
+} esme_model_desc_t;
+
+int64_t esme_hip_forward_workspace_bytes(const esme_model_desc_t* model, int64_t T);
+int esme_hip_forward(const esme_model_desc_t* model, void* x, int64_t ldx, const int32_t* cu_lens, int B,
+                     int64_t T, int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes,
+                     void* logits, int64_t ld_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -292,3 +292,35 @@ def test_high_precision_mode_small_models(kind, L, E, H, lengths):
         assert torch.equal(model.graphed(tokens.to(DEV), (cu.to(DEV), ml)), high)
     model.set_precision('fast')
     assert torch.equal(model(tokens.to(DEV), (cu.to(DEV), ml)), fast)
+
+
+@pytest.mark.parametrize('kind,L,E,H,lengths', [('esm2', 3, 320, 20, [33, 150, 70]), ('esmc', 2, 960, 15, [45, 150, 5]),
+                                                ('esm2', 2, 480, 20, [9, 130, 61]), ('esm1b', 2, 320, 20, [40, 17]),
+                                                ('esm2', 1, 2560, 20, [150, 70])])
+def test_c_forward_entry_equals_module_path(kind, L, E, H, lengths):
+    """esme_hip_forward (one C call for all layers + the final LayerNorm; SURVEY section 8b's optional export) issues the
+    same launches as the Python modules: logits, representations and the 2-D path are bit-identical with it on or off."""
+    model = build(kind, L, E, H, 23)
+    assert model._c_forward_ok()
+    tokens, cu, ml = syn.random_tokens(lengths, seed=4).to(DEV), syn.cu_lens_of(lengths).to(DEV), max(lengths)
+    type(model).c_forward, keep = True, type(model).c_forward
+    try:
+        a = model(tokens, (cu, ml))
+        ra = model.forward_representation(tokens, (cu, ml))
+        assert getattr(model, '_cdesc', None) is not None          # the C entry really ran
+        type(model).c_forward = False
+        b = model(tokens, (cu, ml))
+        rb = model.forward_representation(tokens, (cu, ml))
+    finally:
+        type(model).c_forward = keep
+    assert torch.equal(a, b) and torch.equal(ra, rb)
+    # a weight update invalidates the cached descriptor
+    with torch.no_grad():
+        model.layers[0].final[0].weight.mul_(1.5)
+    c = model(tokens, (cu, ml))
+    assert not torch.equal(c, a)
+    type(model).c_forward = False
+    try:
+        assert torch.equal(c, model(tokens, (cu, ml)))
+    finally:
+        type(model).c_forward = keep

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Small-M GEMM shapes (BASELINE config 2: ESM2-150M, 8 192 residues): tile configuration 1 (128 x 128, 4 waves) vs
+2 (256 x 256, 8 waves), plain epilogue, interleaved timing.  usage: python tools/gemm_small_m.py [--m 8192]"""
+import argparse, math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'esm-efficient_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import torch
+from esme import _hip
+ap = argparse.ArgumentParser()
+ap.add_argument('--m', type=int, default=8192)
+ap.add_argument('--e', type=int, default=640)
+args = ap.parse_args()
+lib = _hip.load()
+dev = torch.device('cuda', 0)
+M, E = args.m, args.e
+shapes = [('qkv', 3 * E, E), ('out', E, E), ('ffn-up', 4 * E, E), ('ffn-down', E, 4 * E)]
+for name, N, K in shapes:
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
+    b = torch.randn(N, device=dev).bfloat16()
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    res = {}
+    for rnd in range(5):
+        for tile in (1, 2):
+            lib.esme_hip_debug_set_gemm_tile(tile)
+            _hip.gemm(a, w, b, out=out)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(50):
+                _hip.gemm(a, w, b, out=out)
+            e.record()
+            torch.cuda.synchronize()
+            res.setdefault(tile, []).append(s.elapsed_time(e) / 50 * 1e3)
+    lib.esme_hip_debug_set_gemm_tile(0)
+    fl = 2.0 * M * N * K
+    line = f'{name:9s} M={M} N={N} K={K}: '
+    for tile in (1, 2):
+        t = sorted(res[tile])[len(res[tile]) // 2]
+        tiles = math.ceil(M / (128 * tile)) * math.ceil(N / (128 * tile))
+        line += f' tile{tile}: {t:6.1f} us ({fl / t / 1e6:5.0f} TF/s, {tiles} tiles)'
+    print(line)
