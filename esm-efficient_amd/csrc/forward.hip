@@ -20,7 +20,7 @@ inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
 int64_t carve(const esme_model_desc_t* m, int64_t T, Ws* w, char* base) {
     const int64_t Ea = (int64_t)m->heads * m->head_pad, Ep = m->phys_dim;
     const int64_t mid_cols = m->ffn_dim;                    // output columns of the FFN up-projection (F)
-    const int64_t nblk = (Ep + 63) / 64;
+    const int64_t nblk = esme_hip_gemm_stats_blocks(T, (int)Ep);
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += align256(bytes); return base ? base + o : (char*)nullptr; };
     char* qkv = take(T * 3 * Ea * 2);
@@ -56,7 +56,7 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
     carve(m, T, &w, (char*)workspace);
     const int Ep = m->phys_dim, E = m->embed_dim, H = m->heads, dp = m->head_pad;
     const int64_t Ea = (int64_t)H * dp;
-    const int nblk = (Ep + 63) / 64;
+    const int nblk = esme_hip_gemm_stats_blocks(T, Ep);
     const float scale = m->softmax_scale;
     const bool rot_fused = m->rotary && !m->qk_norm && (dp == 16 || dp == 32 || dp == 64) && Ea % 32 == 0;
     int rc;

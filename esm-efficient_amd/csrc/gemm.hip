@@ -24,7 +24,7 @@ namespace esme {
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
-    static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64), "row statistics are emitted by the residual epilogue");
+    static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64 && (WN == 2 || WN == 4)), "row statistics are emitted by the residual epilogue");
     static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
                   "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
     constexpr int NW = WM * WN;               // waves per block
@@ -196,22 +196,49 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         if (tid < BM) {
             int64_t m = m0 + tid;
             m = m < a.M ? m : a.M - 1;
-            // Canonical order: the producers emit one partial per 64 columns whatever their tile size, and the
-            // partials are added strictly left to right, so a row's statistics (hence its logits) do not depend on the
-            // tile configuration, i.e. on how many rows the batch has.  Loads are batched (independent), adds are not.
+            // Canonical association, so that a row's statistics (hence its logits) do not depend on the tile configuration
+            // of the producer, i.e. on how many rows the batch has: 64-column wave partials are combined as a tree inside
+            // a 256-column block, ((w0 + w1) + (w2 + w3)), and 256-column blocks are added strictly left to right.  A
+            // 256 x 256 producer emits one partial per 256 columns (its four column waves combined in that order), a
+            // 128 x 128 producer one per 128 columns (w0 + w1): in that case (ln_nblk > ceil(K / 256)) pairs are combined
+            // here first.  K of this GEMM = the width the statistics were taken over.
             float s1 = 0.f, s2 = 0.f;
             const f32x2* pp = reinterpret_cast<const f32x2*>(a.ln_partial) + m;
-            int b = 0;
-            for (; b + 10 <= a.ln_nblk; b += 10) {
-                f32x2 p[10];
+            const int n256 = (a.K + 255) >> 8;
+            if (a.ln_nblk > n256) {                             // 128-column partials: pair them up
+                int b = 0;
+                for (; b + 10 <= a.ln_nblk; b += 10) {          // 10 independent loads in flight, not a serial latency chain
+                    f32x2 p[10];
 #pragma unroll
-                for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
+                    for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
 #pragma unroll
-                for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
-            }
-            for (; b < a.ln_nblk; ++b) {
-                const f32x2 p = pp[(int64_t)b * a.stat_ld];
-                s1 += p[0]; s2 += p[1];
+                    for (int u = 0; u < 10; u += 2) { s1 += p[u][0] + p[u + 1][0]; s2 += p[u][1] + p[u + 1][1]; }
+                }
+                for (; b + 2 <= a.ln_nblk; b += 2) {
+                    const f32x2 p0 = pp[(int64_t)b * a.stat_ld], p1 = pp[(int64_t)(b + 1) * a.stat_ld];
+                    s1 += p0[0] + p1[0]; s2 += p0[1] + p1[1];
+                }
+                if (b < a.ln_nblk) { const f32x2 p = pp[(int64_t)b * a.stat_ld]; s1 += p[0]; s2 += p[1]; }
+            } else {
+                int b = 0;
+                for (; b + 10 <= a.ln_nblk; b += 10) {
+                    f32x2 p[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
+                }
+                for (; b + 5 <= a.ln_nblk; b += 5) {
+                    f32x2 p[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
+                }
+                for (; b < a.ln_nblk; ++b) {
+                    const f32x2 p = pp[(int64_t)b * a.stat_ld];
+                    s1 += p[0]; s2 += p[1];
+                }
             }
             const float inv = 1.0f / (float)a.ln_dim;
             const float mean = s1 * inv;
@@ -439,6 +466,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
         const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
+        f32x2* blkst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);      // STATS: [wn][tile row] partial sums
         if (col_ok || STATS) {
 #pragma unroll
             for (int it = 0; it < WTM / RPI; ++it) {
@@ -458,14 +486,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);      // lane ^ 1
                     t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);      // lane ^ 2
                     t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);    // lane -> 7 - lane (other quad)
-                    // one partial per (64-column block, row), written by the block's wave itself: the layout
-                    // (N/64, M, 2) is the same for every tile configuration (see the consumer's canonical sum)
-                    if (ch == 0 && m < a.M && nw0 < a.N)
-                        *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(nw0 >> 6) * a.stat_ld + m)) = f32x2{t1, t2};
+                    if (ch == 0) blkst[wn * BM + wm * WTM + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
                 }
             }
         }
         ESME_TRACE_MARK(6);
+        if constexpr (STATS) {
+            // the block's column waves combine as a tree ((w0 + w1) + (w2 + w3)): the canonical association the consumer
+            // assumes (see the LN-fold prologue), whatever the tile width
+            __syncthreads();
+            if (tid < BM && m0 + tid < a.M) {
+                f32x2 acc2 = blkst[tid];
+                acc2[0] += blkst[BM + tid][0]; acc2[1] += blkst[BM + tid][1];
+                if constexpr (WN == 4) {
+                    f32x2 hi2 = blkst[2 * BM + tid];
+                    hi2[0] += blkst[3 * BM + tid][0]; hi2[1] += blkst[3 * BM + tid][1];
+                    acc2[0] += hi2[0]; acc2[1] += hi2[1];
+                }
+                *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(n0 / BN) * a.stat_ld + m0 + tid)) = acc2;
+            }
+        }
         ESME_TRACE_MARK(7);
         ESME_TRACE_REAL(9);
         return;
@@ -523,7 +563,7 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0);
+    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
     const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
@@ -602,8 +642,8 @@ static int pick_tile(int64_t M, int N) {
 }
 
 extern "C" int esme_hip_gemm_stats_blocks(int64_t M, int N) {
-    (void)M;                         // one partial per 64 output columns, whatever tile the launch picks
-    return (N + 63) / 64;
+    const int bn = pick_tile(M, N) == 2 ? 256 : 128;      // one partial per column tile of the configuration the launch picks
+    return (N + bn - 1) / bn;
 }
 
 extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,

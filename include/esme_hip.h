@@ -162,13 +162,14 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              {sum, sum of squares} as emitted by stats_out / esme_hip_row_sums (ln_nblk = 1).
  *              Replaces the nn.LayerNorm in front of q/k/v (esme/attention.py:75,92) and of the FFN
  *              (esme/attention.py:222,230) without writing or reading a normalised copy of x;
- *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per block of 64 output columns, the sum
- *              and sum of squares of the bf16-ROUNDED output, float (nblk, M, 2) with
- *              nblk = esme_hip_gemm_stats_blocks(M, N) = N / 64: what the next LN-folding GEMM reduces
- *              its row statistics from (pass it as ln_partial / ln_nblk).  The block width and the
- *              consumer's summation order (block 0, 1, 2, ... strictly left to right) are fixed, so a
- *              row's statistics do not depend on the tile configuration a launch picks, i.e. on the
- *              number of rows in the batch: a sequence's logits are bit-identical alone or packed. */
+ *  - stats_out != NULL (ESME_EPI_RESIDUAL only): per row and per column tile of the launch (256 or 128 columns,
+ *              whichever configuration the shape picks), the sum and sum of squares of the bf16-ROUNDED output,
+ *              float (nblk, M, 2) with nblk = esme_hip_gemm_stats_blocks(M, N): what the next LN-folding GEMM
+ *              reduces its row statistics from (pass it as ln_partial / ln_nblk).  The association is canonical --
+ *              64-column wave partials combine as ((w0 + w1) + (w2 + w3)) inside a 256-column block, blocks add
+ *              left to right, and a consumer that is handed 128-column partials pairs them up first -- so a row's
+ *              statistics do not depend on the tile configuration a launch picks, i.e. on the number of rows in
+ *              the batch: a sequence's logits are bit-identical alone or packed. */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;
@@ -185,7 +186,7 @@ typedef struct esme_gemm_fusion {
     int rot_cols;
 } esme_gemm_fusion_t;
 
-/* number of 64-column blocks a residual-epilogue GEMM of this shape writes to stats_out (= ceil(N / 64)) */
+/* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
 int esme_hip_gemm_stats_blocks(int64_t M, int N);
 
 int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias,

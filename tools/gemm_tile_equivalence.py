@@ -22,6 +22,9 @@ for tile in (1,2):
     res[tile]=(plain,gelu,y,part,gelu2)
 lib.esme_hip_debug_set_gemm_tile(0)
 for name,a,b_ in zip(('plain','gelu+lnf','resid','stats','gelu2 via stats'),res[1],res[2]):
+    if name == 'stats':      # (N/128, M, 2) vs (N/256, M, 2): different granularity by design; the consumers must agree (next line)
+        print(name, 'blocks', a.shape[0], b_.shape[0], 'row totals close', bool(torch.allclose(a.sum(0), b_.sum(0), rtol=1e-5, atol=1e-3)))
+        continue
     print(name, 'bit-equal', bool(torch.equal(a,b_)), 'max diff', float((a.float()-b_.float()).abs().max()))
 # fused QKV: LN fold + rotary epilogue, ragged positions
 from esme.rotary import RotaryEmbedding
