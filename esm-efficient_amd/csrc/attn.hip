@@ -497,16 +497,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             }
         };
         // P, packed to bf16, and four partial row sums of block bs against the reference maximum -nm.  Pair p covers
-        // scores (kbk, r), (kbk, r + 1); the empty asm pins the pair's instructions where they are written (between two
-        // MFMAs): hipcc otherwise sinks the softmax below the last MFMA of the phase, next to its consumers.
+        // scores (kbk, r), (kbk, r + 1).  The three steps of a pair -- x = s*c - m (2 v_fma), P = exp2(x) (2 v_exp),
+        // sum + pack (2 v_add + 1 v_cvt_pk) -- are SKEWED over three consecutive MFMA slots (slot m: fma of pair m+1, exp
+        // of pair m, sum/pack of pair m-1), so no instruction of a slot waits for another of the same slot: an in-order
+        // wave otherwise stalls on the fma -> exp -> add chain (transcendental latency) in every slot.  The empty asm pins
+        // the slot's instructions where they are written (between two MFMAs): hipcc otherwise sinks the softmax below
+        // the last MFMA of the phase, next to its consumers.
         float ps0, ps1, ps2, ps3;
-        auto exp_pair = [&](const int p, const float nm) {
+        float xa0, xa1, pa0 = 0.f, pa1 = 0.f;               // in flight: x of the next pair, P of the previous pair
+        auto pair_fma = [&](const int p, const float nm) {
             const int kbk = p >> 3, r = (2 * p) & 15;
-            const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[bs][kbk][r], c, nm));
-            const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[bs][kbk][r + 1], c, nm));
-            pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack_bf16(p0, p1);
-            if (p & 1) { ps2 += p0; ps3 += p1; asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps2), "+v"(ps3)); }
-            else { ps0 += p0; ps1 += p1; asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps0), "+v"(ps1)); }
+            xa0 = fmaf(sacc[bs][kbk][r], c, nm);
+            xa1 = fmaf(sacc[bs][kbk][r + 1], c, nm);
+        };
+        auto pair_sum_pack = [&](const int p, const float q0, const float q1) {
+            const int kbk = p >> 3, r = (2 * p) & 15;
+            pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack_bf16(q0, q1);
+            if (p & 1) { ps2 += q0; ps3 += q1; } else { ps0 += q0; ps1 += q1; }
+        };
+        auto softmax_slot = [&](const int m, const float nm) {      // m = 0..15
+            const float x0 = xa0, x1 = xa1;                  // x of pair m (from slot m - 1)
+            const float q0 = pa0, q1 = pa1;                  // P of pair m - 1
+            if (m + 1 < 16) pair_fma(m + 1, nm);
+            pa0 = __builtin_amdgcn_exp2f(x0);
+            pa1 = __builtin_amdgcn_exp2f(x1);
+            if (m >= 1) pair_sum_pack(m - 1, q0, q1);
+            const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
+            asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(xa0), "+v"(xa1), "+v"(pa0), "+v"(pa1));
         };
         // exact tile maximum of block bs's rows (both key halves), in log2 units
         auto tile_max = [&]() -> float {
@@ -547,16 +564,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             const float tmc = tile_max();
             if (__any(tmc > mc[bs] + thr)) rescale_to(tmc);  // thr = 0: the maximum is always exact
         }
-        // 16 x { 1 MFMA (+ the LDS read of the fragment two MFMAs ahead), one pair of scores: 7 VALU }
+        // 16 x { 1 MFMA (+ the LDS read of the fragment two MFMAs ahead), 7 VALU of three different score pairs }
         ps0 = ps1 = ps2 = ps3 = 0.f;
         const float nm = -mc[bs];
+        pair_fma(0, nm);
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             mfma_step(m);
             __builtin_amdgcn_sched_barrier(0);
-            exp_pair(m, nm);
+            softmax_slot(m, nm);
             __builtin_amdgcn_sched_barrier(0);
         }
+        pair_sum_pack(15, pa0, pa1);
         const float psum = (ps0 + ps1) + (ps2 + ps3);
         if (__any(!(psum < 1e30f))) ovf = 1;                 // overflow (inf / NaN included): the work item is redone exactly
         lrun[bs] += psum;
@@ -641,7 +660,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT);
                 phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT);
             }
-            __syncthreads();
+            // End of iteration t.  NOT __syncthreads(): with an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of
+            // the barrier, i.e. every key tile would wait for the K / V prefetch issued at its own top (a full memory latency
+            // per tile: measured 4 000 cycles per iteration with or without any softmax work).  What must have landed here is
+            // the K tile t+2 (LDS-DMA issued in iteration t-1, first read in phase B of iteration t+1): everything this
+            // iteration issued after it -- 4 V loads on the V-staging waves, KI LDS-DMAs -- may stay in flight.
+            if (t + 3 < nt) {
+                if (do_v) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 + KI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
         }
         if (wave_active) {                          // drain: O^T(b1) += V(nt-1) P(b1, nt-1)
             const char* Vs = smem + ((nt - 1) & 3) * SLOT;

@@ -11,11 +11,15 @@ from esme import _hip
 ap = argparse.ArgumentParser()
 ap.add_argument('--m', type=int, default=8192)
 ap.add_argument('--e', type=int, default=640)
+ap.add_argument('--ffn', type=int, default=0)
+ap.add_argument('--tiles', default='1,2,3')
 args = ap.parse_args()
 lib = _hip.load()
 dev = torch.device('cuda', 0)
 M, E = args.m, args.e
-shapes = [('qkv', 3 * E, E), ('out', E, E), ('ffn-up', 4 * E, E), ('ffn-down', E, 4 * E)]
+F = args.ffn or 4 * E
+TILES = [int(t) for t in args.tiles.split(',')]
+shapes = [('qkv', 3 * E, E), ('out', E, E), ('ffn-up', F, E), ('ffn-down', E, F if not args.ffn else F // 2)]
 for name, N, K in shapes:
     a = torch.randn(M, K, device=dev).bfloat16()
     w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
@@ -23,7 +27,7 @@ for name, N, K in shapes:
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     res = {}
     for rnd in range(5):
-        for tile in (1, 2):
+        for tile in TILES:
             lib.esme_hip_debug_set_gemm_tile(tile)
             _hip.gemm(a, w, b, out=out)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,8 +40,9 @@ for name, N, K in shapes:
     lib.esme_hip_debug_set_gemm_tile(0)
     fl = 2.0 * M * N * K
     line = f'{name:9s} M={M} N={N} K={K}: '
-    for tile in (1, 2):
+    for tile in TILES:
         t = sorted(res[tile])[len(res[tile]) // 2]
-        tiles = math.ceil(M / (128 * tile)) * math.ceil(N / (128 * tile))
+        bm, bn = {1: (128, 128), 2: (256, 256), 3: (256, 128)}[tile]
+        tiles = math.ceil(M / bm) * math.ceil(N / bn)
         line += f' tile{tile}: {t:6.1f} us ({fl / t / 1e6:5.0f} TF/s, {tiles} tiles)'
     print(line)
