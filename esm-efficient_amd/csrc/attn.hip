@@ -324,13 +324,13 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
 // =============================================================================================
 // Head dim 64: software-pipelined ("ping-pong") kernel.
 //
-// Same math, LDS images and MFMA operand layouts as attn_varlen_kernel above; what changes is the
-// schedule and the amount of VALU work per score (the first-generation kernel is VALU-bound: ~210
+// Same math and MFMA operand layouts as attn_varlen_kernel above; what changes is the schedule, the data
+// path into LDS and the amount of VALU work per score (the first-generation kernel is VALU-bound: ~210
 // vector instructions per 32 x 64 block of scores against 16 MFMAs).
 //
 // * A wave owns TWO 32-row query blocks b0, b1 and runs them half a key tile out of phase, so that every
-//   softmax has the 16 MFMAs of the OTHER block issued between its instructions (one MFMA + one LDS
-//   fragment read per 7 VALU instructions, prescribed with sched_group_barrier):
+//   softmax has the 16 MFMAs of the OTHER block issued between its instructions (one MFMA + its LDS
+//   fragment reads per 7 VALU instructions, pinned with sched_barrier + empty asm statements):
 //
 //     phase A(t):  softmax(b0, tile t)   ||   S^T(b1, t)   = K_t     Q_b1^T       (8 MFMA)
 //                                             O^T(b1)     += V_t-1^T P(b1, t-1)^T  (8 MFMA)
@@ -341,20 +341,31 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
 //   tiles compute P = exp2(s*c - m) WITHOUT looking for the tile maximum (16 v_max3 + exchange + compare
 //   per block) -- fp32 / bf16 hold P up to 2^127, the bf16 rounding of P is relative, O and l accumulate
 //   in fp32, so any finite P is as accurate as a P <= 1.  Only overflow must be caught: a row sum that is
-//   not < 1e30 (inf / NaN included) sends the wave through the exact path for that tile (true tile
-//   maximum, rescale of O and l, P recomputed from the still-intact scores).  spec = 0 is the classic
-//   online softmax with the defer-max threshold `thr` (thr = 0: a row's maximum is always exact).
-// * The last, partial key tile has its own instantiation of the phase (hipcc if-converts a run-time
-//   `if (tail)` mask into 63 selects executed on EVERY tile).
-// * K / V tiles are fetched with raw buffer loads whose descriptor ends at the sequence's last row: rows
-//   past the end read as zeros by hardware bounds checking, no per-load clamping or 64-bit address math.
+//   not < 1e30 (inf / NaN included) makes the WORKGROUP redo its work item with the classic online softmax
+//   (same code, need_max on every tile).  spec = 0 is the classic online softmax with the defer-max
+//   threshold `thr` (thr = 0: a row's maximum is always exact).
+// * K AND V tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds: no VGPR round trip, no ds_write, no
+//   transposition pass): K as [key][d] rows for ds_read_b128 fragments, V as [key][d] rows as well -- the
+//   V^T fragments of the second MFMA are gathered by ds_read_b64_tr_b16 (the hardware 4x4 transposing
+//   read).  The descriptors end at the sequence's last row: rows past the end read as zeros.
+// * The DMA instructions are inline asm, NOT the builtin: hipcc guards every LDS read that follows an
+//   LDS-DMA it knows of with s_waitcnt vmcnt(0) (possible alias), which made every key tile wait a memory
+//   latency for a prefetch that is needed two tiles later.  The kernel counts instead: each wave waits
+//   for its own DMAs of the PREVIOUS iteration (s_waitcnt vmcnt(n issued in this one)) right before the
+//   one s_barrier that ends a key tile.  The pieces (1 KB per wave instruction, 60-180 cycles of issue
+//   each) are issued one at a time from inside the phases, under a running MFMA.
+// * What bounds it (tools/lab/mfma_issue_probe.hip, tools/attn_power_probe.py): with 2 waves per SIMD a
+//   stream of {1 MFMA, 1-2 LDS reads, 7 VALU of this mix} runs at 48 cycles per MFMA (v_exp_f32 = 8,
+//   other VALU = 4 cycles of the SIMD's one VALU port; v_pk_*_f32 are slower than two scalar ops), the
+//   loop measures 60; and the kernel runs AT the 1 400 W package power cap (2.0 GHz instead of 2.4; all-zero
+//   inputs: 2.39 GHz, +20-25 % throughput), so removed stall cycles come back only in part.
 //
-// LDS: a ring of 4 slots (K tile + V^T tile, 16 KB each); iteration t reads slots t-1, t, t+1 and fills
-// slot t+2 from registers loaded one iteration earlier, ONE barrier per key tile.  A workgroup is NW
-// waves = NW*64 query rows of one (sequence, head): NW = 8 covers a 500-residue protein in one workgroup
-// (K/V staged and fetched once), NW = 4 runs two workgroups per CU.  The row sum exchange with lane^32 is
-// a v_permlane32_swap (VALU), not an LDS permute; results leave through a wave-private LDS slab as whole
-// 128-byte rows (16 B per lane).
+// LDS: a ring of 4 slots (K tile + V tile, 16 KB each); iteration t reads K of slots t, t+1 and V of slots
+// t-1, t, and prefetches K tile t+3 / V tile t+2; ONE barrier per key tile.  A workgroup is NW waves =
+// NW*64 query rows of one (sequence, head): NW = 4 runs two workgroups per CU (one's prologue / epilogue
+// overlaps the other's main loop), NW = 8 stays behind the tuning hook.  The row sum exchange with lane^32
+// is a v_permlane32_swap (VALU), not an LDS permute; results leave through a wave-private LDS slab as
+// whole 128-byte rows (16 B per lane).
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
     constexpr int D = 64, DS = 4, NT = NW * 64;
@@ -384,8 +395,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
     // K / V of this (sequence, head) behind buffer descriptors that end with the head's slice of row S-1
     const unsigned int kv_bytes = ((unsigned int)(S - 1) * ld + D) * 2u;
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.k + (int64_t)s0 * a.ld + h * D), 0, (int)kv_bytes, 0x00020000);
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.v + (int64_t)s0 * a.ld + h * D), 0, (int)kv_bytes, 0x00020000);
+    // Raw descriptor words (base, stride 0, bytes, DATA_FORMAT 32): the LDS-DMA is issued from inline asm (below).
+    auto make_rsrc = [&](const u16* p) -> u32x4 {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        return u32x4{(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v),
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)(v >> 32) & 0xffffu)),
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)kv_bytes), 0x00020000u};
+    };
+    const u32x4 krs = make_rsrc(a.k + (int64_t)s0 * a.ld + h * D);
+    const u32x4 vrs = make_rsrc(a.v + (int64_t)s0 * a.ld + h * D);
+    // One LDS-DMA instruction: 64 lanes x 16 B from (descriptor, per-lane byte offset) to LDS bytes [dst, dst + 1024).
+    // Inline asm ON PURPOSE: hipcc guards every LDS read that follows an LDS-DMA it knows about with `s_waitcnt vmcnt(0)`
+    // (it cannot prove the read does not alias the DMA's target), i.e. each key tile would wait a full memory latency for
+    // the prefetch of a tile that is needed two iterations later.  The kernel does its own accounting instead: counted
+    // vmcnt + s_barrier at the end of every key tile.  M0 (the LDS destination) is saved and restored: hipcc owns it.
+    auto dma16 = [&](const u32x4 rs, const unsigned int voff, const char* dst) {
+        const unsigned int d = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)dst);
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(d), "s"(rs) : "memory");
+    };
 
     // ---- Q fragments of the wave's two q-blocks (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 ..]
     bf16x8 qf[2][DS];
@@ -400,62 +429,58 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             qf[bb][ds] = *reinterpret_cast<const bf16x8*>(qb + (qc * ld + ds * 16 + hi * 8));
     }
 
-    // ---- staging.  K tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, 1 KB = 8 rows per wave
-    // instruction, no VGPR round trip, no ds_write): the LDS image is lane-linear, so the chunk swizzle is applied to the
-    // per-lane SOURCE address; rows past the sequence end read as zeros (descriptor bounds).  V tiles go through
-    // registers (threads 0..255: one 4x4 block each, transposed with v_perm into the V^T image).
-    constexpr int KI = 8 / NW;                                   // K DMA instructions per wave per tile (2 or 1)
+    // ---- staging.  K and V tiles both go HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, 1 KB = 8 rows per
+    // wave instruction, no VGPR round trip, no ds_write): the LDS image is lane-linear, so the chunk swizzle is applied
+    // to the per-lane SOURCE address; rows past the sequence end read as zeros (descriptor bounds).  V stays row-major
+    // ([key][d], as in HBM): the V^T fragments of the second MFMA are gathered by ds_read_b64_tr_b16 (below).
+    constexpr int KI = 8 / NW;                                   // DMA instructions per wave per K (or V) tile (2 or 1)
     const unsigned int tile_bytes = (unsigned int)KT * ld * 2u;
-    unsigned int kg0;                                            // byte offset of this lane's K chunk inside a tile (piece 0)
+    unsigned int kg0, vg0;                                       // byte offset of this lane's chunk inside a tile (piece 0)
     {
         const int r = wave * 8 + (lane >> 3), pch = lane & 7;    // LDS row / chunk position this lane fills
         kg0 = ((unsigned int)r * ld + ((pch ^ kswz<D>(r)) * 8)) * 2u;
+        vg0 = ((unsigned int)r * ld + ((pch ^ (((r >> 1) & 1) << 2)) * 8)) * 2u;   // V: 64-B halves swapped on rows 2, 3 (mod 4)
     }
-    const unsigned int kg_step = (unsigned int)(NW * 8) * ld * 2u;   // piece i: rows + NW*8 (same swizzle: NW*8 is a multiple of 16)
+    const unsigned int kg_step = (unsigned int)(NW * 8) * ld * 2u;   // piece i: rows + NW*8 (same swizzles: NW*8 is a multiple of 16)
     auto dma_k = [&](int tile, char* slot) {
         const unsigned int base = (unsigned int)tile * tile_bytes + kg0;
 #pragma unroll
         for (int i = 0; i < KI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lptr_t)(slot + (i * NW + wave) * 1024), 16, base + i * kg_step, 0, 0, 0);
+            dma16(krs, base + i * kg_step, slot + (i * NW + wave) * 1024);
     };
-    const bool do_v = wave < 4;                                  // wave-uniform
-    const int vrest = (lane >> 4) | ((wave & 3) << 2);
-    const int v_dq = (lane & 3) | ((vrest & 3) << 2);           // 4-wide column group of V (0..15)
-    const int v_kq = ((lane >> 2) & 3) | ((vrest >> 2) << 2);   // 4-key group (0..15)
-    const unsigned int vg0 = ((unsigned int)(v_kq * 4) * ld + v_dq * 4) * 2u, vg_step = ld * 2u;
-    const int v_ch = v_kq >> 1, v_sub = (v_kq & 1) * 8;
-    // the four transposed V^T rows of a 4x4 block sit at vl0, vl0 + 128, vl1, vl1 + 128
-    const int vl0 = K_BYTES + (v_dq * 4) * 128 + ((v_ch ^ ((v_dq * 2) & 7)) << 4) + v_sub;
-    const int vl1 = K_BYTES + (v_dq * 4 + 2) * 128 + ((v_ch ^ ((v_dq * 2 + 1) & 7)) << 4) + v_sub;
-    struct Stage { u32x2 v[4]; };
-    auto load_v = [&](Stage& st, int tile) {
-        if (do_v) {
-            const unsigned int base = (unsigned int)tile * tile_bytes + vg0;
+    auto dma_v = [&](int tile, char* slot) {
+        const unsigned int base = (unsigned int)tile * tile_bytes + vg0;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) st.v[kk] = __builtin_amdgcn_raw_buffer_load_b64(vrs, base + kk * vg_step, 0, 0);
-        }
-    };
-    auto store_v = [&](const Stage& st, char* slot) {
-        if (do_v) {
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {               // 4x4 transpose of 16-bit elements
-                const int w = dd >> 1;
-                const unsigned int sel = (dd & 1) ? 0x07060302u : 0x05040100u;
-                u32x2 out = {__builtin_amdgcn_perm(st.v[1][w], st.v[0][w], sel), __builtin_amdgcn_perm(st.v[3][w], st.v[2][w], sel)};
-                *reinterpret_cast<u32x2*>(slot + ((dd & 2) ? vl1 : vl0) + (dd & 1) * 128) = out;
-            }
-        }
+        for (int i = 0; i < KI; ++i)
+            dma16(vrs, base + i * kg_step, slot + K_BYTES + (i * NW + wave) * 1024);
     };
 
     // ---- per-lane LDS fragment offsets.  K row fed to MFMA row i: bits 2 and 3 of i swapped (P lands in the
     // B-operand layout of the second MFMA); the chunk swizzles do not depend on the 32-row block.
     const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
-    int kfo[4], vfo[4];
+    int kfo[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        kfo[i] = krow_perm * 128 + (((i * 2 + hi) ^ ((krow_perm >> 1) & 7)) << 4);
-        vfo[i] = K_BYTES + l31 * 128 + (((i * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+    for (int i = 0; i < 4; ++i) kfo[i] = krow_perm * 128 + (((i * 2 + hi) ^ ((krow_perm >> 1) & 7)) << 4);
+    // V^T fragment (A operand of O^T += V^T P^T: row = d, k = key) of 32-d block db, 16-key step ks: two transposing
+    // reads of 4 keys each.  ds_read_b64_tr_b16 works on 16-lane groups: lane 4j + p of a group SUPPLIES the 8 bytes
+    // V[key j][4p .. 4p+3] of a [4 keys][16 d] block, lane c RECEIVES column c (V[key 0..3][c]).  Lane (l31, hi) of the
+    // MFMA wants d = l31, keys hi*8 + 0..7: group (lane >> 4) & 1 covers d 0..15 / 16..31, so this lane supplies row
+    // hi*8 + j (+4 for the second read), bytes gsel*32 + p*8 of the 64-B half that holds block db (halves swapped on rows
+    // with bit 1 set: the four 64-B row pieces of a 32-lane group fall into four different 16-bank quarters).
+    int vb[2];
+    {
+        const int j = (lane & 15) >> 2, p = lane & 3, gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) vb[db] = K_BYTES + (hi * 8 + j) * 128 + ((db ^ (j >> 1)) * 64) + gsel * 32 + p * 8;
     }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto vfrag = [&](const char* Vs, const int db, const int ks) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4* ltr_t;
+        const char* p = Vs + vb[db] + ks * 2048;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p));
+        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p + 512));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
 
     f32x16 oacc[2][2], sacc[2][2];
     u32x4 pw[2][2][2];                 // P of block bb as packed bf16: [bb][32-key block][16-key step]
@@ -469,13 +494,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // Consecutive MFMAs alternate between the two accumulators of a contraction (32-row blocks of O^T, 32-key blocks of
     // S^T): an MFMA never follows one on the same accumulator with VALU instructions in between (a 43-cycle cliff).
     auto frag = [&](int m, const char* Ks, const char* Vs) -> bf16x8 {
-        if (m < 8) return *reinterpret_cast<const bf16x8*>(Vs + (m & 1) * 4096 + vfo[m >> 1]);
+        if (m < 8) return vfrag(Vs, m & 1, m >> 1);
         return *reinterpret_cast<const bf16x8*>(Ks + (m & 1) * 4096 + kfo[(m - 8) >> 1]);
     };
 
     // One phase: softmax of block BS on its finished scores, interleaved with the 16 MFMAs of block BM.
     // SPEC: speculative softmax (no tile maximum; see the header).  TAIL: mask the keys past the sequence end.
-    auto phase = [&](auto BS_, auto BM_, const bool need_max, const bool tail, const char* Ks, const char* Vs, const int kv0) __attribute__((always_inline)) {
+    auto phase = [&](auto BS_, auto BM_, const bool need_max, const bool tail, const char* Ks, const char* Vs, const int kv0, auto&& hook) __attribute__((always_inline)) {
         constexpr int bs = decltype(BS_)::value, bm = decltype(BM_)::value;
         bf16x8 fr[3];
         fr[0] = frag(0, Ks, Vs);
@@ -573,6 +598,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             mfma_step(m);
             __builtin_amdgcn_sched_barrier(0);
             softmax_slot(m, nm);
+            hook(m);                                         // this wave's share of the prefetch DMAs (issued under an MFMA)
             __builtin_amdgcn_sched_barrier(0);
         }
         pair_sum_pack(15, pa0, pa1);
@@ -589,9 +615,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     const int nt = (S + KT - 1) / KT;
     bool exact = !a.spec;
     for (;;) {
-        // ---- prologue: K tiles 0..2 by LDS-DMA, V tiles 0, 1 through registers (both fetched at once), V tile 2 into the
-        // staging registers, V^T of slot 3 zeroed (phase A of iteration 0 multiplies it by P = 0: no NaN / Inf patterns)
-        Stage st;
+        // ---- prologue: K tiles 0..2 and V tiles 0, 1 by LDS-DMA; V of slot 3 zeroed (phase A of iteration 0 multiplies
+        // it by P = 0: no NaN / Inf patterns)
     #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
             mc[bb] = -1e30f; lrun[bb] = 0.f;
@@ -603,29 +628,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 for (int s = 0; s < 2; ++s) pw[bb][i][s] = u32x4{0u, 0u, 0u, 0u};
             }
         }
-        {
-            Stage st1;
-            load_v(st, 0);
-            if (nt > 1) load_v(st1, 1);
-            dma_k(0, smem);
-            if (nt > 1) dma_k(1, smem + SLOT);
-            if (nt > 2) dma_k(2, smem + 2 * SLOT);
-            store_v(st, smem);
-            if (nt > 1) store_v(st1, smem + SLOT);
-        }
+        dma_k(0, smem);
+        dma_v(0, smem);
+        if (nt > 1) { dma_k(1, smem + SLOT); dma_v(1, smem + SLOT); }
+        if (nt > 2) dma_k(2, smem + 2 * SLOT);
         // The Q fragments are re-defined by an (empty) asm statement here, while no other load is in flight: hipcc's
         // wait-count pass otherwise carries "the Q loads may still be pending" into the loop header and guards their
         // first uses with s_waitcnt vmcnt(3..0) -- which, in steady state, drains the staging loads issued at the top of
         // the same iteration (an HBM latency per key tile; the kernel ran 1.7x slower on long sequences).
         asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]),
                           "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]) : : "memory");
-        if (nt > 2) load_v(st, 2);
         {
             const u32x4 z = {0u, 0u, 0u, 0u};
             char* v3 = smem + 3 * SLOT + K_BYTES;
     #pragma unroll
             for (int i = 0; i < (D * 128) / (NT * 16); ++i) *reinterpret_cast<u32x4*>(v3 + (i * NT + tid) * 16) = z;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the prologue DMAs (hipcc does not know about them)
         __syncthreads();
         if (wave_active) {                      // S^T(b0, tile 0)
     #pragma unroll
@@ -640,37 +659,44 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         // One key tile per iteration: phase A: softmax(b0,t) || S^T(b1,t), O^T(b1) += V(t-1) P(b1,t-1);
         // phase B: softmax(b1,t) || S^T(b0,t+1), O^T(b0) += V(t) P(b0,t).  The loop holds ONE instantiation of the phase
         // pair (several variants in branches of the loop make the register allocator spill ~150 VGPRs).
-        auto stage_next = [&](int t) {
-            // iteration t: V tile t+2 (registers, loaded an iteration ago) -> its slot; fetch V tile t+3 and start the
-            // LDS-DMA of K tile t+3 into its slot (K region of slot t-1: last read in phase A of iteration t-1).  The barrier
-            // that ends the iteration also waits for both (they had the whole iteration to land).
-            if (t + 2 < nt) {
-                store_v(st, smem + ((t + 2) & 3) * SLOT);
-                if (t + 3 < nt) { load_v(st, t + 3); dma_k(t + 3, smem + ((t + 3) & 3) * SLOT); }
-            }
+        // iteration t also starts the LDS-DMA of K tile t+3 (K region of slot t-1: last read in phase A of iteration t-1)
+        // and of V tile t+2 (V region of slot t-2: last read in phase A of iteration t-1); both are first read in phase B
+        // of iteration t+2, two iterations to land.  An LDS-DMA instruction holds its wave for 60-180 cycles until the
+        // memory pipeline has taken it, so the pieces are issued one at a time from inside the phases, each right after an
+        // MFMA (the matrix pipe keeps running); issued together at the top of the iteration they cost ~600 cycles per tile.
+        auto dma_piece = [&](const unsigned int rs_sel, const int tile, char* slot, const int i) {
+            if (rs_sel == 0) dma16(krs, (unsigned int)tile * tile_bytes + kg0 + i * kg_step, slot + (i * NW + wave) * 1024);
+            else dma16(vrs, (unsigned int)tile * tile_bytes + vg0 + i * kg_step, slot + K_BYTES + (i * NW + wave) * 1024);
         };
         for (int t = 0; t < nt; ++t) {
-            stage_next(t);
+            const bool pf_k = t + 3 < nt, pf_v = t + 2 < nt;       // block-uniform
+            char* kslot = smem + ((t + 3) & 3) * SLOT;
+            char* vslot = smem + ((t + 2) & 3) * SLOT;
             if (wave_active) {
                 const char* cur = smem + (t & 3) * SLOT;
                 const char* prv = smem + ((t + 3) & 3) * SLOT;
                 const char* nxt = smem + ((t + 1) & 3) * SLOT;
                 const bool tail = t == nt - 1 && ragged;
                 const bool need_max = exact || t == 0;
-                phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT);
-                phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT);
+                phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT, [&](const int m) {
+                    if (KI == 2) { if (m == 3 && pf_k) dma_piece(0, t + 3, kslot, 0); if (m == 11 && pf_k) dma_piece(0, t + 3, kslot, KI - 1); }
+                    else if (m == 7 && pf_k) dma_piece(0, t + 3, kslot, 0);
+                });
+                phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT, [&](const int m) {
+                    if (KI == 2) { if (m == 3 && pf_v) dma_piece(1, t + 2, vslot, 0); if (m == 11 && pf_v) dma_piece(1, t + 2, vslot, KI - 1); }
+                    else if (m == 7 && pf_v) dma_piece(1, t + 2, vslot, 0);
+                });
+            } else {
+                if (pf_k) dma_k(t + 3, kslot);
+                if (pf_v) dma_v(t + 2, vslot);
             }
             // End of iteration t.  NOT __syncthreads(): with an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of
-            // the barrier, i.e. every key tile would wait for the K / V prefetch issued at its own top (a full memory latency
-            // per tile: measured 4 000 cycles per iteration with or without any softmax work).  What must have landed here is
-            // the K tile t+2 (LDS-DMA issued in iteration t-1, first read in phase B of iteration t+1): everything this
-            // iteration issued after it -- 4 V loads on the V-staging waves, KI LDS-DMAs -- may stay in flight.
-            if (t + 3 < nt) {
-                if (do_v) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 + KI) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
+            // the barrier, i.e. every key tile would wait for the prefetch issued at its own top.  What must have landed
+            // here are the tiles first read in iteration t+1 (K tile t+2, V tile t+1: issued in iteration t-1); the DMAs this
+            // iteration issued may stay in flight.
+            if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * KI) : "memory");
+            else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         if (wave_active) {                          // drain: O^T(b1) += V(nt-1) P(b1, nt-1)
@@ -679,7 +705,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             for (int ks = 0; ks < 4; ++ks)
     #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + db * 4096 + vfo[ks]);
+                    const bf16x8 vf = vfrag(Vs, db, ks);
                     oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks >> 1][ks & 1]),
                                                                           oacc[1][db], 0, 0, 0);
                 }
