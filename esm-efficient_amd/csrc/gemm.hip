@@ -18,6 +18,17 @@
 // only shape requirement is K % 64 == 0.
 #include "gemm.h"
 #include <atomic>
+#include <type_traits>
+
+#ifndef ESME_GEMM_P3N
+#define ESME_GEMM_P3N 4            // eighths of a K-tile's LDS-DMA pieces issued two k-steps early (k-step 3 of the previous tile)
+#endif
+#ifndef ESME_GEMM_K1
+#define ESME_GEMM_K1 0             // 1: the rest is split over k-steps 0 and 1; 0: all of it in k-step 0
+#endif
+#ifndef ESME_GEMM_SPREAD
+#define ESME_GEMM_SPREAD 1      // 0: the round-1 schedule (two bursts of LDS-DMAs per K-tile); kept for A/B builds
+#endif
 
 namespace esme {
 
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
         for (int j = 0; j < FM; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 32 * 128 + coff[ks]);
     };
+#if !ESME_GEMM_SPREAD
     auto mm = [&](const Frag& f) {
 #pragma unroll
         for (int i = 0; i < FN; ++i)
@@ -136,6 +148,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             for (int j = 0; j < FM; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
     };
+#endif
+#if !ESME_GEMM_SPREAD
     auto stage_half = [&](int kt, int buf, int h) {            // half of the LDS-DMA of one K-tile
         char* base = smem + buf * STAGE;
         const int k0 = kt * BK;
@@ -147,7 +161,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0),
                                              (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
     };
+#endif
     static_assert(IA % 2 == 0 && IW % 2 == 0, "stage_half splits the per-thread chunks in two");
+    // One LDS-DMA instruction of a K-tile (piece p of NP = IA + IW per thread).  An LDS-DMA holds its wave for 60-180
+    // cycles until the memory pipeline has taken it; issued four in a row (stage_half) both waves of a SIMD sit in that
+    // stall at the same time and the matrix pipe drains.  The main loop therefore issues the pieces ONE at a time, each
+    // behind an MFMA, spread over three of the four k-steps (mm_dma below).
+    constexpr int NP = IA + IW;
+    auto stage_piece = [&](int kt, int buf, int p) {
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * BK;
+        if (p < IA) __builtin_amdgcn_global_load_lds((gptr_t)(srcA[p] + k0), (lptr_t)(base + (p * NW + wave) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)(srcW[p - IA] + k0),
+                                              (lptr_t)(base + A_ROWS_BYTES + ((p - IA) * NW + wave) * 1024), 16, 0, 0);
+    };
     f32x2* lnst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);
     int* lpos = reinterpret_cast<int*>(smem + 2 * STAGE + BM * 8);       // rotary: position of each tile row
     f32x4* c1s = reinterpret_cast<f32x4*>(smem + 2 * STAGE + BM * 12);    // LN fold: c1 / c2 of the tile's columns
@@ -257,6 +284,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     ESME_TRACE_MARK(1);
     Frag f0, f1;
     rd(f0, smem, 0);
+#if ESME_GEMM_SPREAD
+    // One k-step: the FN*FM MFMAs on fragments f, with -- one instruction behind each MFMA -- the ds_read_b128s of the NEXT
+    // k-step's fragments (into nf) and this k-step's share of the LDS-DMA pieces.  Issued as bursts (6 reads, then 8
+    // MFMAs; 4 DMAs in a row) the same instructions cost the loop 12 % (reads) + 1-10 % (DMAs) of the matrix pipe:
+    // both waves of a SIMD run the same code in lockstep, so both sit in the burst at the same time
+    // (tools/lab/dma_role_probe.hip: 2 374 -> 2 103 cycles per K-tile for the reads alone).
+    // Pieces [0, P3) of a K-tile are issued during k-step 3 of the iteration TWO tiles earlier (right after the barrier
+    // that frees their buffer), [P3, P0) during k-step 0 and [P0, NP) during k-step 1 of the previous iteration.
+    constexpr int P3 = (NP * ESME_GEMM_P3N) / 8, P0 = ESME_GEMM_K1 ? P3 + (NP - P3 + 1) / 2 : NP;
+    static_assert(FN + FM <= FN * FM, "one fragment read behind each MFMA");
+    auto kstep = [&](const Frag& f, Frag& nf, const char* nbase, const int nks, const bool rd_on,
+                     const bool on, const int kt, const int buf, auto PF, auto PL) {
+        constexpr int pf = decltype(PF)::value, pl = decltype(PL)::value, cnt = pl - pf, total = FN * FM;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
+                const int m = i * FM + j;
+                if (rd_on) {
+                    if (m < FN) nf.w[m] = *reinterpret_cast<const bf16x8*>(nbase + rowW + m * 32 * 128 + coff[nks]);
+                    else if (m < FN + FM) nf.a[m - FN] = *reinterpret_cast<const bf16x8*>(nbase + rowA + (m - FN) * 32 * 128 + coff[nks]);
+                }
+#pragma unroll
+                for (int q = 0; q < (cnt > 0 ? cnt : 0); ++q)
+                    if (m == ((2 * q + 1) * total) / (2 * (cnt > 0 ? cnt : 1)) && on) stage_piece(kt, buf, pf + q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    using std::integral_constant;
+    if (KT > 1) {
+#pragma unroll
+        for (int p = 0; p < P3; ++p) stage_piece(1, 1, p);        // lands long before the first barrier of the loop
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const char* base = smem + buf * STAGE;
+        const bool more = kt + 1 < KT, more2 = kt + 2 < KT;
+        if (!more) rot_prefetch(buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(f0, f1, base, 1, true, more, kt + 1, buf ^ 1, integral_constant<int, P3>{}, integral_constant<int, P0>{});
+        if (!more) rot_prefetch(buf ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(f1, f0, base, 2, true, more, kt + 1, buf ^ 1, integral_constant<int, P0>{}, integral_constant<int, NP>{});
+        kstep(f0, f1, base, 3, true, false, 0, 0, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        __syncthreads();                      // K-tile t+1 landed; every wave's reads of tile t are done
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(f1, f0, smem + (buf ^ 1) * STAGE, 0, more, more2, kt + 2, buf, integral_constant<int, 0>{}, integral_constant<int, P3>{});
+    }
+#else
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         const char* base = smem + buf * STAGE;
@@ -284,6 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         mm(f1);
         __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     // No barrier here: every wave finished its last LDS fragment reads before the barrier inside the final
     // iteration (the k-step-3 fragments are read ahead of it and nothing is read after it), so the stage
     // memory is already free for the epilogue slabs.

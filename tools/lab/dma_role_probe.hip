@@ -1,0 +1,121 @@
+// LDS-DMA issue-cost probe (gfx950): 8 waves per workgroup (2 per SIMD), one workgroup per CU, a GEMM-like K loop of
+// 32 MFMAs per wave per "K-tile" (+ 24 ds_read_b128), 64 LDS-DMA instructions (64 KB) per K-tile per workgroup, one
+// vmcnt(0) + barrier per K-tile.  How the 64 DMAs are issued:
+//   0: none   1: 8 per wave, two bursts of 4   2: 8 per wave, one behind every 3rd MFMA
+//   3: alternating loader: one wave of each SIMD issues 16 (behind its first 16 MFMAs), its partner none; roles swap per tile
+//   4: as 3, one behind every 2nd MFMA (spread over the whole tile)
+//   hipcc --offload-arch=gfx950 -O3 dma_role_probe.hip -o dma_role_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16(const u32x4 rs, const unsigned int voff, const unsigned int soff, const unsigned int lds_dst) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rs), "s"(soff) : "memory");
+}
+
+template <int MODE, int LDSR>
+__global__ __launch_bounds__(512) void probe(unsigned long long* out, const unsigned short* src, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 131072 / 4; i += 512) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 1023);
+    __syncthreads();
+    const unsigned long long v = (unsigned long long)(size_t)(src + (size_t)blockIdx.x * 65536);     // 128 KB window per block
+    const u32x4 rs = {(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v),
+                      (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)(v >> 32) & 0xffffu)), 131072u, 0x00020000u};
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const char* base = smem + (wave & 3) * 8192 + l31 * 128 + (((hi) ^ ((l31 >> 1) & 7)) << 4);
+    bf16x8 fa[2][2], fb[2][4];
+    for (int i = 0; i < 2; ++i) { for (int j = 0; j < 2; ++j) fa[i][j] = *reinterpret_cast<const bf16x8*>(base + j * 4096);
+                                  for (int j = 0; j < 4; ++j) fb[i][j] = *reinterpret_cast<const bf16x8*>(base + 32768 + j * 4096); }
+    const unsigned int voff = lane * 16;
+    const unsigned int lds0 = (unsigned int)(size_t)smem;
+    const bool upper = wave >= 4;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int t = 0; t < tiles; ++t) {
+        const int buf = t & 1;
+        const bool loader = ((t & 1) != 0) == upper;
+        int issued = 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (LDSR == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fa[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(base + buf * 65536 + j * 4096 + ((ks & 1) << 5));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(base + buf * 65536 + 32768 + j * 4096 + ((ks & 1) << 5));
+            }
+            if (MODE == 1 && ks < 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma16(rs, voff, (unsigned int)((ks * 4 + q) * 8 + wave) * 1024u, lds0 + (buf ^ 1) * 65536 + ((ks * 4 + q) * 8 + wave) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i * 4 + j], 0, 0, 0);
+                    const int m = ks * 8 + i * 4 + j;       // 0..31
+                    if (LDSR == 2) {
+                        const int r = i * 4 + j;
+                        if (r < 2) fa[(ks + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(base + buf * 65536 + r * 4096 + ((ks & 1) << 5));
+                        else if (r < 6) fb[(ks + 1) & 1][r - 2] = *reinterpret_cast<const bf16x8*>(base + buf * 65536 + 32768 + (r - 2) * 4096 + ((ks & 1) << 5));
+                    }
+                    if (MODE == 2 && m < 24 && m % 3 == 1) {
+                        const int p = m / 3;
+                        dma16(rs, voff, (unsigned int)(p * 8 + wave) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + wave) * 1024);
+                    }
+                    if (MODE == 3 && m < 16 && loader) {
+                        const int p = m >> 1, w = (m & 1) ? (wave ^ 4) : wave;
+                        dma16(rs, voff, (unsigned int)(p * 8 + w) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + w) * 1024);
+                    }
+                    if (MODE == 4 && (m & 1) == 0 && loader) {
+                        const int q = m >> 1, p = q >> 1, w = (q & 1) ? (wave ^ 4) : wave;
+                        dma16(rs, voff, (unsigned int)(p * 8 + w) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + w) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        (void)issued;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[4096] = 1;
+    if (threadIdx.x == 0 && blockIdx.x < 4096) out[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE, int LDSR>
+static void run(const char* name, unsigned long long* d_out, const unsigned short* src) {
+    const int tiles = 200, smem = 131072, blocks = 256;
+    hipFuncSetAttribute((const void*)probe<MODE, LDSR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    std::vector<unsigned long long> h(blocks);
+    for (int rep = 0; rep < 2; ++rep) probe<MODE, LDSR><<<blocks, 512, smem>>>(d_out, src, tiles);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), d_out, blocks * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[blocks / 2] / tiles;
+    printf("%-58s ds_reads %d: %7.0f cycles per K-tile (2048 = matrix pipe busy) -> %4.1f %% MFMA\n", name, LDSR, med, 204800.0 / med);
+}
+
+int main() {
+    unsigned long long* d; unsigned short* src;
+    hipMalloc(&d, 8 * 8192); hipMalloc(&src, (size_t)256 * 131072); hipMemset(src, 0x11, (size_t)256 * 131072);
+    run<0, 0>("no DMA", d, src);                                   run<0, 1>("no DMA", d, src);
+    run<0, 2>("no DMA (reads interleaved with the MFMAs)", d, src);  run<2, 2>("8 per wave spread (reads interleaved)", d, src);
+    run<1, 0>("8 per wave, two bursts of 4", d, src);              run<1, 1>("8 per wave, two bursts of 4", d, src);
+    run<2, 0>("8 per wave, one behind every 3rd MFMA", d, src);    run<2, 1>("8 per wave, one behind every 3rd MFMA", d, src);
+    run<3, 0>("alternating loader, 16 behind its first 16 MFMAs", d, src); run<3, 1>("alternating loader, 16 behind its first 16 MFMAs", d, src);
+    run<4, 0>("alternating loader, 16 behind every 2nd MFMA", d, src);     run<4, 1>("alternating loader, 16 behind every 2nd MFMA", d, src);
+    return 0;
+}
