@@ -18,6 +18,7 @@
 // only shape requirement is K % 64 == 0.
 #include "gemm.h"
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef ESME_GEMM_P3N
@@ -32,7 +33,7 @@
 
 namespace esme {
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
     static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64 && (WN == 2 || WN == 4)), "row statistics are emitted by the residual epilogue");
@@ -69,36 +70,58 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // XCD-aware, L2-friendly tile order: each XCD (own 4 MB L2) walks a contiguous range of ids;
     // ids sweep gm x gn groups of tiles so the ~32 workgroups resident on an XCD share gm
     // activation slabs and gn weight slabs instead of 1-2 and all of them.
-    const unsigned int pid = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_band = a.gm * a.tiles_n;
-    const int band = pid / per_band, lb = pid - band * per_band;
-    const int rows = min(a.gm, a.tiles_m - band * a.gm);
-    const int grp = rows * a.gn;
-    const int ng = lb / grp, rg = lb - ng * grp;
-    const int tile_n = ng * a.gn + rg / rows;
-    const int64_t tile_m = (int64_t)band * a.gm + rg % rows;
-    const int64_t m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
+    // PERSIST: one workgroup per CU walks several tiles (the ids slot, slot + nslots, ... of its XCD's contiguous id range;
+    // nslots = workgroups per XCD), so that the next tile's first K-tile and LayerNorm strip are fetched under the
+    // current tile's epilogue instead of behind a workgroup launch.
+    unsigned int pid, pid_end = 0u, pid_step = 0u;
+    if constexpr (PERSIST) {
+        const unsigned int nblk = (unsigned int)(a.tiles_m * a.tiles_n);
+        const unsigned int q = nblk >> 3, r = nblk & 7u, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const unsigned int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        pid_step = gridDim.x >> 3;                                  // the host launches a multiple of 8 workgroups
+        pid = base + slot;
+        pid_end = base + q + (xcd < r ? 1u : 0u);
+        if (pid >= pid_end) return;
+    } else {
+        pid = xcd_remap(blockIdx.x, gridDim.x);
+    }
+    int64_t m0;
+    int n0;
+    auto tile_coords = [&](const unsigned int id) {
+        const int per_band = a.gm * a.tiles_n;
+        const int band = id / per_band, lb = id - band * per_band;
+        const int rows = min(a.gm, a.tiles_m - band * a.gm);
+        const int grp = rows * a.gn;
+        const int ng = lb / grp, rg = lb - ng * grp;
+        const int tile_n = ng * a.gn + rg / rows;
+        const int64_t tile_m = (int64_t)band * a.gm + rg % rows;
+        m0 = tile_m * BM;
+        n0 = tile_n * BN;
+    };
+    tile_coords(pid);
 
     // ---- per-thread staging sources (k0 = 0); chunk swizzle folded into the address
     const u16* srcA[IA];
     const u16* srcW[IW];
+    auto set_sources = [&]() {
 #pragma unroll
-    for (int i = 0; i < IA; ++i) {
-        const int q = (i * NW + wave) * 64 + lane;
-        const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-        int64_t gr = m0 + row;
-        gr = gr < a.M ? gr : a.M - 1;
-        srcA[i] = a.A + gr * a.lda + c * 8;
-    }
+        for (int i = 0; i < IA; ++i) {
+            const int q = (i * NW + wave) * 64 + lane;
+            const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+            int64_t gr = m0 + row;
+            gr = gr < a.M ? gr : a.M - 1;
+            srcA[i] = a.A + gr * a.lda + c * 8;
+        }
 #pragma unroll
-    for (int i = 0; i < IW; ++i) {
-        const int q = (i * NW + wave) * 64 + lane;
-        const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-        int gr = n0 + row;
-        gr = gr < a.N ? gr : a.N - 1;
-        srcW[i] = a.W + (int64_t)gr * a.K + c * 8;
-    }
+        for (int i = 0; i < IW; ++i) {
+            const int q = (i * NW + wave) * 64 + lane;
+            const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
+            int gr = n0 + row;
+            gr = gr < a.N ? gr : a.N - 1;
+            srcW[i] = a.W + (int64_t)gr * a.K + c * 8;
+        }
+    };
+    set_sources();
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
@@ -207,83 +230,89 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
     };
+    int par = 0;                              // stage buffer that holds K-tile 0 of the current tile
     stage(0, 0);
-    // ---- folded LayerNorm: reduce this tile's 256 row statistics from the producer's partial sums
-    // once per block, right after K-tile 0's LDS-DMA is issued (the loads overlap its latency), and park {rstd, rstd*mean} in
-    // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
-    if constexpr (ROTD > 0) {
-        if (tid < BM) {
-            int64_t m = m0 + tid;
-            m = m < a.M ? m : a.M - 1;
-            int p = a.pos[m];
-            lpos[tid] = p < a.max_len ? p : a.max_len - 1;
-        }
-    }
-    if constexpr (LNF) {
-        if (tid < BM) {
-            int64_t m = m0 + tid;
-            m = m < a.M ? m : a.M - 1;
-            // Canonical association, so that a row's statistics (hence its logits) do not depend on the tile configuration
-            // of the producer, i.e. on how many rows the batch has: 64-column wave partials are combined as a tree inside
-            // a 256-column block, ((w0 + w1) + (w2 + w3)), and 256-column blocks are added strictly left to right.  A
-            // 256 x 256 producer emits one partial per 256 columns (its four column waves combined in that order), a
-            // 128 x 128 producer one per 128 columns (w0 + w1): in that case (ln_nblk > ceil(K / 256)) pairs are combined
-            // here first.  K of this GEMM = the width the statistics were taken over.
-            float s1 = 0.f, s2 = 0.f;
-            const f32x2* pp = reinterpret_cast<const f32x2*>(a.ln_partial) + m;
-            const int n256 = (a.K + 255) >> 8;
-            if (a.ln_nblk > n256) {                             // 128-column partials: pair them up
-                int b = 0;
-                for (; b + 10 <= a.ln_nblk; b += 10) {          // 10 independent loads in flight, not a serial latency chain
-                    f32x2 p[10];
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
-#pragma unroll
-                    for (int u = 0; u < 10; u += 2) { s1 += p[u][0] + p[u + 1][0]; s2 += p[u][1] + p[u + 1][1]; }
-                }
-                for (; b + 2 <= a.ln_nblk; b += 2) {
-                    const f32x2 p0 = pp[(int64_t)b * a.stat_ld], p1 = pp[(int64_t)(b + 1) * a.stat_ld];
-                    s1 += p0[0] + p1[0]; s2 += p0[1] + p1[1];
-                }
-                if (b < a.ln_nblk) { const f32x2 p = pp[(int64_t)b * a.stat_ld]; s1 += p[0]; s2 += p[1]; }
-            } else {
-                int b = 0;
-                for (; b + 10 <= a.ln_nblk; b += 10) {
-                    f32x2 p[10];
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
-                }
-                for (; b + 5 <= a.ln_nblk; b += 5) {
-                    f32x2 p[5];
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
-                }
-                for (; b < a.ln_nblk; ++b) {
-                    const f32x2 p = pp[(int64_t)b * a.stat_ld];
-                    s1 += p[0]; s2 += p[1];
-                }
+    // The tile's LDS strips (rotary positions, LayerNorm row statistics, c1 / c2 columns); the next barrier publishes them.
+    auto make_strips = [&]() {
+        // ---- folded LayerNorm: reduce this tile's 256 row statistics from the producer's partial sums
+        // once per block, right after K-tile 0's LDS-DMA is issued (the loads overlap its latency), and park {rstd, rstd*mean} in
+        // a 2 KB LDS strip behind the two stages; the first barrier publishes them.
+        if constexpr (ROTD > 0) {
+            if (tid < BM) {
+                int64_t m = m0 + tid;
+                m = m < a.M ? m : a.M - 1;
+                int p = a.pos[m];
+                lpos[tid] = p < a.max_len ? p : a.max_len - 1;
             }
-            const float inv = 1.0f / (float)a.ln_dim;
-            const float mean = s1 * inv;
-            const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
-            lnst[tid] = f32x2{rstd, rstd * mean};
         }
-        if (tid < BN / 4) {                                     // this tile's c1 / c2 columns -> LDS strip
-            int n = n0 + tid * 4;
-            n = n < a.N - 4 ? n : a.N - 4;
-            c1s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c1 + n);
-            c2s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c2 + n);
+        if constexpr (LNF) {
+            if (tid < BM) {
+                int64_t m = m0 + tid;
+                m = m < a.M ? m : a.M - 1;
+                // Canonical association, so that a row's statistics (hence its logits) do not depend on the tile configuration
+                // of the producer, i.e. on how many rows the batch has: 64-column wave partials are combined as a tree inside
+                // a 256-column block, ((w0 + w1) + (w2 + w3)), and 256-column blocks are added strictly left to right.  A
+                // 256 x 256 producer emits one partial per 256 columns (its four column waves combined in that order), a
+                // 128 x 128 producer one per 128 columns (w0 + w1): in that case (ln_nblk > ceil(K / 256)) pairs are combined
+                // here first.  K of this GEMM = the width the statistics were taken over.
+                float s1 = 0.f, s2 = 0.f;
+                const f32x2* pp = reinterpret_cast<const f32x2*>(a.ln_partial) + m;
+                const int n256 = (a.K + 255) >> 8;
+                if (a.ln_nblk > n256) {                             // 128-column partials: pair them up
+                    int b = 0;
+                    for (; b + 10 <= a.ln_nblk; b += 10) {          // 10 independent loads in flight, not a serial latency chain
+                        f32x2 p[10];
+    #pragma unroll
+                        for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
+    #pragma unroll
+                        for (int u = 0; u < 10; u += 2) { s1 += p[u][0] + p[u + 1][0]; s2 += p[u][1] + p[u + 1][1]; }
+                    }
+                    for (; b + 2 <= a.ln_nblk; b += 2) {
+                        const f32x2 p0 = pp[(int64_t)b * a.stat_ld], p1 = pp[(int64_t)(b + 1) * a.stat_ld];
+                        s1 += p0[0] + p1[0]; s2 += p0[1] + p1[1];
+                    }
+                    if (b < a.ln_nblk) { const f32x2 p = pp[(int64_t)b * a.stat_ld]; s1 += p[0]; s2 += p[1]; }
+                } else {
+                    int b = 0;
+                    for (; b + 10 <= a.ln_nblk; b += 10) {
+                        f32x2 p[10];
+    #pragma unroll
+                        for (int u = 0; u < 10; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
+    #pragma unroll
+                        for (int u = 0; u < 10; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
+                    }
+                    for (; b + 5 <= a.ln_nblk; b += 5) {
+                        f32x2 p[5];
+    #pragma unroll
+                        for (int u = 0; u < 5; ++u) p[u] = pp[(int64_t)(b + u) * a.stat_ld];
+    #pragma unroll
+                        for (int u = 0; u < 5; ++u) { s1 += p[u][0]; s2 += p[u][1]; }
+                    }
+                    for (; b < a.ln_nblk; ++b) {
+                        const f32x2 p = pp[(int64_t)b * a.stat_ld];
+                        s1 += p[0]; s2 += p[1];
+                    }
+                }
+                const float inv = 1.0f / (float)a.ln_dim;
+                const float mean = s1 * inv;
+                const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
+                lnst[tid] = f32x2{rstd, rstd * mean};
+            }
+            if (tid < BN / 4) {                                     // this tile's c1 / c2 columns -> LDS strip
+                int n = n0 + tid * 4;
+                n = n < a.N - 4 ? n : a.N - 4;
+                c1s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c1 + n);
+                c2s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c2 + n);
+            }
         }
-    }
 
+    };
+    make_strips();
     __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier; publishes the LN strip
-    ESME_TRACE_MARK(1);
     Frag f0, f1;
-    rd(f0, smem, 0);
+    for (;;) {                                // PERSIST: one pass per tile; otherwise a single pass
+    ESME_TRACE_MARK(1);
+    rd(f0, smem + par * STAGE, 0);
 #if ESME_GEMM_SPREAD
     // One k-step: the FN*FM MFMAs on fragments f, with -- one instruction behind each MFMA -- the ds_read_b128s of the NEXT
     // k-step's fragments (into nf) and this k-step's share of the LDS-DMA pieces.  Issued as bursts (6 reads, then 8
@@ -316,10 +345,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     using std::integral_constant;
     if (KT > 1) {
 #pragma unroll
-        for (int p = 0; p < P3; ++p) stage_piece(1, 1, p);        // lands long before the first barrier of the loop
+        for (int p = 0; p < P3; ++p) stage_piece(1, par ^ 1, p);  // lands long before the first barrier of the loop
     }
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+        const int buf = (kt + par) & 1;
         const char* base = smem + buf * STAGE;
         const bool more = kt + 1 < KT, more2 = kt + 2 < KT;
         if (!more) rot_prefetch(buf ^ 1, 0);
@@ -335,7 +364,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     }
 #else
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+        const int buf = (kt + par) & 1;
         const char* base = smem + buf * STAGE;
         const bool more = kt + 1 < KT;
         rd(f1, base, 1);
@@ -379,7 +408,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     constexpr int CH = OUTC / 8;                                       // 16-B chunks per slab row
     constexpr int ROWB = OUTC * 2;
     constexpr int RPI = 64 / CH;                                       // rows per store instruction
-    char* slab = smem + wave * (WTM * ROWB);
+    // PERSIST: the epilogue runs in two passes of WTM / 2 rows through slabs in the stage buffer that held the LAST K-tile
+    // (64 KB in all), so that the other stage buffer can already receive the next tile's first K-tile.
+    constexpr int NPASS = PERSIST ? 2 : 1;
+    constexpr int RPP = WTM / NPASS;                                   // slab rows per pass
+    constexpr int FMP = FM / NPASS;                                    // 32-row blocks per pass
+    static_assert(!PERSIST || (FM % 2 == 0), "two-pass epilogue");
+    const int lastbuf = (a.K / BK - 1 + par) & 1;
+    char* slab = smem + (PERSIST ? lastbuf * STAGE : 0) + wave * (RPP * ROWB);
+    const int64_t em0 = m0;                                            // this tile's origin (PERSIST moves m0 / n0 on mid-epilogue)
+    const int en0 = n0;
     const int n_out = (EPI == ESME_EPI_SWIGLU) ? (a.N >> 1) : a.N;
     const int nw0 = (EPI == ESME_EPI_SWIGLU) ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN);   // first output column of the wave
     const int64_t mw0 = m0 + wm * WTM;
@@ -425,7 +463,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // cos/sin rows of the tile's positions were prefetched during the last K-tile into the stage buffer that
         // was free by then (rot_prefetch; shared by the WN waves of a row group; the main loop's last barrier
         // published them), so the accumulator quads read them straight from LDS.
-        const char* tab = smem + ((((a.K / BK) - 1) & 1) ^ 1) * STAGE + wm * (WTM * TB);
+        const char* tab = smem + (lastbuf ^ 1) * STAGE + wm * (WTM * TB);
         if (nw0 < a.rot_cols) {                               // wave-uniform: whole heads of q or k
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
@@ -455,9 +493,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
         // the result slabs overlay the table region: every wave must be done reading tables before any slab write
-        if (n0 < a.rot_cols) __syncthreads();
+        if (!PERSIST && n0 < a.rot_cols) __syncthreads();
     }
-
+    bool have_next = false;
+    if constexpr (PERSIST && ROTD > 0) __syncthreads();      // (PERSIST: all tiles take the barrier) table reads done before the slab writes
     ESME_TRACE_MARK(3);
     if (a.vec_ok) {
         // Branch-free: every load of the epilogue (bias quads, residual quads) is issued up front
@@ -486,12 +525,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // slab (same XOR-swizzled layout the results use, swizzle applied on the global source
         // address), then read back per accumulator quad -- instead of 8-B loads scattered over 32
         // rows per instruction (measured ~20 us per tile for the scattered form).
+        f32x2* blkst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);      // STATS: [wn][tile row] partial sums
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slab
         if constexpr (EPI == ESME_EPI_RESIDUAL) {
 #pragma unroll
-            for (int it = 0; it < WTM / 8; ++it) {
+            for (int it = 0; it < RPP / 8; ++it) {
                 const int r = it * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ (r & 7);
-                int64_t m = mw0 + r;
+                int64_t m = mw0 + pass * RPP + r;
                 m = m < a.M ? m : a.M - 1;
                 int n = nw0 + c * 8;
                 n = n < a.N - 8 ? n : a.N - 8;
@@ -511,8 +554,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     bv[0] = bf_lo(bq[i][g][0]); bv[1] = bf_hi(bq[i][g][0]); bv[2] = bf_lo(bq[i][g][1]); bv[3] = bf_hi(bq[i][g][1]);
                 }
 #pragma unroll
-                for (int j = 0; j < FM; ++j) {
-                    const int r = j * 32 + l31;
+                for (int jj = 0; jj < FMP; ++jj) {
+                    const int j = pass * FMP + jj;
+                    const int r = jj * 32 + l31;                        // row inside this pass's slab
                     float o[4];
                     if constexpr (EPI == ESME_EPI_SWIGLU) {
 #pragma unroll
@@ -541,15 +585,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         }
         __builtin_amdgcn_wave_barrier();
         ESME_TRACE_MARK(5);
+        // ---- PERSIST, after the first pass is packed (half of the accumulators are dead: the registers the address
+        // set-up below needs): every wave is past its last fragment / strip / table read after this barrier, so the free
+        // stage buffer and the strips are refilled for the NEXT tile while this one's results are stored.
+        if constexpr (PERSIST) {
+            if (pass == 0) {
+                __syncthreads();
+                pid += pid_step;
+                have_next = pid < pid_end;
+                if (have_next) {
+                    tile_coords(pid);
+                    set_sources();
+                    par = lastbuf ^ 1;
+                    stage(0, par);
+                    make_strips();
+                }
+            }
+        }
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
         const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
-        f32x2* blkst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);      // STATS: [wn][tile row] partial sums
         if (col_ok || STATS) {
 #pragma unroll
-            for (int it = 0; it < WTM / RPI; ++it) {
+            for (int it = 0; it < RPP / RPI; ++it) {
                 const int r = it * RPI + rl;
-                const int64_t m = mw0 + r;
+                const int64_t m = mw0 + pass * RPP + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (col_ok && m < a.M && ESME_TUNE_STORE_OK) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
                 if constexpr (STATS) {
@@ -564,16 +624,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);      // lane ^ 1
                     t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);      // lane ^ 2
                     t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);    // lane -> 7 - lane (other quad)
-                    if (ch == 0) blkst[wn * BM + wm * WTM + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
+                    if (ch == 0) blkst[wn * BM + wm * WTM + pass * RPP + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
                 }
             }
         }
+        }   // pass
         ESME_TRACE_MARK(6);
         if constexpr (STATS) {
             // the block's column waves combine as a tree ((w0 + w1) + (w2 + w3)): the canonical association the consumer
             // assumes (see the LN-fold prologue), whatever the tile width
             __syncthreads();
-            if (tid < BM && m0 + tid < a.M) {
+            if (tid < BM && em0 + tid < a.M) {
                 f32x2 acc2 = blkst[tid];
                 acc2[0] += blkst[BM + tid][0]; acc2[1] += blkst[BM + tid][1];
                 if constexpr (WN == 4) {
@@ -581,42 +642,65 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     hi2[0] += blkst[3 * BM + tid][0]; hi2[1] += blkst[3 * BM + tid][1];
                     acc2[0] += hi2[0]; acc2[1] += hi2[1];
                 }
-                *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(n0 / BN) * a.stat_ld + m0 + tid)) = acc2;
+                *reinterpret_cast<f32x2*>(a.stats_out + 2 * ((int64_t)(en0 / BN) * a.stat_ld + em0 + tid)) = acc2;
             }
         }
         ESME_TRACE_MARK(7);
         ESME_TRACE_REAL(9);
-        return;
-    }
-
-    // Slow path (C or resid rows not 16-byte addressable, e.g. the (T, 33) vocab logits):
-    // direct 2-byte stores from the accumulator layout.
-    if constexpr (EPI != ESME_EPI_SWIGLU) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nw0 + i * 32 + 8 * g + 4 * hi;
-#pragma unroll
-                for (int j = 0; j < FM; ++j) {
-                    const int64_t m = mw0 + j * 32 + l31;
-                    if (m >= a.M) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e < a.N) {
-                            float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
-                            if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
-                            if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
-                            a.C[m * a.ldc + n + e] = f2bf(v);
+    } else {
+        // Slow path (C or resid rows not 16-byte addressable, e.g. the (T, 33) vocab logits):
+        // direct 2-byte stores from the accumulator layout.
+        if constexpr (EPI != ESME_EPI_SWIGLU) {
+    #pragma unroll
+            for (int i = 0; i < FN; ++i) {
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw0 + i * 32 + 8 * g + 4 * hi;
+    #pragma unroll
+                    for (int j = 0; j < FM; ++j) {
+                        const int64_t m = mw0 + j * 32 + l31;
+                        if (m >= a.M) continue;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < a.N) {
+                                float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
+                                if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
+                                if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
+                                a.C[m * a.ldc + n + e] = f2bf(v);
+                            }
                         }
                     }
                 }
             }
         }
     }
+    if constexpr (!PERSIST) {
+        break;
+    } else {
+        if (!have_next) break;
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();                      // the next tile's K-tile 0 has landed (vmcnt) and its strips are published;
+                                              // every wave is done with this tile's slabs
+    }
+    }   // tile loop
 }
 
 static int g_raster_gm = 0, g_raster_gn = 0;      // test/tuning hook (0 = heuristic)
+static int g_persist = -1;                         // persistent 256 x 256 workgroups: -1 = not resolved yet (env ESME_GEMM_PERSIST, else the
+                                                   // default below); tuning hook esme_hip_debug_set_gemm_persist
+static int persist_on() {
+    if (g_persist < 0) {
+        const char* e = getenv("ESME_GEMM_PERSIST");
+        g_persist = e ? (atoi(e) != 0) : 1;
+    }
+    return g_persist;
+}
+static int cu_count();
 static int g_nt_store = 0;
 static int g_stagger = 0;
 
@@ -639,13 +723,20 @@ static void set_raster(GemmArgs& a) {
     if (a.gn < 1) a.gn = 1;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false>
 static int launch_one(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
-    const int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
+    int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS>;
+    if constexpr (!PERSIST && BM == 256 && BN == 256 && ROTD == 0) {     // (fused rotary: the epilogue's tables + the address set-up spill)
+        // Big tiles run one workgroup per CU (128 KB of LDS): once a launch is several rounds long, ONE persistent
+        // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
+        const int ncu = cu_count() & ~7;
+        if (persist_on() && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true>(a, s);
+    }
+    if constexpr (PERSIST) blocks = cu_count() & ~7;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST>;
     if (smem >= 64 * 1024) {
         // the attribute is per (kernel, device): one bit per device ordinal, set once, safe from any host thread
         static std::atomic<unsigned long long> done{0ull};
@@ -694,7 +785,7 @@ static int g_split = 0;           // tail split of 256 x 256 launches: tuning ho
 extern "C" void esme_hip_debug_set_gemm_split(int v) { g_split = v; }
 
 // compute units of the current device (cached per device ordinal; 256 on MI355X)
-static int cu_count() {
+static int esme::cu_count() {
     static std::atomic<int> cached[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -706,6 +797,7 @@ static int cu_count() {
     return v;
 }
 extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
+extern "C" void esme_hip_debug_set_gemm_persist(int v) { esme::g_persist = v; }
 extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
 extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
 static unsigned long long* g_trace = nullptr;     // honoured by ESME_GEMM_TRACE builds only

@@ -543,3 +543,44 @@ def test_attention_defer_max_threshold_error_report():
     print()
     for r in rows:
         print(f'[attn thr] qscale {r[0]} variant {r[1]} spec {r[2]} thr {r[3]}: max|err| {r[4]:.3e} rel_fro {r[5]:.3e}')
+
+
+@pytest.mark.parametrize('K', [64, 256, 1280])
+@pytest.mark.parametrize('epi', ['none', 'gelu+lnf', 'resid+stats', 'swiglu'])
+def test_gemm_persistent_workgroups_equal_per_tile(K, epi):
+    """Launches of >= 2 rounds of 256 x 256 tiles run ONE persistent workgroup per CU (next tile's first K-tile and LN
+    strip fetched under the current epilogue, two-pass epilogue through one stage buffer): same bits as one workgroup per
+    tile, on a ragged M, for every epilogue that takes the path."""
+    from esme import _hip
+    from esme.attention import _fold_layernorm
+    lib = _hip.load()
+    M, N = 27001, 1280                      # 106 x 5 tiles = 530 >= 2 x 256 CUs
+    x = rnd((M, K), 1).to(dev())
+    w = rnd((N, K), 2, 1 / math.sqrt(K)).to(dev())
+    b = rnd((N,), 3, 0.1).to(dev())
+    outs = {}
+    for persist in (0, 1):
+        lib.esme_hip_debug_set_gemm_persist(persist)
+        try:
+            if epi == 'none':
+                outs[persist] = (_hip.gemm(x, w, b),)
+            elif epi == 'gelu+lnf':
+                g = (1 + 0.1 * rnd((K,), 4).float()).to(torch.bfloat16).to(dev())
+                be = rnd((K,), 5, 0.1).to(dev())
+                wf, c1, c2 = _fold_layernorm(w, b, g, be)
+                outs[persist] = (_hip.gemm_fused(x, wf, None, _hip.EPI_GELU, ln=(_hip.row_sums(x), K, 1e-5, c1, c2)),)
+            elif epi == 'resid+stats':
+                res = rnd((M, N), 6).to(dev())
+                part = torch.zeros(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=dev())
+                y = _hip.gemm_fused(x, w, b, _hip.EPI_RESIDUAL, res, 0.5, stats_out=part)
+                outs[persist] = (y, part)
+            else:
+                outs[persist] = (_hip.gemm_fused(x, w, None, _hip.EPI_SWIGLU),)
+        finally:
+            lib.esme_hip_debug_set_gemm_persist(1)
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, c), f'{epi} K={K}: max |diff| {float((a.float() - c.float()).abs().max()):.3e}'
+    if epi == 'none':                       # and the per-tile result is the oracle's
+        ref = x[-300:].cpu().float() @ w.cpu().float().T + b.cpu().float()          # the last (ragged) row tile
+        check(outs[1][0][-300:], ref, what='persistent gemm')
