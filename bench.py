@@ -71,10 +71,10 @@ def parse():
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).
+    (profiles/r02_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).
     Counters cannot be read from inside the process, so this is the last profiled value, valid
     for the default workload only; None otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
     try:
         with open(path) as f:
             return int(json.load(f)['traffic_bytes_per_launch'])

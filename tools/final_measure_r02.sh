@@ -19,6 +19,14 @@ python bench.py --quantization 4bit --no-cpu-baseline > $O/bench_650m_q4.json 2>
 python tools/attn_lab.py > $O/attn_lab_uniform.txt 2>&1
 python tools/attn_lab.py --batch proteome --rounds 3 > $O/attn_lab_proteome.txt 2>&1
 python tools/attn_lab.py --seq-len 2000 --rounds 3 > $O/attn_lab_s2000.txt 2>&1
+ESME_HIP_LIB=/root/repo/esm-efficient_amd/esme/libesme_hip_trace.so PERSIST=0 python tools/gemm_phase_trace.py > $O/gemm_phase_trace.txt 2>&1
+python tools/gemm_persist_check.py > $O/gemm_persist.txt 2>&1
+python tools/gemm_epi_bench.py > $O/gemm_epi_bench.txt 2>&1
+python tools/attn_power_probe.py > $O/attn_power_probe.txt 2>&1
+python tools/power_probe.py > $O/power_probe.txt 2>&1
+python tools/qk_norm_bench.py > $O/qk_norm_bench.txt 2>&1
+for p in mfma_issue_probe dma_role_probe; do [ -x tools/lab/bin/$p ] && tools/lab/bin/$p > $O/$p.txt 2>&1; done
+ESME_GEMM_PERSIST=0 python bench.py --no-cpu-baseline > $O/bench_nopersist.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/prof -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /root/repo/$O/prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /root/repo/$O/pmc_fetch -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_fetch.log 2>&1

@@ -84,7 +84,8 @@ def main():
             ('ESMC-600M, 32 064 residues = 32 x 1 002 (configs[4] batch shape)', 'bench_esmc600m.json'),
             ('ESM2-150M, 8 192 residues = 16 x 512 (configs[1]), eager, one C call per forward (esme_hip_forward)', 'bench_150m.json'),
             ('same, eager, one ctypes call per kernel (ESME_NO_C_FORWARD=1)', 'bench_150m_pyloop.json'),
-            ('same, hipGraph replay (--graph)', 'bench_150m_graph.json')]
+            ('same, hipGraph replay (--graph)', 'bench_150m_graph.json'),
+            ('headline with one workgroup per GEMM tile (ESME_GEMM_PERSIST=0)', 'bench_nopersist.json')]
     lines = ['# bench.py on other workloads (1 x MI355X, round 2; separate gpurun boxes differ by +-3 %)', '',
              '| workload | residues/s | ms/step | % of 2.5 PF bf16 peak (algorithmic FLOPs) | kernel ms per step |', '|---|---:|---:|---:|---|']
     for label, f in rows:
@@ -100,6 +101,16 @@ def main():
         except Exception:
             pass
     open(os.path.join(P, 'r02_attention.md'), 'w').write('\n'.join(att))
+    # plain-text tool outputs, copied as they are (rocm-smi / libdrm noise lines dropped)
+    for src, dst in (('gemm_phase_trace.txt', 'r02_gemm_phase_trace.txt'), ('gemm_persist.txt', 'r02_gemm_persistent_vs_per_tile.txt'),
+                     ('gemm_epi_bench.txt', 'r02_gemm_epilogue_bench.txt'), ('attn_power_probe.txt', 'r02_attn_power_probe.txt'),
+                     ('power_probe.txt', 'r02_power_probe.txt'), ('qk_norm_bench.txt', 'r02_qk_norm_bench.txt'),
+                     ('mfma_issue_probe.txt', 'r02_mfma_issue_probe.txt'), ('dma_role_probe.txt', 'r02_dma_role_probe.txt')):
+        try:
+            txt = [l for l in open(os.path.join(O, src)).read().splitlines() if 'amdgpu.ids' not in l]
+            open(os.path.join(P, dst), 'w').write('\n'.join(txt) + '\n')
+        except Exception as e:
+            print('missing', src, e)
 
 
 if __name__ == '__main__':
