@@ -279,12 +279,17 @@ __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* _
 // ------------------------------------------- q/k LayerNorm + rotary (ESM-C)
 // ESM-C normalises q and k over the FULL embedding width between the projection and the rotary
 // (attention.py:104-105), so that LayerNorm cannot ride in a GEMM epilogue (a row spans several
-// column tiles).  One wave per (row, q|k): the row stays in registers, gets normalised, rounded to
-// bf16 (the value the stand-alone LayerNorm kernel would have written) and rotated in place; the
+// column tiles).  A wave takes (q | k) of RPW consecutive rows: a row stays in registers, gets normalised,
+// rounded to bf16 (the value the stand-alone LayerNorm kernel would have written) and rotated in place; the
 // rotary partner of a lane's 8 elements (d/2 further inside the head) lives d/16 lanes away, so
 // the exchange is four 32-bit lane shuffles.  One read + one write of q and k: 8*E bytes per row,
 // instead of three passes (two LayerNorms + rotary).
-template <int NCH>
+// The pass is bound by vector-memory INSTRUCTIONS, not bytes (a 64-lane 16-byte access occupies the address
+// unit ~16 cycles; ~10 B/clk/CU): the first version issued 15 per 2.3 KB row item (3 row loads, 3 weight, 3
+// cos, 3 sin, 3 stores) and ran at 4.2 TB/s.  Here the LayerNorm weights (biases) of the wave's type are loaded
+// once for its RPW rows, and the cos / sin chunk of a lane is the same for every 64-lane chunk of the row
+// (512 elements per chunk step is a multiple of the head dim), so it is ONE load each per row: 8 + 6 / RPW.
+template <int NCH, int RPW>
 __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q, u16* __restrict__ k, int64_t ld,
                                                              const u16* __restrict__ wq, const u16* __restrict__ wk,
                                                              const u16* __restrict__ bq, const u16* __restrict__ bk,
@@ -292,79 +297,96 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
                                                              const u16* __restrict__ sinT, const int32_t* __restrict__ pos,
                                                              int64_t T, int E, int d, int max_len) {
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t row = item >> 1;
-    if (row >= T) return;
-    const bool is_k = item & 1;
-    u16* xr = (is_k ? k : q) + row * ld;
+    const int wv = threadIdx.x >> 6;                     // waves 0, 1: q; 2, 3: k
+    const bool is_k = wv >= 2;
+    const int64_t row0 = ((int64_t)blockIdx.x * 2 + (wv & 1)) * RPW;
+    if (row0 >= T) return;
     const u16* w = is_k ? wk : wq;
     const u16* b = is_k ? bk : bq;
-    float v[NCH][8];
-    float s = 0.f;
+    u32x4 wraw[NCH], braw[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int e0 = (c * 64 + lane) * 8;
+        wraw[c] = braw[c] = u32x4{0u, 0u, 0u, 0u};
         if (e0 < E) {
-            unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[c][j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+            wraw[c] = *reinterpret_cast<const u32x4*>(w + e0);
+            if (b) braw[c] = *reinterpret_cast<const u32x4*>(b + e0);
         }
     }
-    const float inv_e = 1.0f / (float)E;
-    const float mean = wave_sum(s) * inv_e;
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int e0 = (c * 64 + lane) * 8;
-        if (e0 < E) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float dv = v[c][j] - mean; ss += dv * dv; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
-    int p = pos[row];
-    p = p < max_len ? p : max_len - 1;
     const int half = d >> 1, shift = d >> 4;            // partner lane = lane ^ shift
+    const int local = (lane * 8) % d;                   // position inside the head: the same for every chunk step
+    const bool lower = local < half;
+    const int jc = lower ? local : local - half;
+    const float inv_e = 1.0f / (float)E;
+    for (int it = 0; it < RPW; ++it) {
+        const int64_t row = row0 + it;
+        if (row >= T) break;
+        u16* xr = (is_k ? k : q) + row * ld;
+        int p = pos[row];
+        p = p < max_len ? p : max_len - 1;
+        const u32x4 craw = *reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc);
+        const u32x4 sraw = *reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc);
+        float v[NCH][8];
+        float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int e0 = (c * 64 + lane) * 8;
-        const bool ok = e0 < E;
-        u32x4 y = {0u, 0u, 0u, 0u};
-        if (ok) {
-            float wf[8], o[8];
-            unpack8(*reinterpret_cast<const u32x4*>(w + e0), wf);
-            if (b) {
-                float bfv[8];
-                unpack8(*reinterpret_cast<const u32x4*>(b + e0), bfv);
+        for (int c = 0; c < NCH; ++c) {
+            const int e0 = (c * 64 + lane) * 8;
+            if (e0 < E) {
+                unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+                for (int j = 0; j < 8; ++j) s += v[c][j];
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
+                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
             }
-            y = pack8(o);                                 // bf16 rounding point of the LayerNorm output
         }
-        u32x4 other;
+        const float mean = wave_sum(s) * inv_e;
+        float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
-        if (ok) {
-            const int local = e0 % d;
-            const bool lower = local < half;
-            const int jc = lower ? local : local - half;
-            float a[8], o2[8], cs[8], sn[8], r[8];
-            unpack8(y, a);
-            unpack8(other, o2);
-            unpack8(*reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc), cs);
-            unpack8(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc), sn);
+        for (int c = 0; c < NCH; ++c) {
+            const int e0 = (c * 64 + lane) * 8;
+            if (e0 < E) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float t = __fmul_rn(o2[j], sn[j]);
-                r[j] = fmaf(a[j], cs[j], lower ? -t : t);
+                for (int j = 0; j < 8; ++j) { const float dv = v[c][j] - mean; ss += dv * dv; }
             }
-            *reinterpret_cast<u32x4*>(xr + e0) = pack8(r);
+        }
+        const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
+        float cs[8], sn[8];
+        unpack8(craw, cs);
+        unpack8(sraw, sn);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e0 = (c * 64 + lane) * 8;
+            const bool ok = e0 < E;
+            u32x4 y = {0u, 0u, 0u, 0u};
+            if (ok) {
+                float wf[8], o[8];
+                unpack8(wraw[c], wf);
+                if (b) {
+                    float bfv[8];
+                    unpack8(braw[c], bfv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
+                }
+                y = pack8(o);                                 // bf16 rounding point of the LayerNorm output
+            }
+            u32x4 other;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
+            if (ok) {
+                float a[8], o2[8], r[8];
+                unpack8(y, a);
+                unpack8(other, o2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = __fmul_rn(o2[j], sn[j]);
+                    r[j] = fmaf(a[j], cs[j], lower ? -t : t);
+                }
+                *reinterpret_cast<u32x4*>(xr + e0) = pack8(r);
+            }
         }
     }
 }
@@ -641,10 +663,14 @@ extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void*
     ESME_CHECK_ARG(ld % 8 == 0 && ld >= E, "qk_norm_rotary: bad row stride");
     ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(wq) && aligned16(wk) && (!bq || aligned16(bq)) &&
                    (!bk || aligned16(bk)) && aligned16(cosT) && aligned16(sinT), "qk_norm_rotary: misaligned");
-    const dim3 grid((unsigned int)((2 * T + 3) / 4)), block(256);
+#ifndef ESME_QKN_RPW
+#define ESME_QKN_RPW 2
+#endif
+    constexpr int RPW = ESME_QKN_RPW;                        // rows per wave
+    const dim3 grid((unsigned int)((T + 2 * RPW - 1) / (2 * RPW))), block(256);
     const hipStream_t s = (hipStream_t)stream;
 #define ESME_QKN(N)                                                                                                 \
-    hipLaunchKernelGGL(qk_norm_rotary_kernel<N>, grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
+    hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
                        (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len)
     if (E <= 512) ESME_QKN(1);
     else if (E <= 1024) ESME_QKN(2);
