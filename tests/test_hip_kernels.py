@@ -545,7 +545,7 @@ def test_attention_defer_max_threshold_error_report():
         print(f'[attn thr] qscale {r[0]} variant {r[1]} spec {r[2]} thr {r[3]}: max|err| {r[4]:.3e} rel_fro {r[5]:.3e}')
 
 
-@pytest.mark.parametrize('K', [64, 256, 1280])
+@pytest.mark.parametrize('K', [64, 192, 256, 320, 1280])
 @pytest.mark.parametrize('epi', ['none', 'gelu+lnf', 'resid+stats', 'swiglu'])
 def test_gemm_persistent_workgroups_equal_per_tile(K, epi):
     """Launches of >= 2 rounds of 256 x 256 tiles run ONE persistent workgroup per CU (next tile's first K-tile and LN
