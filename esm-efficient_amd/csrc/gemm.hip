@@ -27,6 +27,9 @@
 #ifndef ESME_GEMM_K1
 #define ESME_GEMM_K1 0             // 1: the rest is split over k-steps 0 and 1; 0: all of it in k-step 0
 #endif
+#ifndef ESME_GEMM_PERSIST_ROT
+#define ESME_GEMM_PERSIST_ROT 0
+#endif
 #ifndef ESME_GEMM_SPREAD
 #define ESME_GEMM_SPREAD 1      // 0: the round-1 schedule (two bursts of LDS-DMAs per K-tile); kept for A/B builds
 #endif
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     Frag f0, f1;
     for (;;) {                                // PERSIST: one pass per tile; otherwise a single pass
     ESME_TRACE_MARK(1);
+    if constexpr (PERSIST) set_sources();     // recomputed here so the 16 address registers are dead across the previous epilogue
     rd(f0, smem + par * STAGE, 0);
 #if ESME_GEMM_SPREAD
     // One k-step: the FN*FM MFMAs on fragments f, with -- one instruction behind each MFMA -- the ds_read_b128s of the NEXT
@@ -731,7 +735,7 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
     set_raster<BM, BN>(a);
     int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
-    if constexpr (!PERSIST && BM == 256 && BN == 256 && ROTD == 0) {     // (fused rotary: the epilogue's tables + the address set-up spill)
+    if constexpr (!PERSIST && BM == 256 && BN == 256 && (ROTD == 0 || ESME_GEMM_PERSIST_ROT)) {     // (fused rotary: the epilogue's tables + the address set-up spill)
         // Big tiles run one workgroup per CU (128 KB of LDS): once a launch is several rounds long, ONE persistent
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
