@@ -21,9 +21,9 @@ def short(name):
 
 
 def kernel_stats():
-    f = glob.glob(os.path.join(O, 'prof', '**', '*kernel_stats.csv'), recursive=True)
+    f = sorted(glob.glob(os.path.join(O, 'prof', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
     if not f:
-        return
+        return                                   # (newest run first: gpurun_out/ accumulates the runs of a round)
     rows = list(csv.DictReader(open(f[0])))
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (round 2, headline workload)', '',
@@ -41,7 +41,7 @@ def kernel_stats():
 def pmc(dirs, out, title):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in dirs:
-        for f in glob.glob(os.path.join(O, d, '**', '*counter_collection.csv'), recursive=True):
+        for f in sorted(glob.glob(os.path.join(O, d, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime, reverse=True)[:1]:
             for row in csv.DictReader(open(f)):
                 agg[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
     counters = sorted({c for k in agg.values() for c in k})
