@@ -342,7 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
 #pragma unroll
                 for (int q = 0; q < (cnt > 0 ? cnt : 0); ++q)
-                    if (m == ((2 * q + 1) * total) / (2 * (cnt > 0 ? cnt : 1)) && on) stage_piece(kt, buf, pf + q);
+                    if (m == (q * total) / (cnt > 0 ? cnt : 1) && on) stage_piece(kt, buf, pf + q);      // pieces spread from the FIRST MFMA on
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
