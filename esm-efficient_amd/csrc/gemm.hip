@@ -30,6 +30,9 @@
 #ifndef ESME_GEMM_PERSIST_ROT
 #define ESME_GEMM_PERSIST_ROT 0
 #endif
+#ifndef ESME_GEMM_MFMA_ORDER
+#define ESME_GEMM_MFMA_ORDER 0
+#endif
 #ifndef ESME_GEMM_SPREAD
 #define ESME_GEMM_SPREAD 1      // 0: the round-1 schedule (two bursts of LDS-DMAs per K-tile); kept for A/B builds
 #endif
@@ -331,11 +334,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                      const bool on, const int kt, const int buf, auto PF, auto PL) {
         constexpr int pf = decltype(PF)::value, pl = decltype(PL)::value, cnt = pl - pf, total = FN * FM;
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j) {
+        for (int m = 0; m < FN * FM; ++m) {
+#if ESME_GEMM_MFMA_ORDER
+                const int j = m / FN, i = m % FN;         // activation fragment held, weight fragment alternates
+#else
+                const int i = m / FM, j = m % FM;         // weight fragment held for FM MFMAs
+#endif
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
-                const int m = i * FM + j;
                 if (rd_on) {
                     if (m < FN) nf.w[m] = *reinterpret_cast<const bf16x8*>(nbase + rowW + m * 32 * 128 + coff[nks]);
                     else if (m < FN + FM) nf.a[m - FN] = *reinterpret_cast<const bf16x8*>(nbase + rowA + (m - FN) * 32 * 128 + coff[nks]);
