@@ -789,7 +789,9 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
                softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec};
     const hipStream_t s = (hipStream_t)stream;
-    if (d == 64 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o)) {
+    // (the ping-pong kernel addresses K / V with 32-bit byte offsets inside one sequence: (max_len + one tile) rows must fit)
+    const bool fits32 = ((int64_t)max_len + KT) * ld_qkv * 2 < 0xffffffffLL;
+    if (d == 64 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o) && fits32) {
         // head dim 64 (ESM2-650M / 3B, ESM-C): the software-pipelined kernel.  4 waves = 256 query rows per workgroup, two
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
         // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
