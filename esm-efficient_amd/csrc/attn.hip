@@ -27,6 +27,11 @@
 #include "common.h"
 #include "launch.h"
 #include "gemm.h"
+
+#ifndef ESME_ATTN_DMA0          // MFMA slots of a phase behind which this wave's two LDS-DMA pieces are issued (A/B builds)
+#define ESME_ATTN_DMA0 3
+#define ESME_ATTN_DMA1 11
+#endif
 #include <atomic>
 #include <type_traits>
 
@@ -679,11 +684,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 const bool tail = t == nt - 1 && ragged;
                 const bool need_max = exact || t == 0;
                 phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT, [&](const int m) {
-                    if (KI == 2) { if (m == 3 && pf_k) dma_piece(0, t + 3, kslot, 0); if (m == 11 && pf_k) dma_piece(0, t + 3, kslot, KI - 1); }
+                    if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_k) dma_piece(0, t + 3, kslot, 0); if (m == ESME_ATTN_DMA1 && pf_k) dma_piece(0, t + 3, kslot, KI - 1); }
                     else if (m == 7 && pf_k) dma_piece(0, t + 3, kslot, 0);
                 });
                 phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT, [&](const int m) {
-                    if (KI == 2) { if (m == 3 && pf_v) dma_piece(1, t + 2, vslot, 0); if (m == 11 && pf_v) dma_piece(1, t + 2, vslot, KI - 1); }
+                    if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_v) dma_piece(1, t + 2, vslot, 0); if (m == ESME_ATTN_DMA1 && pf_v) dma_piece(1, t + 2, vslot, KI - 1); }
                     else if (m == 7 && pf_v) dma_piece(1, t + 2, vslot, 0);
                 });
             } else {

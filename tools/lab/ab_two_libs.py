@@ -31,6 +31,14 @@ fns = {'qkv +rot+lnf': lambda: _hip.gemm_fused(x, wqkv, None, out=qkv, rot=(cos,
        'ffn1 gelu+lnf': lambda: _hip.gemm_fused(x, w1, None, _hip.EPI_GELU, out=u, ln=(stats, E, 1e-5, c11, c21)),
        'out resid+stats': lambda: _hip.gemm_fused(x, wo, bo, _hip.EPI_RESIDUAL, y, 1.0, y, stats_out=part),
        'ffn2 resid+stats': lambda: _hip.gemm_fused(h4, w2, b2, _hip.EPI_RESIDUAL, y, 1.0, y, stats_out=part)}
+if os.environ.get('ATTN', '0') == '1':          # attention instead of the GEMMs: three batch shapes, head dim 64
+    from esme import synthetic as syn
+    fns = {}
+    for S_ in (500, 1002, 2000):
+        _, cu_, ml_, ln_ = syn.uniform_batch(50000 if S_ != 1002 else 32064, S_, seed=0)
+        q_ = torch.randn(sum(ln_), 3 * E, device=dev).bfloat16()
+        cu_ = cu_.cuda()
+        fns[f'attention S={S_}'] = (lambda q_=q_, cu_=cu_, ml_=ml_: _hip.attn_varlen(q_[:, :E], q_[:, E:2 * E], q_[:, 2 * E:], cu_, ml_, 20))
 times = {(k, l): [] for k in fns for l in 'AB'}
 for r in range(int(os.environ.get('ROUNDS', 5))):
     for k, fn in fns.items():
