@@ -316,6 +316,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     make_strips();
     __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier; publishes the LN strip
     Frag f0, f1;
+#ifdef ESME_GEMM_TRACE
+    unsigned long long trace_barrier_wait = 0, trace_vm_wait = 0;
+#endif
     for (;;) {                                // PERSIST: one pass per tile; otherwise a single pass
     ESME_TRACE_MARK(1);
     if constexpr (PERSIST) set_sources();     // recomputed here so the 16 address registers are dead across the previous epilogue
@@ -367,7 +370,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         __builtin_amdgcn_sched_barrier(0);
         kstep(f1, f0, base, 2, true, more, kt + 1, buf ^ 1, integral_constant<int, P0>{}, integral_constant<int, NP>{});
         kstep(f0, f1, base, 3, true, false, 0, 0, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+#ifdef ESME_GEMM_TRACE
+        const unsigned long long bw0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long bw1 = __builtin_readcyclecounter();
+        trace_vm_wait += bw1 - bw0;
+#endif
         __syncthreads();                      // K-tile t+1 landed; every wave's reads of tile t are done
+#ifdef ESME_GEMM_TRACE
+        trace_barrier_wait += __builtin_readcyclecounter() - bw1;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         kstep(f1, f0, smem + (buf ^ 1) * STAGE, 0, more, more2, kt + 2, buf, integral_constant<int, 0>{}, integral_constant<int, P3>{});
     }
@@ -404,6 +416,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // iteration (the k-step-3 fragments are read ahead of it and nothing is read after it), so the stage
     // memory is already free for the epilogue slabs.
     ESME_TRACE_MARK(2);
+#ifdef ESME_GEMM_TRACE
+    if (a.trace && threadIdx.x == 0) { a.trace[(size_t)blockIdx.x * 16 + 10] = trace_barrier_wait; a.trace[(size_t)blockIdx.x * 16 + 11] = trace_vm_wait; }   // wave 0: cycles in the loop's barrier / in the vmcnt(0) before it
+#endif
 #ifdef ESME_GEMM_TRACE
     if (a.nt_store == 3) return;              // tuning hook: main loop only (results discarded)
 #endif

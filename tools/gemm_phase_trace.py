@@ -62,6 +62,9 @@ for name, fn in fns.items():
     for i, nm in enumerate(names):
         dlt = (marks[:, i + 1] - marks[:, i]) / ghz / 1e3
         print(f'   {nm:38s} median {np.median(dlt):7.2f} us   p10 {np.percentile(dlt, 10):7.2f}   p90 {np.percentile(dlt, 90):7.2f}')
+    for col, nm in ((11, 'in-loop wait for the LDS-DMA (vmcnt(0)), wave 0, summed over the K-tiles'), (10, 'in-loop s_barrier (waiting for the other waves), wave 0, summed')):
+        bw = t[:, col].astype(np.float64) / ghz / 1e3
+        print(f'   {nm:78s} median {np.median(bw):7.2f} us   p10 {np.percentile(bw, 10):7.2f}   p90 {np.percentile(bw, 90):7.2f}')
     start = (t[:, 8] - t[:, 8].min()) * 0.01               # us
     end = (t[:, 9] - t[:, 8].min()) * 0.01
     order = np.argsort(start)
