@@ -4,6 +4,7 @@
 //   0: none   1: 8 per wave, two bursts of 4   2: 8 per wave, one behind every 3rd MFMA
 //   3: alternating loader: one wave of each SIMD issues 16 (behind its first 16 MFMAs), its partner none; roles swap per tile
 //   4: as 3, one behind every 2nd MFMA (spread over the whole tile)
+//   5 / 6: the first- / second-dispatched wave of every SIMD issues all 16, every tile
 //   hipcc --offload-arch=gfx950 -O3 dma_role_probe.hip -o dma_role_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -77,6 +78,14 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, const unsi
                         const int p = m >> 1, w = (m & 1) ? (wave ^ 4) : wave;
                         dma16(rs, voff, (unsigned int)(p * 8 + w) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + w) * 1024);
                     }
+                    if (MODE == 5 && (m & 1) == 0 && !upper) {          // the first-dispatched wave of each SIMD loads for both, every tile
+                        const int q = m >> 1, p = q >> 1, w = (q & 1) ? (wave ^ 4) : wave;
+                        dma16(rs, voff, (unsigned int)(p * 8 + w) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + w) * 1024);
+                    }
+                    if (MODE == 6 && (m & 1) == 0 && upper) {           // ... or the second-dispatched one
+                        const int q = m >> 1, p = q >> 1, w = (q & 1) ? (wave ^ 4) : wave;
+                        dma16(rs, voff, (unsigned int)(p * 8 + w) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + w) * 1024);
+                    }
                     if (MODE == 4 && (m & 1) == 0 && loader) {
                         const int q = m >> 1, p = q >> 1, w = (q & 1) ? (wave ^ 4) : wave;
                         dma16(rs, voff, (unsigned int)(p * 8 + w) * 1024u, lds0 + (buf ^ 1) * 65536 + (p * 8 + w) * 1024);
@@ -117,5 +126,8 @@ int main() {
     run<2, 0>("8 per wave, one behind every 3rd MFMA", d, src);    run<2, 1>("8 per wave, one behind every 3rd MFMA", d, src);
     run<3, 0>("alternating loader, 16 behind its first 16 MFMAs", d, src); run<3, 1>("alternating loader, 16 behind its first 16 MFMAs", d, src);
     run<4, 0>("alternating loader, 16 behind every 2nd MFMA", d, src);     run<4, 1>("alternating loader, 16 behind every 2nd MFMA", d, src);
+    run<5, 2>("first-dispatched wave of a SIMD loads all 16 (reads interleaved)", d, src);
+    run<6, 2>("second-dispatched wave of a SIMD loads all 16 (reads interleaved)", d, src);
+    run<2, 2>("8 per wave spread (reads interleaved), again", d, src);
     return 0;
 }
