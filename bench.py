@@ -241,7 +241,9 @@ def main():
                                f'{args.batch} batch ({len(lengths)} seqs, max_len {max_len})',
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
                    'parallelism': f'dp{world} (protein-sharded, logits all-gather over RCCL)' if world > 1 else 'single GPU',
-                   'launch': 'hipGraph replay' if use_graph else 'eager (one ctypes launch per kernel)',
+                   'launch': 'hipGraph replay' if use_graph else
+                             ('eager (one C call for the layer stack: esme_hip_forward)' if (model.c_forward and model._c_forward_ok())
+                              else 'eager (one ctypes launch per kernel)'),
                    'launcher': 'torch.distributed.run (self-launched)' if os.environ.get('ESME_BENCH_SPAWNED') else
                                ('torch.distributed.run' if launched else 'plain python'),
                    'precision': 'high (fp32 residual stream)' if args.high_precision else 'fast (bf16 residual stream)',
