@@ -1,12 +1,20 @@
 // bf16 MFMA GEMM for the packed forward pass:  C = epilogue(A (M,K) @ W (N,K)^T + bias).
 //
 // Both operands are K-contiguous ("NT" GEMM: activations (T,E) row-major, nn.Linear
-// weights (out,in) row-major), which is exactly what v_mfma_f32_32x32x16_bf16 wants: each
-// lane feeds 8 consecutive k of one row.  The product is computed TRANSPOSED -- the MFMA
-// A operand is a 32-row slab of W, the B operand a 32-row slab of activations -- so a lane
-// ends up holding 4 consecutive output columns of one token row per accumulator quad and
-// the epilogue (bias, exact-erf GELU, SiLU*mul, residual add + scale, bf16 rounding) and
-// the C store work on 8-byte row segments without any cross-lane traffic.
+// weights (out,in) row-major), which is exactly what v_mfma_f32_16x16x32_bf16 wants: lane l
+// feeds 8 consecutive k (k chunk l >> 4 of the 32) of row l & 15.  The product is computed
+// TRANSPOSED -- the MFMA A operand is a 16-row slab of W, the B operand a 16-row slab of
+// activations -- so a lane ends up holding 4 consecutive output columns (4 (l >> 4) ..+3 of the
+// fragment's 16) of ONE token row (l & 15) per accumulator fragment and the epilogue (bias,
+// exact-erf GELU, SiLU*mul, residual add + scale, bf16 rounding) and the C store work on
+// 8-byte row segments without any cross-lane traffic.
+//
+// Why 16x16x32 and not 32x32x16 (rounds 1-2): the part runs these GEMMs AT its package power
+// cap, and per FLOP the 16x16x32 form reads and writes its accumulators half as often.  A loop
+// of nothing but MFMAs on random operands: 2 050 TFLOP/s (16x16x32) vs 1 800 (32x32x16); both
+// 2 470 on zeros (tools/lab/mfma_shape_probe.hip, profiles/r03_mfma_shape_probe.txt); the whole
+// K loop +11 % on the model's shapes (profiles/r03_gemm_8phase_lab.txt).  Same LDS image, same
+// 24 ds_read_b128 per wave per K-tile, same bits in the results.
 //
 // Data path per K-tile (BK = 64):  HBM --global_load_lds (16 B/lane, no VGPR round trip)-->
 // LDS [rows][64] bf16, two stages --ds_read_b128--> MFMA fragments.  LDS rows are 128 B, so
@@ -22,19 +30,10 @@
 #include <type_traits>
 
 #ifndef ESME_GEMM_P3N
-#define ESME_GEMM_P3N 4            // eighths of a K-tile's LDS-DMA pieces issued two k-steps early (k-step 3 of the previous tile)
-#endif
-#ifndef ESME_GEMM_K1
-#define ESME_GEMM_K1 0             // 1: the rest is split over k-steps 0 and 1; 0: all of it in k-step 0
+#define ESME_GEMM_P3N 4            // eighths of a K-tile's LDS-DMA pieces issued two sub-steps early (sub-step 3 of the previous tile)
 #endif
 #ifndef ESME_GEMM_PERSIST_ROT
 #define ESME_GEMM_PERSIST_ROT 0
-#endif
-#ifndef ESME_GEMM_MFMA_ORDER
-#define ESME_GEMM_MFMA_ORDER 0
-#endif
-#ifndef ESME_GEMM_SPREAD
-#define ESME_GEMM_SPREAD 1      // 0: the round-1 schedule (two bursts of LDS-DMAs per K-tile); kept for A/B builds
 #endif
 
 namespace esme {
@@ -48,7 +47,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     constexpr int NW = WM * WN;               // waves per block
     constexpr int NT = NW * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int FM = WTM / 32, FN = WTN / 32;
+    constexpr int FM = WTM / 16, FN = WTN / 16;          // 16 x 16 accumulator fragments of the wave tile: FN along n, FM along m
+    constexpr int FMH = FM / 2;                            // a sub-step of the main loop covers half of the wave tile's rows
+    static_assert(FM % 2 == 0, "wave tile rows split in two halves");
     constexpr int A_ROWS_BYTES = BM * 128, W_ROWS_BYTES = BN * 128;
     constexpr int STAGE = A_ROWS_BYTES + W_ROWS_BYTES;
     constexpr int IA = BM * 8 / NT, IW = BN * 8 / NT;      // 16-B chunks per thread per tile
@@ -60,8 +61,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    const int l31 = lane & 31, hi = lane >> 5;
+    // P8: the 8-wave 256 x 256 configuration runs the "8-phase" main loop (below); its two wave groups are the waves that share
+    // SIMDs (w and w + 4), so the row group is wave >> 2 there.
+    constexpr bool P8 = (NW == 8 && WM == 2 && WN == 4 && BM == 256 && BN == 256);
+    const int wm = P8 ? (wave >> 2) : wave % WM, wn = P8 ? (wave & 3) : wave / WM;
+    const int l15 = lane & 15, lq = lane >> 4;           // fragment row this lane feeds / owns; its k chunk (operands) = its column quad (results)
     ESME_TRACE_REAL(8);
     ESME_TRACE_MARK(0);
 
@@ -110,19 +114,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const u16* srcA[IA];
     const u16* srcW[IW];
     auto set_sources = [&]() {
+        // PERSIST: an opaque copy of the lane id, so that the lane-only parts of the 16 addresses are recomputed per tile (a few
+        // VALU) instead of being hoisted out of the tile loop and kept alive -- i.e. spilled -- across main loop and epilogue
+        int ln = lane;
+        if constexpr (PERSIST) asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int q = (i * NW + wave) * 64 + lane;
+            const int q = (i * NW + wave) * 64 + ln;
             const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-            int64_t gr = m0 + row;
+            // P8: LDS rows are grouped in HALF-TILES (see the main loop): LDS row (h, wm', rr) holds tile row wm' * WTM + h * WTM/2 + rr
+            const int trow = P8 ? ((row >> 6) & 1) * WTM + (row >> 7) * (WTM / 2) + (row & 63) : row;
+            int64_t gr = m0 + trow;
             gr = gr < a.M ? gr : a.M - 1;
             srcA[i] = a.A + gr * a.lda + c * 8;
         }
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
-            const int q = (i * NW + wave) * 64 + lane;
+            const int q = (i * NW + wave) * 64 + ln;
             const int row = q >> 3, c = (q & 7) ^ ((row >> 1) & 7);
-            int gr = n0 + row;
+            const int tcol = P8 ? ((row >> 5) & 3) * WTN + (row >> 7) * (WTN / 2) + (row & 31) : row;      // LDS row (h, wn', rr) = tile column wn' * WTN + h * WTN/2 + rr
+            int gr = n0 + tcol;
             gr = gr < a.N ? gr : a.N - 1;
             srcW[i] = a.W + (int64_t)gr * a.K + c * 8;
         }
@@ -141,57 +152,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                                              (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
     };
 
-    // ---- fragment read offsets: row*128 + ((chunk ^ swz) << 4); swz depends on lane only
-    const int swz = (l31 >> 1) & 7;
-    int coff[4];
+    // ---- fragment read offsets: row*128 + ((chunk ^ swz) << 4); swz depends on lane only.  A K-tile is two k-steps of 32.
+    const int swz = (l15 >> 1) & 7;
+    int coff[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((ks * 2 + hi) ^ swz) << 4;
-    const int rowA = (wm * WTM + l31) * 128;                     // activation slab rows (MFMA B operand)
-    const int rowW = A_ROWS_BYTES + (wn * WTN + l31) * 128;      // weight slab rows (MFMA A operand)
+    for (int ks = 0; ks < 2; ++ks) coff[ks] = ((ks * 4 + lq) ^ swz) << 4;
+    const int rowA = (P8 ? wm * (WTM / 2) + l15 : wm * WTM + l15) * 128;                       // activation slab rows (MFMA B operand); P8: inside a half-tile
+    const int rowW = A_ROWS_BYTES + (P8 ? wn * (WTN / 2) + l15 : wn * WTN + l15) * 128;        // weight slab rows (MFMA A operand)
 
-    f32x16 acc[FN][FM];
+    f32x4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     const int KT = a.K / BK;
-    // Main loop.  MFMA fragments are double-buffered in registers: the ds_read_b128s of k-step
-    // s+1 are in flight while the 8 MFMAs of k-step s issue, the LDS-DMA of K-tile t+1 is
-    // spread over k-steps 0/1 of tile t, and the ONE barrier per K-tile sits between the MFMAs
-    // of k-steps 2 and 3 (so the pipe has work queued across it).  sched_barrier pins the order.
-    struct Frag { bf16x8 w[FN], a[FM]; };
-    auto rd = [&](Frag& f, const char* base, int ks) {
+    // Main loop.  A K-tile is FOUR sub-steps (k-step ks = 0, 1 of 32 k  x  row half h = 0, 1 of the wave tile), each
+    // FN * FMH MFMAs on {W fragments of k-step ks, activation fragments of (ks, h)}.  The activation fragments are
+    // double-buffered in registers: the ds_read_b128s of the next sub-step's fragments are in flight while the MFMAs of this one issue,
+    // the LDS-DMA of K-tile t+1 is spread over sub-steps 3 (previous tile) and 0, and the ONE barrier per K-tile sits
+    // between the MFMAs of sub-steps 2 and 3 (so the pipe has work queued across it).  sched_barrier pins the order.
+    struct FragW { bf16x8 v[FN]; };
+    struct FragA { bf16x8 v[FMH]; };
+    auto rdW = [&](FragW& f, const char* base, int ks) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 32 * 128 + coff[ks]);
-#pragma unroll
-        for (int j = 0; j < FM; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(base + rowA + j * 32 * 128 + coff[ks]);
+        for (int i = 0; i < FN; ++i) f.v[i] = *reinterpret_cast<const bf16x8*>(base + rowW + i * 16 * 128 + coff[ks]);
     };
-#if !ESME_GEMM_SPREAD
-    auto mm = [&](const Frag& f) {
+    auto rdA = [&](FragA& f, const char* base, int ks, int h) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FMH; ++j) f.v[j] = *reinterpret_cast<const bf16x8*>(base + rowA + (h * FMH + j) * 16 * 128 + coff[ks]);
     };
-#endif
-#if !ESME_GEMM_SPREAD
-    auto stage_half = [&](int kt, int buf, int h) {            // half of the LDS-DMA of one K-tile
-        char* base = smem + buf * STAGE;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = h * (IA / 2); i < (h + 1) * (IA / 2); ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(base + (i * NW + wave) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = h * (IW / 2); i < (h + 1) * (IW / 2); ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0),
-                                             (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
-    };
-#endif
-    static_assert(IA % 2 == 0 && IW % 2 == 0, "stage_half splits the per-thread chunks in two");
+    static_assert(IA % 2 == 0 && IW % 2 == 0, "the LDS-DMA pieces of a K-tile split in two halves");
     // One LDS-DMA instruction of a K-tile (piece p of NP = IA + IW per thread).  An LDS-DMA holds its wave for 60-180
     // cycles until the memory pipeline has taken it; issued four in a row (stage_half) both waves of a SIMD sit in that
     // stall at the same time and the matrix pipe drains.  The main loop therefore issues the pieces ONE at a time, each
@@ -315,46 +308,139 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     };
     make_strips();
     __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier; publishes the LN strip
-    Frag f0, f1;
+    FragW w0;
+    FragA a0, a1;
 #ifdef ESME_GEMM_TRACE
     unsigned long long trace_barrier_wait = 0, trace_vm_wait = 0;
 #endif
     for (;;) {                                // PERSIST: one pass per tile; otherwise a single pass
     ESME_TRACE_MARK(1);
     if constexpr (PERSIST) set_sources();     // recomputed here so the 16 address registers are dead across the previous epilogue
-    rd(f0, smem + par * STAGE, 0);
-#if ESME_GEMM_SPREAD
-    // One k-step: the FN*FM MFMAs on fragments f, with -- one instruction behind each MFMA -- the ds_read_b128s of the NEXT
-    // k-step's fragments (into nf) and this k-step's share of the LDS-DMA pieces.  Issued as bursts (6 reads, then 8
-    // MFMAs; 4 DMAs in a row) the same instructions cost the loop 12 % (reads) + 1-10 % (DMAs) of the matrix pipe:
-    // both waves of a SIMD run the same code in lockstep, so both sit in the burst at the same time
-    // (tools/lab/dma_role_probe.hip: 2 374 -> 2 103 cycles per K-tile for the reads alone).
-    // Pieces [0, P3) of a K-tile are issued during k-step 3 of the iteration TWO tiles earlier (right after the barrier
-    // that frees their buffer), [P3, P0) during k-step 0 and [P0, NP) during k-step 1 of the previous iteration.
-    constexpr int P3 = (NP * ESME_GEMM_P3N) / 8, P0 = ESME_GEMM_K1 ? P3 + (NP - P3 + 1) / 2 : NP;
-    static_assert(FN + FM <= FN * FM, "one fragment read behind each MFMA");
-    auto kstep = [&](const Frag& f, Frag& nf, const char* nbase, const int nks, const bool rd_on,
-                     const bool on, const int kt, const int buf, auto PF, auto PL) {
-        constexpr int pf = decltype(PF)::value, pl = decltype(PL)::value, cnt = pl - pf, total = FN * FM;
+    if constexpr (P8) {
+    // ---- 8-phase main loop (the CDNA4 guide's 256 x 256 template, rebuilt on this kernel's operand layout; lab version and
+    // ablations: tools/lab/gemm_8phase.hip, profiles/r03_gemm_8phase_lab.txt).  With 16-cycle MFMAs the lockstep schedule below
+    // is ISSUE-bound (two waves per SIMD each interleave a ds_read behind every MFMA: > 16 issue cycles per MFMA slot) and gains
+    // 2-3 % from the 16x16x32 form where this one gains 11 %.  A K-tile is FOUR half-tiles of 128 LDS rows:
+    //   A-h = rows {wm * 128 + h * 64 + [0, 64)},  W-h = columns {wn * 64 + h * 32 + [0, 32)}      (h = 0, 1; all wm / wn)
+    // so every half-tile is consumed by ALL waves in exactly ONE phase and is restaged right after it:
+    //   ph1: read W-h0 (4 x b128), A-h0 (8) | 16 MFMA acc[0..1][0..3] | stage A-h1 of tile t+1
+    //   ph2: read W-h1 (4)                  | 16 MFMA acc[2..3][0..3] | stage W-h0 of tile t+2  (its reads were retired by lgkmcnt(8) in ph1)
+    //   ph3: read A-h1 (8)                  | 16 MFMA acc[2..3][4..7] | stage A-h0 of tile t+2
+    //   ph4: -                              | 16 MFMA acc[0..1][4..7] | stage W-h1 of tile t+2, then vmcnt(6): tile t+1 has landed,
+    //                                                                   three half-tiles of t+2 stay in flight ACROSS the barriers
+    // Each phase = {reads, 2 LDS-DMAs} s_barrier {lgkmcnt(0), 16 MFMAs} s_barrier, raw barriers (no vmcnt drain), and the wave
+    // group of waves 4-7 runs ONE barrier behind waves 0-3: on every SIMD one wave issues its MFMAs back to back while its
+    // partner reads and stages.  A buffer is read one phase after the wait that retires it and restaged >= 2 phases after its
+    // last read (1 after for W-h0, whose reads are retired before the phase's first barrier).
+    if (KT > 1) {                             // first three half-tiles of K-tile 1 (W-h0, A-h0, W-h1); the fourth goes out in phase 1
+        stage_piece(1, par ^ 1, IA); stage_piece(1, par ^ 1, IA + 1);
+        stage_piece(1, par ^ 1, 0); stage_piece(1, par ^ 1, 1);
+        stage_piece(1, par ^ 1, IA + 2); stage_piece(1, par ^ 1, IA + 3);
+    }
+    if (wm == 1) __builtin_amdgcn_s_barrier();                         // stagger: waves 4-7 run one barrier behind
+    bf16x8 fa[FMH][2], fw0[FN / 2][2], fw1[FN / 2][2];
+    constexpr int HALFB = (BM / 2) * 128;                              // bytes of a half-tile
+    auto rdWh = [&](bf16x8 (*f)[2], const char* base, const int h) {
 #pragma unroll
-        for (int m = 0; m < FN * FM; ++m) {
-#if ESME_GEMM_MFMA_ORDER
-                const int j = m / FN, i = m % FN;         // activation fragment held, weight fragment alternates
-#else
-                const int i = m / FM, j = m % FM;         // weight fragment held for FM MFMAs
-#endif
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
-                if (rd_on) {
-                    if (m < FN) nf.w[m] = *reinterpret_cast<const bf16x8*>(nbase + rowW + m * 32 * 128 + coff[nks]);
-                    else if (m < FN + FM) nf.a[m - FN] = *reinterpret_cast<const bf16x8*>(nbase + rowA + (m - FN) * 32 * 128 + coff[nks]);
-                }
+        for (int w = 0; w < FN / 2; ++w)
 #pragma unroll
-                for (int q = 0; q < (cnt > 0 ? cnt : 0); ++q)
-                    if (m == (q * total) / (cnt > 0 ? cnt : 1) && on) stage_piece(kt, buf, pf + q);      // pieces spread from the FIRST MFMA on
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int ks = 0; ks < 2; ++ks) f[w][ks] = *reinterpret_cast<const bf16x8*>(base + rowW + h * HALFB + w * 16 * 128 + coff[ks]);
     };
+    auto rdAh = [&](const char* base, const int h) {
+#pragma unroll
+        for (int f = 0; f < FMH; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *reinterpret_cast<const bf16x8*>(base + rowA + h * HALFB + f * 16 * 128 + coff[ks]);
+    };
+    auto mma = [&](const bf16x8 (*fw)[2], const int i0, const int j0) {       // W half-tile (fragments i0, i0 + 1) x A half-tile (j0 .. j0 + 3)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int w = 0; w < FN / 2; ++w)
+#pragma unroll
+                for (int f = 0; f < FMH; ++f)
+                    acc[i0 + w][j0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[w][ks], fa[f][ks], acc[i0 + w][j0 + f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = (kt + par) & 1;
+        const char* base = smem + buf * STAGE;
+        const bool m1 = kt + 1 < KT, m2 = kt + 2 < KT;
+        // ---- phase 1
+        rdWh(fw0, base, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdAh(base, 0);
+        if (m1) { stage_piece(kt + 1, buf ^ 1, 2); stage_piece(kt + 1, buf ^ 1, 3); }
+        else rot_prefetch(buf ^ 1, 0);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");            // the four W-h0 reads have returned: W-h0 may be restaged in phase 2
+        mma(fw0, 0, 0);
+        // ---- phase 2
+        rdWh(fw1, base, 1);
+        if (m2) { stage_piece(kt + 2, buf, IA); stage_piece(kt + 2, buf, IA + 1); }
+        else if (!m1) rot_prefetch(buf ^ 1, 1);
+        mma(fw1, FN / 2, 0);
+        // ---- phase 3
+        rdAh(base, 1);
+        if (m2) { stage_piece(kt + 2, buf, 0); stage_piece(kt + 2, buf, 1); }
+        mma(fw1, FN / 2, FMH);
+        // ---- phase 4
+        if (m2) { stage_piece(kt + 2, buf, IA + 2); stage_piece(kt + 2, buf, IA + 3); }
+#ifdef ESME_GEMM_TRACE
+        const unsigned long long bw0 = __builtin_readcyclecounter();
+#endif
+        if (m2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // K-tile t+1 has landed; t+2's first three half-tiles stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ESME_GEMM_TRACE
+        trace_vm_wait += __builtin_readcyclecounter() - bw0;
+#endif
+        mma(fw0, 0, FMH);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                         // re-align the groups: every LDS read of the tile is done after this
+    } else {
+    rdW(w0, smem + par * STAGE, 0);
+    rdA(a0, smem + par * STAGE, 0, 0);
+    // One sub-step: the FN * FMH MFMAs on (w, ca), with -- one instruction behind each MFMA -- the ds_read_b128s of the
+    // fragments the NEXT sub-steps need and this sub-step's share of the LDS-DMA pieces.  The MFMAs run weight-fragment-major,
+    // so w.v[i] is dead after its FMH-th MFMA: when the next sub-step changes k-step (NEWW) the new W fragment i is read IN
+    // PLACE right behind that MFMA (one W set in registers, not two: the 16 VGPRs decide between 0 and 17 spilled registers in
+    // the persistent LN-fold kernels), and the activation fragments (nks, nh) go into the other FragA behind the first MFMAs
+    // that carry no W read.  Issued as bursts (reads first, then the MFMAs; 4 DMAs in a row) the same instructions cost the
+    // loop 12 % (reads) + 1-10 % (DMAs) of the matrix pipe: both waves of a SIMD run the same code in lockstep, so both sit
+    // in the burst at the same time (tools/lab/dma_role_probe.hip).
+    // Pieces [0, P3) of a K-tile are issued during sub-step 3 of the iteration TWO tiles earlier (right after the barrier
+    // that frees their buffer), [P3, NP) during sub-step 0 of the previous iteration.
+    constexpr int P3 = (NP * ESME_GEMM_P3N) / 8;
+    static_assert(FMH >= 2, "activation reads need FMH - 1 of every FMH MFMA slots");
     using std::integral_constant;
+    auto sub = [&](FragW& w, const FragA& ca, auto H, auto NEWW, FragA& na, const char* nbase, const int nks,
+                   const int nh, const bool rd_on, const bool on, const int kt, const int buf, auto PF, auto PL) {
+        constexpr int h = decltype(H)::value, pf = decltype(PF)::value, pl = decltype(PL)::value, cnt = pl - pf, total = FN * FMH;
+        constexpr bool neww = decltype(NEWW)::value;
+        int na_next = 0;                                   // (compile-time after unrolling) next activation fragment to read
+#pragma unroll
+        for (int m = 0; m < total; ++m) {
+            const int i = m / FMH, j = m % FMH;            // weight fragment held for FMH MFMAs
+            acc[i][h * FMH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[i], ca.v[j], acc[i][h * FMH + j], 0, 0, 0);
+            if (neww && j == FMH - 1) {
+                if (rd_on) w.v[i] = *reinterpret_cast<const bf16x8*>(nbase + rowW + i * 16 * 128 + coff[nks]);
+            } else if (na_next < FMH) {
+                if (rd_on) na.v[na_next] = *reinterpret_cast<const bf16x8*>(nbase + rowA + (nh * FMH + na_next) * 16 * 128 + coff[nks]);
+                ++na_next;
+            }
+#pragma unroll
+            for (int q = 0; q < (cnt > 0 ? cnt : 0); ++q)
+                if (m == (q * total) / (cnt > 0 ? cnt : 1) && on) stage_piece(kt, buf, pf + q);      // pieces spread from the FIRST MFMA on
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>;
+    using YES = integral_constant<bool, true>; using NO = integral_constant<bool, false>;
     if (KT > 1) {
 #pragma unroll
         for (int p = 0; p < P3; ++p) stage_piece(1, par ^ 1, p);  // lands long before the first barrier of the loop
@@ -365,11 +451,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const bool more = kt + 1 < KT, more2 = kt + 2 < KT;
         if (!more) rot_prefetch(buf ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        kstep(f0, f1, base, 1, true, more, kt + 1, buf ^ 1, integral_constant<int, P3>{}, integral_constant<int, P0>{});
+        sub(w0, a0, I0{}, NO{}, a1, base, 0, 1, true, more, kt + 1, buf ^ 1, integral_constant<int, P3>{}, integral_constant<int, NP>{});
         if (!more) rot_prefetch(buf ^ 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        kstep(f1, f0, base, 2, true, more, kt + 1, buf ^ 1, integral_constant<int, P0>{}, integral_constant<int, NP>{});
-        kstep(f0, f1, base, 3, true, false, 0, 0, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        sub(w0, a1, I1{}, YES{}, a0, base, 1, 0, true, false, 0, 0, I0{}, I0{});
+        sub(w0, a0, I0{}, NO{}, a1, base, 1, 1, true, false, 0, 0, I0{}, I0{});
 #ifdef ESME_GEMM_TRACE
         const unsigned long long bw0 = __builtin_readcyclecounter();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -381,39 +467,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         trace_barrier_wait += __builtin_readcyclecounter() - bw1;
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        kstep(f1, f0, smem + (buf ^ 1) * STAGE, 0, more, more2, kt + 2, buf, integral_constant<int, 0>{}, integral_constant<int, P3>{});
+        sub(w0, a1, I1{}, YES{}, a0, smem + (buf ^ 1) * STAGE, 0, 0, more, more2, kt + 2, buf, I0{}, integral_constant<int, P3>{});
     }
-#else
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = (kt + par) & 1;
-        const char* base = smem + buf * STAGE;
-        const bool more = kt + 1 < KT;
-        rd(f1, base, 1);
-        if (more) stage_half(kt + 1, buf ^ 1, 0);
-        else rot_prefetch(buf ^ 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(f0, base, 2);
-        if (more) stage_half(kt + 1, buf ^ 1, 1);
-        else rot_prefetch(buf ^ 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f1);
-        __builtin_amdgcn_sched_barrier(0);
-        rd(f1, base, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                      // K-tile t+1 landed; every wave's reads of tile t are done
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) rd(f0, smem + (buf ^ 1) * STAGE, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(f1);
-        __builtin_amdgcn_sched_barrier(0);
     }
-#endif
-    // No barrier here: every wave finished its last LDS fragment reads before the barrier inside the final
-    // iteration (the k-step-3 fragments are read ahead of it and nothing is read after it), so the stage
+    // No barrier here (lockstep loop): every wave finished its last LDS fragment reads before the barrier inside the final
+    // iteration (the sub-step-3 fragments are read ahead of it and nothing is read after it), so the stage
     // memory is already free for the epilogue slabs.
     ESME_TRACE_MARK(2);
 #ifdef ESME_GEMM_TRACE
@@ -423,11 +481,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     if (a.nt_store == 3) return;              // tuning hook: main loop only (results discarded)
 #endif
 
-    // ---- epilogue.  Lane owns token row m; accumulator quad g = 4 consecutive output columns.
+    // ---- epilogue.  Lane owns token row j * 16 + l15 of each row fragment j; accumulator fragment (i, j) holds its 4
+    // consecutive output columns i * 16 + 4 * lq .. + 3.
     // Fast path: bias / activation / residual are applied in the accumulator layout, the bf16
     // results go through a wave-private LDS slab (XOR-swizzled 16-B chunks) and leave as
     // 16 B/lane row-contiguous stores -- whole 128-B lines instead of 8-B fragments scattered
-    // over 32 rows (the direct store path measured 1.5x slower end to end).
+    // over 16 rows (the direct store path measured 1.5x slower end to end).
+    // (the epilogue works from its own copy of the lane id: its lane-only offsets are then not kept alive across the main loop)
+    int lane_e = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_e));
+    const int l15 = lane_e & 15, lq = lane_e >> 4, lane = lane_e;
     constexpr int OUTC = (EPI == ESME_EPI_SWIGLU) ? WTN / 2 : WTN;     // output columns per wave
     constexpr int CH = OUTC / 8;                                       // 16-B chunks per slab row
     constexpr int ROWB = OUTC * 2;
@@ -436,7 +499,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // (64 KB in all), so that the other stage buffer can already receive the next tile's first K-tile.
     constexpr int NPASS = PERSIST ? 2 : 1;
     constexpr int RPP = WTM / NPASS;                                   // slab rows per pass
-    constexpr int FMP = FM / NPASS;                                    // 32-row blocks per pass
+    constexpr int FMP = FM / NPASS;                                    // 16-row fragments per pass
     static_assert(!PERSIST || (FM % 2 == 0), "two-pass epilogue");
     const int lastbuf = (a.K / BK - 1 + par) & 1;
     char* slab = smem + (PERSIST ? lastbuf * STAGE : 0) + wave * (RPP * ROWB);
@@ -445,6 +508,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     const int n_out = (EPI == ESME_EPI_SWIGLU) ? (a.N >> 1) : a.N;
     const int nw0 = (EPI == ESME_EPI_SWIGLU) ? ((n0 + wn * WTN) >> 1) : (n0 + wn * WTN);   // first output column of the wave
     const int64_t mw0 = m0 + wm * WTM;
+    // byte offset of the 8-byte quad (slab row r, wave column cl, cl % 4 == 0): 16-B chunk cl / 8 XORed with the row, half (cl / 4) & 1
+    auto slab_off = [&](const int r, const int cl) { return r * ROWB + (((cl >> 3) ^ (r & (CH - 1))) << 4) + (((cl >> 2) & 1) << 3); };
 
     // ---- folded LayerNorm: the GEMM ran on the RAW residual stream with gamma-scaled weights;
     // finish LN(x) W^T + b algebraically per element (fp32), so no normalised copy of x is ever
@@ -452,67 +517,81 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     if constexpr (LNF) {
         f32x2 st[FM];
 #pragma unroll
-        for (int j = 0; j < FM; ++j) st[j] = lnst[wm * WTM + j * 32 + l31];
+        for (int j = 0; j < FM; ++j) st[j] = lnst[wm * WTM + j * 16 + l15];
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+        for (int i = 0; i < FN; ++i) {
+            const int q4 = (wn * WTN + i * 16 + 4 * lq) >> 2;          // float4 index inside the tile
+            const f32x4 c1q = c1s[q4], c2q = c2s[q4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int q4 = (wn * WTN + i * 32 + 8 * g + 4 * hi) >> 2;      // float4 index inside the tile
-                const f32x4 c1q = c1s[q4], c2q = c2s[q4];
+            for (int j = 0; j < FM; ++j)
 #pragma unroll
-                for (int j = 0; j < FM; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[i][j][4 * g + e] = fmaf(st[j][0], acc[i][j][4 * g + e], fmaf(-st[j][1], c1q[e], c2q[e]));
-            }
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][e] = fmaf(st[j][0], acc[i][j][e], fmaf(-st[j][1], c1q[e], c2q[e]));
+        }
     }
 
-    // ---- fused rotary (QKV projection, head dim ROTD | 64): a head never straddles a wave's
-    // 64 output columns and column c pairs with c + ROTD/2, a multiple of 8 away -- i.e. the
-    // SAME lane, another accumulator quad.  Bias is added first, then q/k columns are rotated
+    // ---- fused rotary (QKV projection, head dim ROTD = 32 or 64): a head never straddles a wave's
+    // 64 output columns and column c pairs with c + ROTD/2, a multiple of 16 away -- i.e. the
+    // SAME lane, another accumulator fragment.  Bias is added first, then q/k columns are rotated
     // in the accumulators (fp32, bf16 tables), so rotary costs no HBM pass of its own.
     if constexpr (ROTD > 0) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+        for (int i = 0; i < FN; ++i) {
+            if (LNF || !a.bias) continue;
+            const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + nw0 + i * 16 + 4 * lq);
+            const float b0 = bf_lo(bw[0]), b1 = bf_hi(bw[0]), b2 = bf_lo(bw[1]), b3 = bf_hi(bw[1]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (LNF || !a.bias) continue;
-                const u32x2 bw = *reinterpret_cast<const u32x2*>(a.bias + nw0 + i * 32 + 8 * g + 4 * hi);
-                const float b0 = bf_lo(bw[0]), b1 = bf_hi(bw[0]), b2 = bf_lo(bw[1]), b3 = bf_hi(bw[1]);
-#pragma unroll
-                for (int j = 0; j < FM; ++j) {
-                    acc[i][j][4 * g] += b0; acc[i][j][4 * g + 1] += b1; acc[i][j][4 * g + 2] += b2; acc[i][j][4 * g + 3] += b3;
-                }
+            for (int j = 0; j < FM; ++j) {
+                acc[i][j][0] += b0; acc[i][j][1] += b1; acc[i][j][2] += b2; acc[i][j][3] += b3;
             }
+        }
         // cos/sin rows of the tile's positions were prefetched during the last K-tile into the stage buffer that
         // was free by then (rot_prefetch; shared by the WN waves of a row group; the main loop's last barrier
-        // published them), so the accumulator quads read them straight from LDS.
+        // published them), so the accumulator fragments read them straight from LDS.
         const char* tab = smem + (lastbuf ^ 1) * STAGE + wm * (WTM * TB);
         if (nw0 < a.rot_cols) {                               // wave-uniform: whole heads of q or k
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                const int r = j * 32 + l31;
-                const char* trow = tab + r * TB + hi * 8;
+                const int r = j * 16 + l15;
+                const char* trow = tab + r * TB + (lq & 1) * 8;          // this lane's 4 columns are half (lq & 1) of a 16-B table chunk
+                if constexpr (ROTD == 16) {
+                    // one fragment = one head: column 4 lq + e pairs with 4 (lq ^ 2) + e, i.e. the same register of lane ^ 32
+                    const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((0 ^ (r & 1)) << 4));
+                    const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + ((1 ^ (r & 1)) << 4));
+                    const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
+                    const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {                 // q = quad index i*4+g over the 64 columns
+                    for (int i = 0; i < FN; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned int own = __float_as_uint(acc[i][j][e]);
+                            const auto sw2 = __builtin_amdgcn_permlane32_swap(own, own, false, false);   // {[lo | lo], [hi | hi]}
+                            const float other = __uint_as_float(lq < 2 ? sw2[1] : sw2[0]);
+                            const float t = __fmul_rn(other, sv[e]);
+                            acc[i][j][e] = fmaf(acc[i][j][e], cv[e], lq < 2 ? -t : t);       // lower half: lo c - up s; upper: up c + lo s
+                        }
+                } else {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
                     constexpr int HALF = ROTD / 2;
-                    const int c0 = q * 8;                     // first column of the quad pair (per hi: +4)
-                    if ((c0 % ROTD) >= HALF) continue;        // upper half of a head: handled with its partner
-                    const int q2 = (c0 + HALF) / 8;           // partner quad
-                    const int cc = (c0 % ROTD) / 8;           // cos chunk; the sin chunk sits CPRW/2 further
+                    const int hc = (i * 16) % ROTD;           // first column of the fragment inside its head
+                    if (hc >= HALF) continue;                 // upper half of a head: handled with its partner
+                    const int i2 = i + HALF / 16;             // partner fragment (same lane, same column quad)
+                    const int cc = (hc >> 3) + (lq >> 1);     // cos chunk of the lane's quad; the sin chunk sits CPRW/2 further
                     const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((cc ^ (r & (CPRW - 1))) << 4));
                     const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + (((cc + CPRW / 2) ^ (r & (CPRW - 1))) << 4));
                     const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
                     const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float lo = acc[q >> 2][j][4 * (q & 3) + e], up = acc[q2 >> 2][j][4 * (q2 & 3) + e];
+                        const float lo = acc[i][j][e], up = acc[i2][j][e];
                         // one product rounded, one fused: spelled out so that every tile configuration contracts the
                         // same way (hipcc chose different fma pairings per instantiation: 1-ulp differences between a
                         // sequence run alone and the same sequence inside a 50 000-residue batch)
-                        acc[q >> 2][j][4 * (q & 3) + e] = fmaf(lo, cv[e], -__fmul_rn(up, sv[e]));
-                        acc[q2 >> 2][j][4 * (q2 & 3) + e] = fmaf(up, cv[e], __fmul_rn(lo, sv[e]));
+                        acc[i][j][e] = fmaf(lo, cv[e], -__fmul_rn(up, sv[e]));
+                        acc[i2][j][e] = fmaf(up, cv[e], __fmul_rn(lo, sv[e]));
                     }
+                }
                 }
             }
         }
@@ -526,23 +605,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // Branch-free: every load of the epilogue (bias quads, residual quads) is issued up front
         // with clamped addresses (overhanging rows/columns are computed but never stored), so the
         // wave pays ONE memory latency, not one per quad.
-        constexpr int FNE = (EPI == ESME_EPI_SWIGLU) ? 1 : FN;
-        u32x2 bq[FNE][4];
+        constexpr int FNE = (EPI == ESME_EPI_SWIGLU) ? FN / 2 : FN;        // (SwiGLU: fragments i and i + FN / 2 are gate and fc of the same output columns)
+        u32x2 bq[FNE];
         if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0 && !LNF) {
             if (a.bias) {
 #pragma unroll
-                for (int i = 0; i < FNE; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        int n = nw0 + i * 32 + 8 * g + 4 * hi;
-                        n = n < a.N - 4 ? n : a.N - 4;
-                        bq[i][g] = *reinterpret_cast<const u32x2*>(a.bias + n);
-                    }
+                for (int i = 0; i < FNE; ++i) {
+                    int n = nw0 + i * 16 + 4 * lq;
+                    n = n < a.N - 4 ? n : a.N - 4;
+                    bq[i] = *reinterpret_cast<const u32x2*>(a.bias + n);
+                }
             } else {
 #pragma unroll
-                for (int i = 0; i < FNE; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) bq[i][g] = u32x2{0u, 0u};
+                for (int i = 0; i < FNE; ++i) bq[i] = u32x2{0u, 0u};
             }
         }
         // Residual tile: fetched with the LDS-DMA in whole 128-B lines straight into this wave's
@@ -570,42 +645,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         ESME_TRACE_MARK(4);
 #pragma unroll
         for (int i = 0; i < FNE; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = i * 32 + 8 * g + 4 * hi;                 // column inside the wave slab
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0 && !LNF) {
-                    bv[0] = bf_lo(bq[i][g][0]); bv[1] = bf_hi(bq[i][g][0]); bv[2] = bf_lo(bq[i][g][1]); bv[3] = bf_hi(bq[i][g][1]);
-                }
-#pragma unroll
-                for (int jj = 0; jj < FMP; ++jj) {
-                    const int j = pass * FMP + jj;
-                    const int r = jj * 32 + l31;                        // row inside this pass's slab
-                    float o[4];
-                    if constexpr (EPI == ESME_EPI_SWIGLU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float gate = acc[0][j][4 * g + e], fc = acc[1][j][4 * g + e];
-                            o[e] = gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gate)) * fc;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] + bv[e];
-                        if constexpr (EPI == ESME_EPI_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
-                        }
-                        if constexpr (EPI == ESME_EPI_RESIDUAL) {
-                            const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3));
-                            o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
-                            o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
-                        }
-                    }
-                    u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
-                    *reinterpret_cast<u32x2*>(slab + r * ROWB + ((((cl >> 3)) ^ (r & (CH - 1))) << 4) + (hi << 3)) = pk;
-                }
-                if constexpr (EPI == ESME_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later quads from being hoisted (VGPRs)
+            const int cl = i * 16 + 4 * lq;                             // column inside the wave slab
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI != ESME_EPI_SWIGLU && ROTD == 0 && !LNF) {
+                bv[0] = bf_lo(bq[i][0]); bv[1] = bf_hi(bq[i][0]); bv[2] = bf_lo(bq[i][1]); bv[3] = bf_hi(bq[i][1]);
             }
+#pragma unroll
+            for (int jj = 0; jj < FMP; ++jj) {
+                const int j = pass * FMP + jj;
+                const int r = jj * 16 + l15;                            // row inside this pass's slab
+                float o[4];
+                if constexpr (EPI == ESME_EPI_SWIGLU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gate = acc[i][j][e], fc = acc[i + FN / 2][j][e];
+                        o[e] = gate * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gate)) * fc;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] + bv[e];
+                    if constexpr (EPI == ESME_EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+                    }
+                    if constexpr (EPI == ESME_EPI_RESIDUAL) {
+                        const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));
+                        o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
+                        o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
+                    }
+                }
+                u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = pk;
+            }
+            if constexpr (EPI == ESME_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later fragments from being hoisted (VGPRs)
         }
         __builtin_amdgcn_wave_barrier();
         ESME_TRACE_MARK(5);
@@ -677,21 +749,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         if constexpr (EPI != ESME_EPI_SWIGLU) {
     #pragma unroll
             for (int i = 0; i < FN; ++i) {
+                const int n = nw0 + i * 16 + 4 * lq;
     #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nw0 + i * 32 + 8 * g + 4 * hi;
+                for (int j = 0; j < FM; ++j) {
+                    const int64_t m = mw0 + j * 16 + l15;
+                    if (m >= a.M) continue;
     #pragma unroll
-                    for (int j = 0; j < FM; ++j) {
-                        const int64_t m = mw0 + j * 32 + l31;
-                        if (m >= a.M) continue;
-    #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (n + e < a.N) {
-                                float v = acc[i][j][4 * g + e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
-                                if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
-                                if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
-                                a.C[m * a.ldc + n + e] = f2bf(v);
-                            }
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < a.N) {
+                            float v = acc[i][j][e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
+                            if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
+                            if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
+                            a.C[m * a.ldc + n + e] = f2bf(v);
                         }
                     }
                 }
@@ -707,7 +776,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
             for (int j = 0; j < FM; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
         __syncthreads();                      // the next tile's K-tile 0 has landed (vmcnt) and its strips are published;
                                               // every wave is done with this tile's slabs
     }
