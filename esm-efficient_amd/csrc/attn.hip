@@ -752,15 +752,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 
 using namespace esme;
 
-static int g_force_qb = 0;      // test hook: force q-blocks per wave (0 = heuristic)
-extern "C" void esme_hip_debug_set_attn_qb(int v) { g_force_qb = v; }
-static int g_attn_variant = 0;  // test / tuning hook: 0 = heuristic, 1 = first-generation kernel, 4 / 8 = ping-pong with 4 / 8 waves
-extern "C" void esme_hip_debug_set_attn_variant(int v) { g_attn_variant = v; }
-static float g_attn_thr = 8.0f; // defer-max threshold, log2 units
-extern "C" void esme_hip_debug_set_attn_thr(float v) { g_attn_thr = v; }
-static int g_attn_spec = 1;     // speculative softmax in the ping-pong kernel
-extern "C" void esme_hip_debug_set_attn_spec(int v) { g_attn_spec = v; }
-
 template <int NW>
 static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     constexpr int smem = 4 * (KT * 64 * 2 + 64 * 128);
@@ -781,8 +772,15 @@ static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     return check_launch("attn_varlen_fwd");
 }
 
+// (per-call options, esme_attn_opts_t: no process-global tuning state; NULL = the defaults below)
 static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o, int64_t ld_o, const int32_t* cu_lens,
-                    int B, int64_t T, int H, int d, int max_len, float softmax_scale, void* stream, bool exact) {
+                    int B, int64_t T, int H, int d, int max_len, float softmax_scale, void* stream, bool exact,
+                    const esme_attn_opts_t* opts) {
+    ESME_CHECK_ARG(!opts || opts->struct_bytes == (int)sizeof(esme_attn_opts_t), "attn: options struct of another ABI");
+    const int g_attn_variant = opts ? opts->variant : 0;       // 0 = heuristic, 1 = first-generation kernel, 4 / 8 = ping-pong with 4 / 8 waves
+    const int g_force_qb = opts ? opts->q_blocks : 0;          // first-generation kernel: q-blocks per wave (0 = heuristic)
+    const float g_attn_thr = opts ? opts->defer_max_thr : 8.0f;   // defer-max threshold, log2 units
+    const int g_attn_spec = opts ? opts->speculative : 1;      // speculative softmax in the ping-pong kernel
     ESME_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && d > 0 && max_len >= 0, "attn: bad sizes");
     if (T == 0 || B == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && v && o && cu_lens, "attn: null pointer");
@@ -828,11 +826,17 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
 extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
                                         int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
                                         int max_len, float softmax_scale, void* stream) {
-    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, false);
+    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, false, nullptr);
+}
+
+extern "C" int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
+                                             int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                             int max_len, float softmax_scale, const esme_attn_opts_t* opts, void* stream) {
+    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, false, opts);
 }
 
 extern "C" int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,
                                               int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
                                               int max_len, float softmax_scale, void* stream) {
-    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, true);
+    return attn_fwd(q, k, v, ld_qkv, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, stream, true, nullptr);
 }

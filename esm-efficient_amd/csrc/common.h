@@ -58,24 +58,42 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
-// erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)) -- the form the reference uses (nn.GELU() /
+// erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x) -- the form the reference uses (nn.GELU() /
 // F.gelu default: attention.py:233, head.py:26), NOT the tanh approximation.  Written as
-//     gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)
-// (no 1 - erf cancellation, so the negative tail keeps its relative accuracy) with erfc from
-// Abramowitz-Stegun 7.1.26, erfc(z) = t (a1 + t (a2 + ... a5 t)) exp(-z^2), t = 1/(1 + p z)
-// (|error| <= 1.5e-7); the -0.5 is folded into the coefficients and 1/sqrt 2 into p and the
-// exponent.  Measured max |error| vs float64 erf-GELU over [-12, 12]: 3.3e-7, i.e. < 1 bf16
-// half-ulp of the result for |x| < 5.  14 VALU ops (2 transcendental) instead of libm erff's ~40:
-// the FFN-up epilogue evaluates it T x 4E times per layer with the MFMA pipe idle.
+//     gelu(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-z) = 2^p(z)
+// (no 1 - erf cancellation: the negative tail keeps its RELATIVE accuracy, which torch's own fp32 formula loses below
+// x = -4) with p a minimax polynomial of log2 Phi(-z) on [0, 6]: log2 Phi(-z) is smooth (~ -0.72 z^2 - log2 z), so one
+// polynomial covers the whole range where the tail term matters, and its leading coefficient is negative, so beyond z = 6
+// it keeps falling (max over [6, 300] is its value at 6, -29.9) and 2^p underflows to the exact limit max(x, 0) -- no clamp.
+// Degree 5 (shipped): |p - log2 Phi| <= 5.3e-4, i.e. relative error of the tail term <= 3.7e-4; against float64 x Phi(x) over
+// ALL finite bf16 inputs the error is <= 0.19 of HALF a bf16 ulp of the result (floor 1.5e-7 |x|: what torch's own fp32
+// formula resolves) -- next to the +-1/2 ulp of the bf16 rounding that follows it adds 1.5 % to the rms error.
+// tests/test_host_cpu.py::test_gelu_polynomial_all_bf16_inputs pins the same fp32 arithmetic in numpy, the GPU kernel
+// test compares the epilogue with torch.  Degree 7 (-DESME_GELU_DEG=7): 4.7e-6 / 0.002 of half an ulp, two more FMAs.
+// Cost: 7 full-rate VALU + 1 transcendental (v_exp_f32), against 12 + 2 for the round-1/2 Abramowitz-Stegun erfc (rcp + exp):
+// the FFN-up epilogue evaluates it T x 4E times per layer with the MFMA pipe idle, and every VALU instruction per element
+// costs that launch ~6.5 us (measured: A-S +77 us, degree 7 +60 us, degree 5 +46 us over the plain epilogue).
+#ifndef ESME_GELU_DEG
+#define ESME_GELU_DEG 5
+#endif
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418897f, ax, 1.0f));
-    float p = fmaf(t, -0.5307027145f, 0.7265760135f);      // -0.5 * a5, -0.5 * a4
-    p = fmaf(t, p, -0.7107068705f);                         // -0.5 * a3
-    p = fmaf(t, p, 0.142248368f);                           // -0.5 * a2
-    p = fmaf(t, p, -0.127414796f);                          // -0.5 * a1
-    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044f);   // exp(-x^2 / 2)
-    return fmaf(ax, (p * t) * e, fmaxf(x, 0.0f));
+    const float z = fabsf(x);
+#if ESME_GELU_DEG == 7
+    float p = fmaf(z, -1.8348100638831966e-06f, 6.159828626550734e-05f);
+    p = fmaf(z, p, -0.0009305249550379813f);
+    p = fmaf(z, p, 0.008507892489433289f);
+    p = fmaf(z, p, -0.05396007373929024f);
+    p = fmaf(z, p, -0.4584643840789795f);
+    p = fmaf(z, p, -1.1512510776519775f);
+    p = fmaf(z, p, -0.9999952912330627f);
+#else
+    float p = fmaf(z, -0.00020168392802588642f, 0.004467579070478678f);
+    p = fmaf(z, p, -0.04283246025443077f);
+    p = fmaf(z, p, -0.47278666496276855f);
+    p = fmaf(z, p, -1.1443983316421509f);
+    p = fmaf(z, p, -1.0005322694778442f);
+#endif
+    return fmaf(-z, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
 
 // Observed dispatcher policy: block b runs on XCD b % 8.  Remap so each XCD (own L2)

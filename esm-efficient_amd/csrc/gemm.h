@@ -33,6 +33,7 @@ struct GemmArgs {
     int64_t stat_ld = 0;         // row count of the FULL problem = block stride of ln_partial / stats_out ((nblk, stat_ld, 2));
                                  // a launch may cover a row range of it (tail split, see esme_hip_gemm_bf16_fused)
     unsigned long long* trace = nullptr;      // ESME_GEMM_TRACE builds only: per-block phase timestamps (16 per block)
+    int opt_gm = 0, opt_gn = 0, opt_persist = -1;   // host side: per-call options (esme_gemm_opts_t); 0 / -1 = heuristic
 };
 
 // The tuning hooks (start skew, "no C store", "loop only") exist only in the instrumented build (`make TRACE=1`);

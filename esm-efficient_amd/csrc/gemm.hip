@@ -783,19 +783,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     }   // tile loop
 }
 
-static int g_raster_gm = 0, g_raster_gn = 0;      // test/tuning hook (0 = heuristic)
-static int g_persist = -1;                         // persistent 256 x 256 workgroups: -1 = not resolved yet (env ESME_GEMM_PERSIST, else the
-                                                   // default below); tuning hook esme_hip_debug_set_gemm_persist
-static int persist_on() {
-    if (g_persist < 0) {
-        const char* e = getenv("ESME_GEMM_PERSIST");
-        g_persist = e ? (atoi(e) != 0) : 1;
-    }
-    return g_persist;
+// Persistent 256 x 256 workgroups are on unless ESME_GEMM_PERSIST=0 (read once; immutable afterwards) or the call's
+// options say otherwise.  No mutable process-global tuning state: per-call options travel in GemmArgs.
+static int persist_default() {
+    static const int v = [] { const char* e = getenv("ESME_GEMM_PERSIST"); return e ? (atoi(e) != 0) : 1; }();
+    return v;
 }
 static int cu_count();
-static int g_nt_store = 0;
+#ifdef ESME_GEMM_TRACE
+static int g_nt_store = 0;                         // instrumented build only (libesme_hip_trace.so): timing experiments
 static int g_stagger = 0;
+#endif
 
 // Choose the tile walk.  If the whole weight matrix fits an XCD's L2 (4 MB) next to the
 // streaming activations, plain row-major order is already optimal (W stays resident, every
@@ -806,7 +804,7 @@ static void set_raster(GemmArgs& a) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.tiles_m = (int)((a.M + BM - 1) / BM);
     const double w_bytes = 2.0 * a.N * a.K;
-    if (g_raster_gm > 0) { a.gm = g_raster_gm; a.gn = g_raster_gn > 0 ? g_raster_gn : a.tiles_n; }
+    if (a.opt_gm > 0) { a.gm = a.opt_gm; a.gn = a.opt_gn > 0 ? a.opt_gn : a.tiles_n; }
     else if (w_bytes <= 3.5e6 || a.tiles_n <= 6) { a.gm = 1; a.gn = a.tiles_n; }   // few columns: a row-major
                                                                                      // wavefront is already a g x tiles_n group
     else if (a.tiles_n % 5 == 0) { a.gm = 6; a.gn = 5; }                           // groups that tile the width evenly (N = 5 120: 20 columns):
@@ -828,7 +826,8 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
         // Big tiles run one workgroup per CU (128 KB of LDS): once a launch is several rounds long, ONE persistent
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
-        if (persist_on() && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true>(a, s);
+        const bool want = a.opt_persist < 0 ? persist_default() != 0 : a.opt_persist != 0;
+        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true>(a, s);
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST>;
@@ -873,12 +872,6 @@ static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hip
 
 using namespace esme;
 
-// test / tuning hooks.  Not part of the documented ABI.
-static int g_force_tile = 0;
-extern "C" void esme_hip_debug_set_gemm_tile(int t) { g_force_tile = t; }
-static int g_split = 0;           // tail split of 256 x 256 launches: tuning hook, OFF (measured 1 % slower end to end, see below)
-extern "C" void esme_hip_debug_set_gemm_split(int v) { g_split = v; }
-
 // compute units of the current device (cached per device ordinal; 256 on MI355X)
 static int esme::cu_count() {
     static std::atomic<int> cached[64];
@@ -891,29 +884,33 @@ static int esme::cu_count() {
     }
     return v;
 }
-extern "C" void esme_hip_debug_set_gemm_raster(int gm, int gn) { g_raster_gm = gm; g_raster_gn = gn; }
-extern "C" void esme_hip_debug_set_gemm_persist(int v) { esme::g_persist = v; }
-extern "C" void esme_hip_debug_set_gemm_nt(int v) { g_nt_store = v; }
-extern "C" void esme_hip_debug_set_gemm_stagger(int v) { g_stagger = v; }
-static unsigned long long* g_trace = nullptr;     // honoured by ESME_GEMM_TRACE builds only
+#ifdef ESME_GEMM_TRACE
+// Instrumented build only (make TRACE=1 -> libesme_hip_trace.so, tools/gemm_phase_trace.py): never in the shipped library.
+extern "C" void esme_hip_debug_set_gemm_nt(int v) { esme::g_nt_store = v; }
+extern "C" void esme_hip_debug_set_gemm_stagger(int v) { esme::g_stagger = v; }
+static unsigned long long* g_trace = nullptr;
 extern "C" void esme_hip_debug_set_gemm_trace(void* p) { g_trace = (unsigned long long*)p; }
+#endif
 
 // 256x256 tiles (one workgroup per CU) once they fill the chip about twice over; otherwise the
 // 128x128 configuration (2-3 workgroups per CU, 4x the tiles) keeps more CUs busy.
-static int pick_tile(int64_t M, int N) {
-    if (g_force_tile) return g_force_tile;
+static int pick_tile(int64_t M, int N, const esme_gemm_opts_t* opts) {
+    if (opts && opts->tile) return opts->tile;
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
     return (N >= 256 && big_tiles >= 384) ? 2 : 1;
 }
 
-extern "C" int esme_hip_gemm_stats_blocks(int64_t M, int N) {
-    const int bn = pick_tile(M, N) == 2 ? 256 : 128;      // one partial per column tile of the configuration the launch picks
+extern "C" int esme_hip_gemm_stats_blocks_opts(int64_t M, int N, const esme_gemm_opts_t* opts) {
+    const int bn = pick_tile(M, N, opts) == 2 ? 256 : 128;      // one partial per column tile of the configuration the launch picks
     return (N + bn - 1) / bn;
 }
+extern "C" int esme_hip_gemm_stats_blocks(int64_t M, int N) { return esme_hip_gemm_stats_blocks_opts(M, N, nullptr); }
 
-extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
-                                        int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
-                                        float alpha, const esme_gemm_fusion_t* fu, void* stream) {
+extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
+                                       int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                                       float alpha, const esme_gemm_fusion_t* fu, const esme_gemm_opts_t* opts, void* stream) {
+    ESME_CHECK_ARG(!opts || (opts->struct_bytes == (int)sizeof(esme_gemm_opts_t) && opts->tile >= 0 && opts->tile <= 2),
+                   "gemm: options struct of another ABI or bad tile");
     ESME_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm: bad sizes");
     ESME_CHECK_ARG(epilogue >= ESME_EPI_NONE && epilogue <= ESME_EPI_SWIGLU, "gemm: unknown epilogue");
     if (M == 0) return ESME_OK;
@@ -933,8 +930,11 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
     }
     if (epilogue == ESME_EPI_SWIGLU && !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: swiglu needs ldc % 8 == 0 and a 16-byte aligned C");
     GemmArgs a{(const u16*)A, lda, (const u16*)W, (const u16*)bias, (const u16*)resid, ldr, (u16*)C, ldc, M, N, K, alpha, 0, vec_ok,
-               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, g_nt_store, g_stagger, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr};
-    a.trace = g_trace;
+               nullptr, nullptr, nullptr, 0, 0, 0, 1, 1, 0, 0, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr};
+#ifdef ESME_GEMM_TRACE
+    a.nt_store = g_nt_store; a.stagger = g_stagger; a.trace = g_trace;
+#endif
+    if (opts) { a.opt_gm = opts->raster_gm; a.opt_gn = opts->raster_gn; a.opt_persist = opts->persist; }
     int rotd = 0;
     bool lnf = false, stats = false;
     if (fu) {
@@ -970,43 +970,18 @@ extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* 
     }
     const hipStream_t s = (hipStream_t)stream;
     a.stat_ld = M;
-    const int tile = pick_tile(M, N);
+    const int tile = pick_tile(M, N, opts);
     if (tile == 1) return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
-    if (tile != 2) ESME_FAIL(ESME_ERR_ARG, "gemm: bad forced tile");
-    // Tail split.  256 x 256 tiles run one workgroup per CU, so a launch takes ceil(tiles / CUs) rounds and the last
-    // round is as long as a full one however few tiles it holds (50 000 x 5 120: 3 920 tiles = 15.3 rounds on 256 CUs).
-    // When the last round would be less than ~70 % full, the big-tile launch stops at the last row of tiles that keeps
-    // its rounds full and the remaining rows run as 128 x 128 tiles (two workgroups per CU, ~0.3 of a big tile each) in
-    // a second launch: ~0.35 round instead of 1.  Both configurations produce the same bits (tests), and the row
-    // statistics of the residual epilogue are per 64 columns in either.
-    // MEASURED (tools/gemm_split_ab.py, interleaved A/B, ESM2-650M, 50 000 residues): 76.3 ms with the split vs 75.5 ms
-    // without -- the few workgroups of a short last round run at a higher clock on a power-capped part (idle CUs hand
-    // their power budget over) and the 128 x 128 tiles are less efficient, so the "lost" 0.7 round is mostly not lost.
-    // Kept behind esme_hip_debug_set_gemm_split(1) for other shapes / parts; off by default.
-    const int64_t tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256, total = tiles_m * tiles_n;
-    const int ncu = cu_count();
-    const int64_t rounds = total / ncu, rem = total % ncu;
-    int64_t rows_big = tiles_m;
-    if (g_split && rounds >= 2 && rem != 0 && rem * 10 < (int64_t)ncu * 7) {
-        rows_big = (rounds * ncu) / tiles_n;                       // whole rows of big tiles that fit the full rounds
-        const int64_t m_rest = M - rows_big * 256;
-        const int64_t small = ((m_rest + 127) / 128) * ((N + 127) / 128);
-        if (m_rest <= 0 || small > 3 * 2 * (int64_t)ncu) rows_big = tiles_m;      // remainder too large to pay off
-    }
-    if (rows_big == tiles_m) return launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);      // wave tile 128(m) x 64(n)
-    const int64_t m1 = rows_big * 256;
-    GemmArgs b = a;
-    a.M = m1;
-    int rc = launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);
-    if (rc != ESME_OK) return rc;
-    b.M = M - m1;
-    b.A += m1 * b.lda;
-    b.C += m1 * b.ldc;
-    if (b.resid) b.resid += m1 * b.ldr;
-    if (b.pos) b.pos += m1;
-    if (b.ln_partial) b.ln_partial += 2 * m1;
-    if (b.stats_out) b.stats_out += 2 * m1;
-    return launch_gemm<128, 128, 2, 2>(b, epilogue, rotd, lnf, stats, s);
+    // 256 x 256 tiles run one workgroup per CU, so a launch takes ceil(tiles / CUs) rounds.  (Round 2 measured a "tail split"
+    // -- the last, partly empty round as 128 x 128 tiles in a second launch -- 1 % SLOWER end to end on this power-capped
+    // part; the code is gone.)
+    return launch_gemm<256, 256, 2, 4>(a, epilogue, rotd, lnf, stats, s);      // wave tile 128(m) x 64(n)
+}
+
+extern "C" int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,
+                                        int64_t ldr, void* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                                        float alpha, const esme_gemm_fusion_t* fu, void* stream) {
+    return esme_hip_gemm_bf16_opts(A, lda, W, bias, resid, ldr, C, ldc, M, N, K, epilogue, alpha, fu, nullptr, stream);
 }
 
 extern "C" int esme_hip_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, const void* resid,

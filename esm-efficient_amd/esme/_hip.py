@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 from typing import Optional
 
@@ -26,6 +27,16 @@ class GemmFusion(Structure):
     _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int)]
+
+
+class GemmOpts(Structure):
+    """esme_gemm_opts_t (include/esme_hip.h): per-call kernel selection for tests and tuning."""
+    _fields_ = [('struct_bytes', c_int), ('tile', c_int), ('raster_gm', c_int), ('raster_gn', c_int), ('persist', c_int)]
+
+
+class AttnOpts(Structure):
+    """esme_attn_opts_t (include/esme_hip.h)."""
+    _fields_ = [('struct_bytes', c_int), ('variant', c_int), ('q_blocks', c_int), ('defer_max_thr', c_float), ('speculative', c_int)]
 
 
 class LayerWeights(Structure):
@@ -59,6 +70,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_attn_varlen_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                          c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_attn_varlen_fwd_opts': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                                              c_int64, c_int, c_int, c_int, c_float, POINTER(AttnOpts), c_void_p]),
     'esme_hip_attn_varlen_fwd_exact': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                                c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
@@ -72,6 +85,9 @@ SIGNATURES = {
     'esme_hip_gemm_bf16_fused': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, POINTER(GemmFusion), c_void_p]),
     'esme_hip_gemm_stats_blocks': (c_int, [c_int64, c_int]),
+    'esme_hip_gemm_stats_blocks_opts': (c_int, [c_int64, c_int, POINTER(GemmOpts)]),
+    'esme_hip_gemm_bf16_opts': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                        c_int64, c_int, c_int, c_int, c_float, POINTER(GemmFusion), POINTER(GemmOpts), c_void_p]),
     'esme_hip_forward_workspace_bytes': (c_int64, [POINTER(ModelDesc), c_int64]),
     'esme_hip_forward': (c_int, [POINTER(ModelDesc), c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
@@ -141,11 +157,6 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.esme_hip_abi_version() != ABI_VERSION:
         raise HipLibraryError(f'{_LIB_NAME} ABI {lib.esme_hip_abi_version()} != binding {ABI_VERSION}')
-    try:
-        lib.esme_hip_debug_set_gemm_tile.restype = None
-        lib.esme_hip_debug_set_gemm_tile.argtypes = [c_int]
-    except AttributeError:
-        pass
     _lib = lib
     return lib
 
@@ -156,8 +167,78 @@ def _check(code: int, what: str):
         raise RuntimeError(f'{what} failed (code {code}): {msg}')
 
 
-_PINNED_STREAM = None           # set by stream_scope(): one current_stream() lookup per forward, not per launch
-_PINNED_DEVICE = None           # device ordinal the pinned stream belongs to
+class _ThreadState(threading.local):
+    """Per host thread: the (device, stream) pinned by stream_scope() -- one current_stream() lookup per forward, not per
+    launch -- and the per-call kernel options of gemm_options() / attn_options().  Thread-local, so two host threads can
+    drive two GPUs (or two streams) from one process; the library itself holds no mutable global state either."""
+    stream = None
+    device = None
+    gemm_opts = None
+    attn_opts = None
+
+
+_TLS = _ThreadState()
+
+
+class gemm_options:
+    """`with _hip.gemm_options(tile=2, persist=0):` -- every GEMM launched by THIS thread inside the block goes through
+    esme_hip_gemm_bf16_opts with these per-call options (tests and tuning: force a tile configuration, a tile walk, or
+    one workgroup per tile).  tile: 0 heuristic, 1 = 128 x 128, 2 = 256 x 256; persist: -1 default, 0, 1."""
+
+    def __init__(self, tile: int = 0, raster=(0, 0), persist: int = -1):
+        self.opts = GemmOpts(ctypes.sizeof(GemmOpts), int(tile), int(raster[0]), int(raster[1]), int(persist))
+
+    def __enter__(self):
+        self.prev, _TLS.gemm_opts = _TLS.gemm_opts, self.opts
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.gemm_opts = self.prev
+        return False
+
+
+def set_gemm_options(**kw) -> None:
+    """Script form of gemm_options() (tools/): update the calling thread's GEMM options in place until changed again;
+    set_gemm_options() with no arguments clears them.  Keys: tile, raster=(gm, gn), persist."""
+    if not kw:
+        _TLS.gemm_opts = None
+        return
+    o = _TLS.gemm_opts or GemmOpts(ctypes.sizeof(GemmOpts), 0, 0, 0, -1)
+    if 'tile' in kw: o.tile = int(kw['tile'])
+    if 'raster' in kw: o.raster_gm, o.raster_gn = int(kw['raster'][0]), int(kw['raster'][1])
+    if 'persist' in kw: o.persist = int(kw['persist'])
+    _TLS.gemm_opts = o
+
+
+def set_attn_options(**kw) -> None:
+    """Script form of attn_options(): keys variant, q_blocks, thr, spec; no arguments clears."""
+    if not kw:
+        _TLS.attn_opts = None
+        return
+    o = _TLS.attn_opts or AttnOpts(ctypes.sizeof(AttnOpts), 0, 0, 8.0, 1)
+    if 'variant' in kw: o.variant = int(kw['variant'])
+    if 'q_blocks' in kw: o.q_blocks = int(kw['q_blocks'])
+    if 'thr' in kw: o.defer_max_thr = float(kw['thr'])
+    if 'spec' in kw: o.speculative = int(kw['spec'])
+    _TLS.attn_opts = o
+
+
+class attn_options:
+    """`with _hip.attn_options(variant=1, q_blocks=2):` -- per-call options of esme_hip_attn_varlen_fwd_opts for the
+    attention launches of THIS thread inside the block (kernel variant, q-blocks per wave, defer-max threshold,
+    speculative softmax)."""
+
+    def __init__(self, variant: int = 0, q_blocks: int = 0, thr: float = 8.0, spec: int = 1):
+        self.opts = AttnOpts(ctypes.sizeof(AttnOpts), int(variant), int(q_blocks), float(thr), int(spec))
+
+    def __enter__(self):
+        self.prev, _TLS.attn_opts = _TLS.attn_opts, self.opts
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.attn_opts = self.prev
+        return False
+
 
 
 def _dev(t: torch.Tensor, what: str, dtype=None) -> int:
@@ -169,7 +250,7 @@ def _dev(t: torch.Tensor, what: str, dtype=None) -> int:
     # kernels launch on the CURRENT device's stream: a tensor of another device would be dereferenced by the wrong
     # GPU (the reference's torch ops follow the tensor instead).  Model-level entry points switch the device
     # (stream_scope(device)); a raw wrapper call with a foreign tensor fails loudly here.
-    cur = _PINNED_DEVICE if _PINNED_DEVICE is not None else torch.cuda.current_device()
+    cur = _TLS.device if _TLS.device is not None else torch.cuda.current_device()
     if t.device.index != cur:
         raise RuntimeError(f'{what}: tensor lives on {t.device} but kernels would launch on cuda:{cur}; wrap the call in '
                            f'`with esme._hip.stream_scope({str(t.device)!r}):` or torch.cuda.device(...)')
@@ -177,14 +258,14 @@ def _dev(t: torch.Tensor, what: str, dtype=None) -> int:
 
 
 def _stream() -> int:
-    if _PINNED_STREAM is not None:
-        return _PINNED_STREAM
+    if _TLS.stream is not None:
+        return _TLS.stream
     return torch.cuda.current_stream().cuda_stream
 
 
 class stream_scope:
     """`with _hip.stream_scope(device):` makes `device` current (when given) and pins its current HIP stream
-    handle for every launch inside the block (the torch lookup costs ~9 us, i.e. more than the launch itself
+    handle for every launch of THIS host thread inside the block (the torch lookup costs ~9 us, i.e. more than the launch itself
     for small models).  Re-entrant; the stream that is current when the outermost scope is entered is used,
     which is also the capture stream inside `torch.cuda.graph(...)`.  A nested scope for ANOTHER device
     switches device and stream for its extent."""
@@ -195,23 +276,21 @@ class stream_scope:
         self.guard = None
 
     def __enter__(self):
-        global _PINNED_STREAM, _PINNED_DEVICE
-        self.prev = (_PINNED_STREAM, _PINNED_DEVICE)
+        self.prev = (_TLS.stream, _TLS.device)
         if not torch.cuda.is_available():                  # no device: the first launch raises 'no CPU fallback'
             return self
         want = self.device.index if (self.device is not None and self.device.type == 'cuda') else None
-        if want is not None and want != (_PINNED_DEVICE if _PINNED_DEVICE is not None else torch.cuda.current_device()):
+        if want is not None and want != (_TLS.device if _TLS.device is not None else torch.cuda.current_device()):
             self.guard = torch.cuda.device(want)
             self.guard.__enter__()
-            _PINNED_DEVICE, _PINNED_STREAM = want, torch.cuda.current_stream(want).cuda_stream
-        elif _PINNED_STREAM is None:
-            _PINNED_DEVICE = torch.cuda.current_device()
-            _PINNED_STREAM = torch.cuda.current_stream().cuda_stream
+            _TLS.device, _TLS.stream = want, torch.cuda.current_stream(want).cuda_stream
+        elif _TLS.stream is None:
+            _TLS.device = torch.cuda.current_device()
+            _TLS.stream = torch.cuda.current_stream().cuda_stream
         return self
 
     def __exit__(self, *exc):
-        global _PINNED_STREAM, _PINNED_DEVICE
-        _PINNED_STREAM, _PINNED_DEVICE = self.prev
+        _TLS.stream, _TLS.device = self.prev
         if self.guard is not None:
             self.guard.__exit__(*exc)
             self.guard = None
@@ -328,10 +407,16 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     op, ldo = _rows2d(out, 'attn out')
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
-    fn = load().esme_hip_attn_varlen_fwd_exact if exact else load().esme_hip_attn_varlen_fwd
+    ao = _TLS.attn_opts
     with _Traced('attn', (T, heads, d)):
-        _check(fn(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
-                  cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()), 'esme_hip_attn_varlen_fwd')
+        if ao is not None and not exact:
+            _check(load().esme_hip_attn_varlen_fwd_opts(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32), cu.numel() - 1, T,
+                                                        heads, d, int(max_len), scale, ctypes.byref(ao), _stream()),
+                   'esme_hip_attn_varlen_fwd_opts')
+        else:
+            fn = load().esme_hip_attn_varlen_fwd_exact if exact else load().esme_hip_attn_varlen_fwd
+            _check(fn(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32),
+                      cu.numel() - 1, T, heads, d, int(max_len), scale, _stream()), 'esme_hip_attn_varlen_fwd')
     return out
 
 
@@ -366,6 +451,8 @@ def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
          resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epilogue(a @ w.T + bias); a (M,K), w (N,K) contiguous; see include/esme_hip.h."""
+    if _TLS.gemm_opts is not None:
+        return gemm_fused(a, w, bias, epilogue, resid, alpha, out)
     ap, lda = _rows2d(a, 'gemm a')
     if not w.is_contiguous():
         raise ValueError('gemm: weight must be contiguous (N, K)')
@@ -392,6 +479,8 @@ def gemm_qkv_rotary(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a @ w.T + bias with rotary applied to the heads in columns [0, rot_cols)
     inside the GEMM epilogue (fused QKV projection; head_dim in {16, 32, 64})."""
+    if _TLS.gemm_opts is not None:
+        return gemm_fused(a, w, bias, out=out, rot=(cos, sin, pos, head_dim, rot_cols))
     ap, lda = _rows2d(a, 'gemm_qkv_rotary a')
     if not w.is_contiguous():
         raise ValueError('gemm_qkv_rotary: weight must be contiguous (N, K)')
@@ -409,7 +498,11 @@ def gemm_qkv_rotary(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 
 
 def stats_blocks(M: int, N: int) -> int:
-    """Column-tile blocks a residual-epilogue GEMM of this shape writes to `stats_out`."""
+    """Column-tile blocks a residual-epilogue GEMM of this shape writes to `stats_out` (under the calling thread's
+    gemm_options(), if any)."""
+    go = _TLS.gemm_opts
+    if go is not None:
+        return int(load().esme_hip_gemm_stats_blocks_opts(M, N, ctypes.byref(go)))
     return int(load().esme_hip_gemm_stats_blocks(M, N))
 
 
@@ -451,11 +544,18 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16), _dev(pos, 'pos', torch.int32)
         fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
         tag = 'qkv_rotary'
+    go = _TLS.gemm_opts
     with _Traced('gemm', (M, N, K, tag)):
-        _check(load().esme_hip_gemm_bf16_fused(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
-                                               _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
-                                               rp, ldr, cp, ldc, M, N, K, epilogue, alpha, ctypes.byref(fu), _stream()),
-               'esme_hip_gemm_bf16_fused')
+        if go is not None:
+            _check(load().esme_hip_gemm_bf16_opts(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+                                                  _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
+                                                  rp, ldr, cp, ldc, M, N, K, epilogue, alpha, ctypes.byref(fu), ctypes.byref(go),
+                                                  _stream()), 'esme_hip_gemm_bf16_opts')
+        else:
+            _check(load().esme_hip_gemm_bf16_fused(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+                                                   _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
+                                                   rp, ldr, cp, ldc, M, N, K, epilogue, alpha, ctypes.byref(fu), _stream()),
+                   'esme_hip_gemm_bf16_fused')
     return out
 
 

@@ -276,7 +276,7 @@ class FlashMultiheadAttention(nn.Module):
                 if ctx is not None:
                     _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
                 else:
-                    q, k = self.rot_emb(q, k, cu_lens, max_len)
+                    q, k = self.rot_emb(q, k, cu_lens, max_len, inplace=True)
         a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn))
         wo, bo = self._weights_out()
         if resid is not None:

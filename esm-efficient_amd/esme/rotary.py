@@ -69,13 +69,16 @@ class RotaryEmbedding(nn.Module):
         return self._cos_cached, self._sin_cached
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
-                pos: Optional[torch.Tensor] = None):
-        """q, k: (T, H, d) bf16 (views allowed if rows are contiguous).  Rotates both
-        IN PLACE and returns them (the reference returns new tensors; callers on the
-        path never reuse the unrotated ones)."""
+                pos: Optional[torch.Tensor] = None, inplace: bool = False):
+        """q, k: (T, H, d) bf16.  Returns the rotated (q, k) as NEW tensors and leaves the inputs untouched, like the
+        reference (esme/rotary.py:151-165).  `inplace=True` rotates the given tensors (views allowed if rows are
+        contiguous) and returns them: what the layer stack does (esme/attention.py here), where nothing reuses the
+        unrotated values and the copy would be a wasted HBM pass."""
         T, H, d = q.shape
         cos, sin = self.tables(max_len, q.device, q.dtype)
         if pos is None:
             pos, _ = _hip.seq_positions(cu_lens, T)
+        if not inplace:
+            q, k = q.clone(memory_format=torch.contiguous_format), k.clone(memory_format=torch.contiguous_format)
         _hip.rotary_(q.view(T, H * d), k.view(T, H * d), cos, sin, pos, H)
         return q, k

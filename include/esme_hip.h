@@ -123,6 +123,25 @@ int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_
                              void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
                              int H, int d, int max_len, float softmax_scale, void* stream);
 
+/* Per-call kernel selection for tests and tuning (NULL = exactly esme_hip_attn_varlen_fwd).  There is no process-global
+ * tuning state in the library: two host threads on two streams can use different options concurrently.
+ *   variant:       0 = heuristic; 1 = the first-generation kernel (all head dims); 4 / 8 = the head-dim-64 software-pipelined
+ *                  kernel with 4 / 8 waves per workgroup
+ *   q_blocks:      first-generation kernel: 32-row query blocks per wave (0 = heuristic, 1, 2)
+ *   defer_max_thr: online-softmax rescale threshold in log2 units (default 8; 0 = every row maximum exact)
+ *   speculative:   head-dim-64 kernel: 1 = speculative softmax (default), 0 = classic online softmax */
+typedef struct esme_attn_opts {
+    int struct_bytes;            /* sizeof(esme_attn_opts_t) */
+    int variant;
+    int q_blocks;
+    float defer_max_thr;
+    int speculative;
+} esme_attn_opts_t;
+int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv,
+                                  void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
+                                  int H, int d, int max_len, float softmax_scale,
+                                  const esme_attn_opts_t* opts, void* stream);
+
 /* The same contraction with the classic online softmax: every row maximum exact (no defer-max threshold, no
  * speculative tiles).  Used by the high-precision mode; ~15 % slower at head dim 64. */
 int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, int64_t ld_qkv,
@@ -193,6 +212,25 @@ int esme_hip_gemm_bf16_fused(const void* A, int64_t lda, const void* W, const vo
                              const void* resid, int64_t ldr, void* C, int64_t ldc, int64_t M, int N,
                              int K, int epilogue, float alpha, const esme_gemm_fusion_t* fusion,
                              void* stream);
+
+/* Per-call kernel selection for tests and tuning (NULL = exactly esme_hip_gemm_bf16_fused); no process-global state.
+ *   tile:      0 = heuristic; 1 = 128 x 128 x 64 tiles, 4 waves; 2 = 256 x 256 x 64 tiles, 8 waves
+ *   raster_gm, raster_gn: tile-walk groups (0 = heuristic)
+ *   persist:   -1 = default (persistent workgroups for launches of >= 2 rounds; env ESME_GEMM_PERSIST=0 disables);
+ *              0 = one workgroup per tile; 1 = persistent where the kernel supports it
+ * Every configuration produces the same bits.  With a forced tile, size stats_out with esme_hip_gemm_stats_blocks_opts. */
+typedef struct esme_gemm_opts {
+    int struct_bytes;            /* sizeof(esme_gemm_opts_t) */
+    int tile;
+    int raster_gm;
+    int raster_gn;
+    int persist;
+} esme_gemm_opts_t;
+int esme_hip_gemm_stats_blocks_opts(int64_t M, int N, const esme_gemm_opts_t* opts);
+int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W, const void* bias,
+                            const void* resid, int64_t ldr, void* C, int64_t ldc, int64_t M, int N,
+                            int K, int epilogue, float alpha, const esme_gemm_fusion_t* fusion,
+                            const esme_gemm_opts_t* opts, void* stream);
 
 /* sums[t] = {sum_e x[t,e], sum_e x[t,e]^2} (fp32) of a (T, E) bf16 tensor: the one-block form of
  * the partial sums the LN-folding GEMMs consume (ln_nblk = 1), used for the first layer's input.

@@ -42,13 +42,9 @@ def test_fuzz_gemm(seed):
         ref = (F.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
     else:
         ref = acc
-    lib = _hip.load()
-    lib.esme_hip_debug_set_gemm_tile(tile)
-    try:
+    with _hip.gemm_options(tile=tile):
         got = _hip.gemm(a.to(dev()), w.to(dev()), bias.to(dev()) if use_bias else None, epi,
                         resid.to(dev()) if resid is not None else None, alpha)
-    finally:
-        lib.esme_hip_debug_set_gemm_tile(0)
     check(got, ref, rtol=2.0 ** -6 if epi == _hip.EPI_SWIGLU else BF16_RTOL,
           what=f'gemm M={M} N={N} K={K} epi={epi} tile={tile} bias={use_bias}')
 
@@ -65,13 +61,9 @@ def test_fuzz_attention(seed):
     qkv = rnd((T, 3 * E), seed)
     cu = torch.tensor(np.r_[0, np.cumsum(lengths)], dtype=torch.int32)
     qb = int(rng.choice([0, 1, 2]))
-    lib = _hip.load()
-    lib.esme_hip_debug_set_attn_qb(qb)
-    try:
+    with _hip.attn_options(q_blocks=qb):
         x = qkv.to(dev())
         got = _hip.attn_varlen(x[:, :E], x[:, E:2 * E], x[:, 2 * E:], cu.to(dev()), max(lengths), H)
-    finally:
-        lib.esme_hip_debug_set_attn_qb(0)
     q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
     ref = O.varlen_attention(q, k, v, cu).reshape(T, E)
     check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn lengths={lengths} H={H} d={d} qb={qb}')

@@ -128,16 +128,13 @@ GEMM_SHAPES = [
 @pytest.mark.parametrize('tile', [1, 2])
 def test_gemm_bias(M, N, K, tile):
     from esme import _hip
-    _hip.load().esme_hip_debug_set_gemm_tile(tile)
-    try:
+    with _hip.gemm_options(tile=tile):
         a, w, b = rnd((M, K), 7), rnd((N, K), 8, 1 / math.sqrt(K)), rnd((N,), 9, 0.1)
         ref = a.float() @ w.float().T + b.float()
         got = _hip.gemm(a.to(dev()), w.to(dev()), b.to(dev()))
         check(got, ref, what=f'gemm {M}x{N}x{K} tile{tile}')
         got = _hip.gemm(a.to(dev()), w.to(dev()), None)
         check(got, ref - b.float(), what=f'gemm nobias {M}x{N}x{K} tile{tile}')
-    finally:
-        _hip.load().esme_hip_debug_set_gemm_tile(0)
 
 
 def test_gemm_transpose_detecting():
@@ -153,8 +150,7 @@ def test_gemm_transpose_detecting():
 @pytest.mark.parametrize('tile', [1, 2])
 def test_gemm_epilogues(tile):
     from esme import _hip
-    _hip.load().esme_hip_debug_set_gemm_tile(tile)
-    try:
+    with _hip.gemm_options(tile=tile):
         M, N, K = 333, 1280, 640
         a, w, b = rnd((M, K), 10), rnd((N, K), 11, 1 / math.sqrt(K)), rnd((N,), 12, 0.1)
         r = rnd((M, N), 13)
@@ -174,8 +170,6 @@ def test_gemm_epilogues(tile):
         got = _hip.gemm(a.to(dev()), packed.to(dev()), None, _hip.EPI_SWIGLU)
         ref = torch.nn.functional.silu(a.float() @ wa.float().T) * (a.float() @ wf.float().T)
         check(got, ref, what='gemm+swiglu')
-    finally:
-        _hip.load().esme_hip_debug_set_gemm_tile(0)
 
 
 @pytest.mark.parametrize('lengths,H,d', [([60, 40, 180], 4, 32), ([5, 26, 61], 20, 16), ([37, 70, 193], 20, 64),
@@ -195,12 +189,9 @@ def test_gemm_qkv_rotary_fused(lengths, H, d, tile):
     for blk in range(2):
         x = lin[:, blk * E:(blk + 1) * E].view(T, H, d)
         ref[:, blk * E:(blk + 1) * E] = O.apply_rotary(x, cos.float(), sin.float(), pos).view(T, E)
-    _hip.load().esme_hip_debug_set_gemm_tile(tile)
-    try:
+    with _hip.gemm_options(tile=tile):
         p, _ = _hip.seq_positions(cu.to(dev()), T)
         got = _hip.gemm_qkv_rotary(a.to(dev()), w.to(dev()), b.to(dev()), cos.to(dev()), sin.to(dev()), p, d, 2 * E)
-    finally:
-        _hip.load().esme_hip_debug_set_gemm_tile(0)
     check(got[:, :2 * E], ref[:, :2 * E], what='fused rotary q,k')
     check(got[:, 2 * E:], ref[:, 2 * E:], what='fused rotary v (untouched)')
 
@@ -233,8 +224,7 @@ def test_gemm_layernorm_fold_and_row_sums(M, N, K, epi, tile):
         wf, c1, c2 = _fold_layernorm(w.to(dev()), b.to(dev()), gamma.to(dev()), beta.to(dev()))
         code = _hip.EPI_GELU if epi == 'gelu' else _hip.EPI_NONE
     xg = x.to(dev())
-    _hip.load().esme_hip_debug_set_gemm_tile(tile)
-    try:
+    with _hip.gemm_options(tile=tile):
         sums = _hip.row_sums(xg)
         ref_s = torch.stack((x.float().sum(1), (x.float() ** 2).sum(1)), 1)
         assert torch.allclose(sums[0].cpu(), ref_s, rtol=1e-5, atol=1e-3)
@@ -253,8 +243,6 @@ def test_gemm_layernorm_fold_and_row_sums(M, N, K, epi, tile):
             assert torch.allclose(part.sum(0).cpu(), ref_s, rtol=1e-5, atol=1e-3)
             got2 = _hip.gemm_fused(xg, wf, None, code, ln=(part, K, 1e-5, c1, c2))
             check(got2, got.float(), rtol=2.0 ** -8, atol_scale=2.0 ** -8, what='LN-fold via emitted partial sums')
-    finally:
-        _hip.load().esme_hip_debug_set_gemm_tile(0)
 
 
 def _attn_case(lengths, H, d, seed, qscale=1.0, spike=False):
@@ -285,15 +273,9 @@ def _attn_case(lengths, H, d, seed, qscale=1.0, spike=False):
 @pytest.mark.parametrize('qb', [1, 2])
 def test_attention(lengths, H, d, qb):
     from esme import _hip
-    lib = _hip.load()
-    lib.esme_hip_debug_set_attn_qb.restype = None
-    lib.esme_hip_debug_set_attn_qb(qb)          # q-blocks per wave of the first-generation kernel (2 = long sequences)
-    _attn_hooks().esme_hip_debug_set_attn_variant(1 if d == 64 else 0)
-    try:
+    # q-blocks per wave of the first-generation kernel (2 = long sequences); head dim 64 would pick the pipelined kernel
+    with _hip.attn_options(variant=1 if d == 64 else 0, q_blocks=qb):
         got, ref = _attn_case(lengths, H, d, seed=20)
-    finally:
-        lib.esme_hip_debug_set_attn_qb(0)
-        lib.esme_hip_debug_set_attn_variant(0)
     # P is rounded to bf16 before PV (FA-2 convention): allow 2^-6 relative + 2^-6 of the rms
     check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention {lengths} H{H} d{d}')
 
@@ -425,8 +407,7 @@ def test_layernorm_fold_stress(kind, tile):
     w, b = rnd((N, K), 73, 1 / math.sqrt(K)), rnd((N,), 74, 0.1)
     ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5) @ w.float().T + b.float()
     xg, wg, bg, gg, btg = (t.to(dev()) for t in (x, w, b, gamma, beta))
-    _hip.load().esme_hip_debug_set_gemm_tile(tile)
-    try:
+    with _hip.gemm_options(tile=tile):
         unfused = _hip.gemm(_hip.layernorm(xg, gg, btg, 1e-5), wg, bg).float().cpu()
         wf, c1, c2 = _fold_layernorm(wg, bg, gg, btg)
         # statistics as the model produces them: partial sums emitted by a residual GEMM over 64-column blocks
@@ -436,8 +417,6 @@ def test_layernorm_fold_stress(kind, tile):
         assert torch.equal(y, xg)
         fold = _hip.gemm_fused(xg, wf, None, _hip.EPI_NONE, ln=(part, K, 1e-5, c1, c2)).float().cpu()
         fold1 = _hip.gemm_fused(xg, wf, None, _hip.EPI_NONE, ln=(_hip.row_sums(xg), K, 1e-5, c1, c2)).float().cpu()
-    finally:
-        _hip.load().esme_hip_debug_set_gemm_tile(0)
     assert torch.isfinite(fold).all() and torch.isfinite(fold1).all()
     rms = float(ref.pow(2).mean().sqrt())
     e_unf = float((unfused - ref).abs().max()) / rms
@@ -454,19 +433,6 @@ def test_layernorm_fold_stress(kind, tile):
 
 
 # ------------------------------------------------------------------ head dim 64: the software-pipelined kernel
-def _attn_hooks():
-    import ctypes
-    from esme import _hip
-    lib = _hip.load()
-    lib.esme_hip_debug_set_attn_variant.restype = None
-    lib.esme_hip_debug_set_attn_variant.argtypes = [ctypes.c_int]
-    lib.esme_hip_debug_set_attn_thr.restype = None
-    lib.esme_hip_debug_set_attn_thr.argtypes = [ctypes.c_float]
-    lib.esme_hip_debug_set_attn_spec.restype = None
-    lib.esme_hip_debug_set_attn_spec.argtypes = [ctypes.c_int]
-    return lib
-
-
 @pytest.mark.parametrize('lengths,H', [([37, 70, 193], 20), ([500, 500], 20), ([1, 300, 63, 64, 65], 5), ([1253], 4),
                                        ([256, 257, 255], 3), ([513, 2], 2), ([2049], 1)])
 @pytest.mark.parametrize('variant,spec', [(4, 1), (4, 0), (8, 1), (8, 0), (1, 0)])
@@ -474,14 +440,9 @@ def test_attention_d64_variants(lengths, H, variant, spec):
     """Every schedule of the head-dim-64 kernel (first generation; ping-pong with 4 / 8 waves; speculative or classic
     online softmax) against the fp32 oracle, on ragged tiles, 1-row sequences and lengths around the 256 / 512-row
     workgroup tiles."""
-    lib = _attn_hooks()
-    lib.esme_hip_debug_set_attn_variant(variant)
-    lib.esme_hip_debug_set_attn_spec(spec)
-    try:
+    from esme import _hip
+    with _hip.attn_options(variant=variant, spec=spec):
         got, ref = _attn_case(lengths, H, 64, seed=40)
-    finally:
-        lib.esme_hip_debug_set_attn_variant(0)
-        lib.esme_hip_debug_set_attn_spec(1)
     check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention d64 variant {variant} spec {spec} {lengths}')
 
 
@@ -491,7 +452,6 @@ def test_attention_speculative_overflow_is_redone_exactly():
     online softmax.  Rows: q = k-spike direction, score jump ~ +3000 log2 units at key 700 of 900; plus a sequence
     whose scores hold +inf products."""
     from esme import _hip
-    lib = _attn_hooks()
     H, d = 2, 64
     E = H * d
     lengths = [900, 130]
@@ -505,38 +465,31 @@ def test_attention_speculative_overflow_is_redone_exactly():
     g = qkv.to(dev())
     outs = {}
     for variant, spec in ((4, 1), (8, 1), (4, 0), (1, 0)):
-        lib.esme_hip_debug_set_attn_variant(variant)
-        lib.esme_hip_debug_set_attn_spec(spec)
-        try:
+        with _hip.attn_options(variant=variant, spec=spec):
             outs[(variant, spec)] = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H)
-        finally:
-            lib.esme_hip_debug_set_attn_variant(0)
-            lib.esme_hip_debug_set_attn_spec(1)
     for key, got in outs.items():
         check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'overflow redo {key}')
     # row 5 attends to key 700 alone
     assert torch.allclose(outs[(4, 1)][5].float().cpu(), qkv[700, 2 * E:].float(), atol=2.0 ** -6)
     # the redo IS the classic path: bit-identical to spec = 0 for the workgroups that overflowed (rows 0..255 of seq 0)
     assert torch.equal(outs[(4, 1)][:256], outs[(4, 0)][:256])
+    # ... and the redo is reachable WITHOUT any option: the plain entry point (what the model calls) takes it too
+    plain = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H)
+    assert torch.equal(plain, outs[(4, 1)])
+    exact = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H, exact=True)
+    check(exact, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='overflow case, exact entry point')
+    assert torch.equal(plain[:256], exact[:256])
 
 
 def test_attention_defer_max_threshold_error_report():
     """quantify the defer-max threshold.  Max / Frobenius error vs the fp32 oracle for thr = 0 (row maxima
     always exact) and thr = 8 (the fast default) and the speculative softmax, on sharp (3x scaled) and plain scores."""
     from esme import _hip
-    lib = _attn_hooks()
     rows = []
     for qscale in (1.0, 3.0):
         for variant, spec, thr in ((1, 0, 0.0), (1, 0, 8.0), (4, 0, 0.0), (4, 0, 8.0), (4, 1, 8.0)):
-            lib.esme_hip_debug_set_attn_variant(variant)
-            lib.esme_hip_debug_set_attn_spec(spec)
-            lib.esme_hip_debug_set_attn_thr(thr)
-            try:
+            with _hip.attn_options(variant=variant, spec=spec, thr=thr):
                 got, ref = _attn_case([900, 500, 333], 8, 64, seed=42, qscale=qscale)
-            finally:
-                lib.esme_hip_debug_set_attn_variant(0)
-                lib.esme_hip_debug_set_attn_spec(1)
-                lib.esme_hip_debug_set_attn_thr(8.0)
             err = (got.float().cpu() - ref).abs()
             rows.append((qscale, variant, spec, thr, float(err.max()), rel_fro(got.float().cpu(), ref)))
             check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'thr sweep {rows[-1][:4]}')
@@ -553,15 +506,13 @@ def test_gemm_persistent_workgroups_equal_per_tile(K, epi):
     tile, on a ragged M, for every epilogue that takes the path."""
     from esme import _hip
     from esme.attention import _fold_layernorm
-    lib = _hip.load()
     M, N = 27001, 1280                      # 106 x 5 tiles = 530 >= 2 x 256 CUs
     x = rnd((M, K), 1).to(dev())
     w = rnd((N, K), 2, 1 / math.sqrt(K)).to(dev())
     b = rnd((N,), 3, 0.1).to(dev())
     outs = {}
     for persist in (0, 1):
-        lib.esme_hip_debug_set_gemm_persist(persist)
-        try:
+        with _hip.gemm_options(persist=persist):
             if epi == 'none':
                 outs[persist] = (_hip.gemm(x, w, b),)
             elif epi == 'gelu+lnf':
@@ -576,11 +527,57 @@ def test_gemm_persistent_workgroups_equal_per_tile(K, epi):
                 outs[persist] = (y, part)
             else:
                 outs[persist] = (_hip.gemm_fused(x, w, None, _hip.EPI_SWIGLU),)
-        finally:
-            lib.esme_hip_debug_set_gemm_persist(1)
     for a, c in zip(outs[0], outs[1]):
         assert torch.isfinite(a.float()).all()
         assert torch.equal(a, c), f'{epi} K={K}: max |diff| {float((a.float() - c.float()).abs().max()):.3e}'
     if epi == 'none':                       # and the per-tile result is the oracle's
         ref = x[-300:].cpu().float() @ w.cpu().float().T + b.cpu().float()          # the last (ragged) row tile
         check(outs[1][0][-300:], ref, what='persistent gemm')
+
+
+def test_two_host_threads_two_streams_different_options():
+    """SURVEY 8b 'Threading / streams': the library holds no mutable global state and per-call options are per call.  Two host
+    threads drive GEMMs and attention on two streams at the same time, each with ITS OWN kernel options (128- vs 256-tiles,
+    persistent vs per-tile workgroups, two attention kernels): every result equals the single-threaded one bit for bit."""
+    import threading
+    from esme import _hip
+    M, N, K, H = 6000, 1280, 640, 20
+    x = rnd((M, K), 61).to(dev()); w = rnd((N, K), 62, 1 / math.sqrt(K)).to(dev()); b = rnd((N,), 63, 0.1).to(dev())
+    res = rnd((M, N), 64).to(dev())
+    lengths = [500] * 12
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32).to(dev())
+    qkv = rnd((sum(lengths), 3 * N), 65).to(dev())
+
+    def work(tile, persist, variant):
+        with _hip.gemm_options(tile=tile, persist=persist), _hip.attn_options(variant=variant):
+            y = _hip.gemm_fused(x, w, b, _hip.EPI_RESIDUAL, res, 0.5)
+            z = _hip.gemm(x, w, b, _hip.EPI_GELU)
+            a = _hip.attn_varlen(qkv[:, :N], qkv[:, N:2 * N], qkv[:, 2 * N:], cu, 500, H)
+        return y, z, a
+
+    cfgs = [(1, 0, 1), (2, 1, 4)]
+    want = [work(*c) for c in cfgs]
+    torch.cuda.synchronize()
+    # all tile / persist configurations produce the same bits; the two attention kernels agree within rounding only
+    assert torch.equal(want[0][0], want[1][0]) and torch.equal(want[0][1], want[1][1])
+    errors, got = [], [None, None]
+
+    def runner(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    out = work(*cfgs[i])
+                st.synchronize()
+            got[i] = out
+            assert _hip._TLS.gemm_opts is None and _hip._TLS.attn_opts is None
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=runner, args=(i,)) for i in range(2)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errors, errors
+    for i in range(2):
+        for g_, w_ in zip(got[i], want[i]):
+            assert torch.equal(g_, w_)

@@ -222,3 +222,61 @@ def test_bench_self_launches_n_ranks_without_a_launcher():
     out = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], timeout=600)
     assert out.returncode != 0 and '{' not in out.stdout
     assert out.stderr.count('--gpus 2 but only 0 HIP devices are visible') == 2, out.stderr[-3000:]
+
+
+def test_gelu_polynomial_all_bf16_inputs():
+    """The GEMM epilogue's GELU (csrc/common.h: gelu(x) = max(x, 0) - |x| 2^p(|x|), p a minimax polynomial of log2 Phi(-z))
+    restated in numpy with the kernel's fp32 arithmetic (coefficients parsed from the header, fused multiply-adds) and
+    checked against float64 x Phi(x) over ALL finite bf16 inputs: error <= 1/2 bf16 ulp of the result, with an absolute floor
+    of 1.5e-7 |x| (what torch's own fp32 0.5 x (1 + erf(x / sqrt 2)) resolves: it cancels catastrophically below x = -4).
+    Replaces the reference's nn.GELU() (esme/attention.py:233, esme/head.py:26)."""
+    from scipy.special import ndtr
+    src = open(os.path.join(os.path.dirname(__file__), '..', 'esm-efficient_amd', 'csrc', 'common.h')).read()
+    body = src[src.index('float gelu_erf(float x)'):]
+    body = body[:body.index('return fmaf(-z')]
+    deg7, deg5 = body.split('#else')
+    default = int(re.search(r'#define ESME_GELU_DEG (\d)', src).group(1))
+    assert default in (5, 7)
+    bits = (np.arange(65536, dtype=np.uint32) << 16)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    xd = x.astype(np.float64)
+    ref = xd * ndtr(xd)
+    half_ulp = 0.5 * 2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 1e-300))) - 7)
+    tol = np.maximum(half_ulp, 1.5e-7 * np.abs(xd))
+    worst = {}
+    for name, text, deg in (('7', deg7, 7), ('5', deg5, 5)):
+        co = [float(v) for v in re.findall(r'(-?\d\.\d+(?:e-?\d+)?)f', text)]
+        assert len(co) == deg + 1, (name, co)
+        z = np.abs(x)
+        f32 = lambda v: v.astype(np.float32)
+        with np.errstate(over='ignore', invalid='ignore'):
+            p = f32(z.astype(np.float64) * np.float64(np.float32(co[0])) + np.float64(np.float32(co[1])))   # fmaf: exact product, one rounding
+            for c in co[2:]:
+                p = f32(z.astype(np.float64) * p.astype(np.float64) + np.float64(np.float32(c)))
+            e = f32(np.exp2(p.astype(np.float64)))
+            y = f32(-(z.astype(np.float64)) * e.astype(np.float64) + np.maximum(x, 0).astype(np.float64))
+        err = np.abs(y.astype(np.float64) - ref) / tol
+        worst[name] = float(err.max())
+        assert np.isfinite(y).all()
+    assert worst['7'] <= 0.01 and worst['5'] <= 0.25, worst          # fractions of (1/2 ulp | floor); the shipped degree is
+    assert worst[str(default)] <= 0.25                                # far inside the 1/2-ulp bar
+
+
+@pytest.mark.parametrize('d', [16, 32, 64])
+def test_rotary_tables_bit_equal_reference(d):
+    """RotaryEmbedding.tables() (the PRODUCT's host-side table builder) against the reference's cached tables
+    (esme/rotary.py:116-149; golden g5_rotary.npz made by tests/golden/make_golden.py from RotaryEmbedding._cos_cached /
+    _sin_cached): fp32 tables equal, bf16 tables bit for bit."""
+    from golden_util import load_golden
+    from esme.rotary import RotaryEmbedding
+    g = load_golden('g5_rotary.npz')
+    for dtype, tag in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+        cos, sin = RotaryEmbedding(d).tables(180, 'cpu', dtype)
+        assert cos.shape == (180, d) and cos.dtype == dtype
+        assert torch.equal(cos.float(), g[f'cos_d{d}_{tag}'].float()) and torch.equal(sin.float(), g[f'sin_d{d}_{tag}'].float())
+    # a longer request regrows the cache and keeps the prefix
+    rot = RotaryEmbedding(d)
+    c1, _ = rot.tables(60, 'cpu', torch.bfloat16)
+    c2, _ = rot.tables(180, 'cpu', torch.bfloat16)
+    assert torch.equal(c2[:60], c1) and torch.equal(c2.float(), g[f'cos_d{d}_bf16'].float())

@@ -476,13 +476,13 @@ def test_model_on_non_current_device_is_guarded():
     guard is exercised through the pinned-device bookkeeping.)"""
     from esme import _hip
     x = torch.zeros(4, 64, dtype=torch.bfloat16, device=DEV)
-    _hip._PINNED_DEVICE, _hip._PINNED_STREAM = 1, 0         # pretend a scope for cuda:1 is active
+    _hip._TLS.device, _hip._TLS.stream = 1, 0               # pretend a scope for cuda:1 is active (in THIS thread)
     try:
         with pytest.raises(RuntimeError, match='tensor lives on cuda:0'):
             _hip.row_sums(x)
     finally:
-        _hip._PINNED_DEVICE = _hip._PINNED_STREAM = None
+        _hip._TLS.device = _hip._TLS.stream = None
     with _hip.stream_scope(DEV):
-        assert _hip._PINNED_DEVICE == 0
+        assert _hip._TLS.device == 0
         _hip.row_sums(x)
-    assert _hip._PINNED_DEVICE is None
+    assert _hip._TLS.device is None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Attention kernel lab: correctness vs an fp32 torch reference and interleaved timing of the kernel
-variants behind esme_hip_attn_varlen_fwd (debug hook esme_hip_debug_set_attn_variant: 1 = first-generation
+variants behind esme_hip_attn_varlen_fwd (per-call option esme_attn_opts_t.variant: 1 = first-generation
 kernel, 4 / 8 = ping-pong with 4 / 8 waves, 0 = heuristic).
 
     python tools/attn_lab.py [--batch uniform|proteome] [--rounds 5] [--heads 20] [--d 64]
@@ -44,10 +44,6 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0, help='std of q and k (scores ~ scale^2 * sqrt(d) * N(0,1) / sqrt(d))')
     args = ap.parse_args()
     lib = _hip.load()
-    lib.esme_hip_debug_set_attn_variant.restype = None
-    lib.esme_hip_debug_set_attn_variant.argtypes = [ctypes.c_int]
-    lib.esme_hip_debug_set_attn_thr.restype = None
-    lib.esme_hip_debug_set_attn_thr.argtypes = [ctypes.c_float]
     dev = torch.device('cuda', 0)
     if args.batch == 'uniform':
         _, cu, max_len, lengths = syn.uniform_batch(args.tokens, args.seq_len, seed=0)
@@ -69,8 +65,8 @@ def main():
     outs = {}
     for var in variants:
         for thr in thrs:
-            lib.esme_hip_debug_set_attn_variant(var)
-            lib.esme_hip_debug_set_attn_thr(thr)
+            _hip.set_attn_options(variant=var)
+            _hip.set_attn_options(thr=thr)
             o = _hip.attn_varlen(q, k, v, cu, max_len, H)
             torch.cuda.synchronize()
             err = (o.float() - ref).abs()
@@ -78,12 +74,12 @@ def main():
             outs[(var, thr)] = o
             print(f'variant {var} thr {thr}: max|err| {float(err.max()):.4e}  rel_fro {rel:.3e}  finite {bool(torch.isfinite(o.float()).all())}'
                   + (f'  bit-equal to variant {variants[0]}: {bool(torch.equal(o, outs[(variants[0], thr)]))}' if var != variants[0] else ''))
-    lib.esme_hip_debug_set_attn_thr(thrs[0])
+    _hip.set_attn_options(thr=thrs[0])
     times = {v: [] for v in variants}
     out = torch.empty(T, E, dtype=torch.bfloat16, device=dev)
     for r in range(args.rounds):
         for var in variants:
-            lib.esme_hip_debug_set_attn_variant(var)
+            _hip.set_attn_options(variant=var)
             _hip.attn_varlen(q, k, v, cu, max_len, H, out=out)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -96,7 +92,7 @@ def main():
         t = sorted(times[var])
         med = t[len(t) // 2]
         print(f'variant {var}: median {med:.1f} us  min {t[0]:.1f} us  -> {flops / med / 1e6:.0f} TFLOP/s ({flops / med / 1e6 / 2500 * 100:.1f} % of bf16 peak)')
-    lib.esme_hip_debug_set_attn_variant(0)
+    _hip.set_attn_options(variant=0)
 
 
 if __name__ == '__main__':

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Persistent 256 x 256 workgroups (esme_hip_debug_set_gemm_persist) vs one workgroup per tile: bit equality of the four
+"""Persistent 256 x 256 workgroups (esme_gemm_opts_t.persist) vs one workgroup per tile: bit equality of the four
 production GEMMs of an ESM2-650M layer with their fused epilogues (ragged M), and interleaved timing."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +43,7 @@ def run_all():
     return out
 res = {}
 for p in (0, 1):
-    lib.esme_hip_debug_set_gemm_persist(p)
+    _hip.set_gemm_options(persist=p)
     res[p] = run_all()
     torch.cuda.synchronize()
 ok = True
@@ -62,7 +62,7 @@ if os.environ.get('TIME', '1') == '1':
     for r in range(4):
         for k, fn in fns.items():
             for p in (0, 1):
-                lib.esme_hip_debug_set_gemm_persist(p)
+                _hip.set_gemm_options(persist=p)
                 fn(); fn()
                 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 st.record()
@@ -70,7 +70,7 @@ if os.environ.get('TIME', '1') == '1':
                     fn()
                 en.record(); torch.cuda.synchronize()
                 times[(k, p)].append(st.elapsed_time(en) / 20 * 1e3)
-    lib.esme_hip_debug_set_gemm_persist(1)
+    _hip.set_gemm_options(persist=1)
     for k in fns:
         a, b = statistics.median(times[(k, 0)]), statistics.median(times[(k, 1)])
         print(f'{k:20s} per-tile {a:7.1f} us   persistent {b:7.1f} us   ({100 * (b / a - 1):+.1f} %)')

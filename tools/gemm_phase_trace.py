@@ -40,7 +40,7 @@ fns = {'qkv +rot+lnf': lambda: _hip.gemm_fused(x, wqkv, None, out=qkv, rot=(cos,
 lib = _hip.load()
 lib.esme_hip_debug_set_gemm_trace.argtypes = [ctypes.c_void_p]
 if os.environ.get('PERSIST') is not None:      # persistent workgroups: the marks of a workgroup's LAST tile survive; 'prologue' is meaningless
-    lib.esme_hip_debug_set_gemm_persist(int(os.environ['PERSIST']))
+    _hip.set_gemm_options(persist=int(os.environ['PERSIST']))
 names = ['prologue (K-tile 0 + LN strip)', 'main loop', 'LN fold / rotary math', 'epilogue loads (bias, residual DMA)',
          'epilogue math -> slab', 'slab -> C stores (+row sums)', 'stats reduce / tail']
 for name, fn in fns.items():

@@ -28,7 +28,7 @@ for name, N, K in shapes:
     res = {}
     for rnd in range(5):
         for tile in TILES:
-            lib.esme_hip_debug_set_gemm_tile(tile)
+            _hip.set_gemm_options(tile=tile)
             _hip.gemm(a, w, b, out=out)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -37,7 +37,7 @@ for name, N, K in shapes:
             e.record()
             torch.cuda.synchronize()
             res.setdefault(tile, []).append(s.elapsed_time(e) / 50 * 1e3)
-    lib.esme_hip_debug_set_gemm_tile(0)
+    _hip.set_gemm_options(tile=0)
     fl = 2.0 * M * N * K
     line = f'{name:9s} M={M} N={N} K={K}: '
     for tile in TILES:

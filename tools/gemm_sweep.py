@@ -15,7 +15,6 @@ cases = [('qkv  none', T, 3 * E, E, _hip.EPI_NONE), ('out  resid', T, E, E, _hip
 tiles = [int(t) for t in os.environ.get('TILES', '0').split(',')]
 rasters = [tuple(int(v) for v in r.split('x')) for r in os.environ.get('RASTERS', '0x0').split(',')]
 ITERS = int(os.environ.get('ITERS', 30))
-_hip.load().esme_hip_debug_set_gemm_raster.restype = None
 NT = [int(v) for v in os.environ.get('NT', '0').split(',')]
 STAG = [int(v) for v in os.environ.get('STAG', '0').split(',')]
 torch.manual_seed(0)
@@ -27,10 +26,10 @@ for name, M, N, K, epi in cases:
     r = torch.randn(M, n_out, device='cuda').to(torch.bfloat16) if epi == _hip.EPI_RESIDUAL else None
     out = torch.empty(M, n_out, device='cuda', dtype=torch.bfloat16)
     for tile, (gm, gn), nt, stg in [(t, r, n, sg) for t in tiles for r in rasters for n in NT for sg in STAG]:
-        _hip.load().esme_hip_debug_set_gemm_nt(nt)
-        _hip.load().esme_hip_debug_set_gemm_stagger(stg)
-        _hip.load().esme_hip_debug_set_gemm_tile(tile)
-        _hip.load().esme_hip_debug_set_gemm_raster(gm, gn)
+        if nt or stg:                      # instrumented build only (ESME_HIP_LIB=.../libesme_hip_trace.so)
+            _hip.load().esme_hip_debug_set_gemm_nt(nt); _hip.load().esme_hip_debug_set_gemm_stagger(stg)
+        _hip.set_gemm_options(tile=tile)
+        _hip.set_gemm_options(raster=(gm, gn))
         for _ in range(5):
             _hip.gemm(a, w, b, epi, r, 1.0, out)
         torch.cuda.synchronize()
@@ -41,5 +40,5 @@ for name, M, N, K, epi in cases:
         en.record(); torch.cuda.synchronize()
         ms = st.elapsed_time(en) / ITERS
         print(f'{name:11s} M={M} N={N} K={K} tile={tile} raster={gm}x{gn} nt={nt} stag={stg} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TF', flush=True)
-    _hip.load().esme_hip_debug_set_gemm_tile(0)
-    _hip.load().esme_hip_debug_set_gemm_raster(0, 0)
+    _hip.set_gemm_options(tile=0)
+    _hip.set_gemm_options(raster=(0, 0))

@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo/esm-efficient_amd')
 import torch
 from esme import _hip
 torch.manual_seed(0)
-if os.environ.get('TILE'): _hip.load().esme_hip_debug_set_gemm_tile(int(os.environ['TILE']))
+if os.environ.get('TILE'): _hip.set_gemm_options(tile=int(os.environ['TILE']))
 for n in (4096, 8192):
     for fill in ('uniform', 'zeros'):
         if fill == 'uniform':
