@@ -237,8 +237,13 @@ class FlashMultiheadAttention(nn.Module):
         return tuple(qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
 
     def _attn(self, q, k, v, cu_lens, max_len, exact=False):
+        """(T, H, d) x 3 -> (T, E), the reference's `_attn` (esme/attention.py:112-124).  The kernel reads q, k, v with ONE
+        row stride (the layer hands it column blocks of the fused (T, 3E) projection); a caller that passes separately
+        allocated tensors, as the reference's call sites may, gets them repacked."""
         T = q.shape[0]
         E = self.attn_dim
+        if not (q.stride(0) == k.stride(0) == v.stride(0)) or q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
+            q, k, v = (t.reshape(T, E).contiguous() for t in (q, k, v))
         return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads,
                                 softmax_scale=self.head_dim ** -0.5, exact=exact)
 

@@ -478,7 +478,6 @@ def test_attention_speculative_overflow_is_redone_exactly():
     assert torch.equal(plain, outs[(4, 1)])
     exact = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H, exact=True)
     check(exact, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='overflow case, exact entry point')
-    assert torch.equal(plain[:256], exact[:256])
 
 
 def test_attention_defer_max_threshold_error_report():
