@@ -13,8 +13,9 @@ final LN -> LM head -> (T, V) bf16 logits on device) over one synthetic packed b
 that is already resident in HBM.  Workload at N=1: BASELINE.json configs[2], the config
 the metric is quoted on: ESM2-650M, 50 000 packed residues, uniform-500 (B=100 x S=500;
 closed-form FLOPs).  With N>1 every rank runs its own 50 000-residue batch
-(weak scaling, weights replicated, proteins never span GPUs) and the only collective is
-the all-gather of the (T_r, V) logits over RCCL/xGMI at the end of the step.
+(weak scaling, weights replicated, proteins never span GPUs); the timed step is the forward with the logits
+left on the device, and the only collective of the path -- the all-gather of the (T_r, V) logits over
+RCCL/xGMI -- is timed separately right after (`multi_gpu.gather_ms`).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel = the bf16 MFMA GEMM (94 % of the FLOPs); `achieved` is
@@ -22,6 +23,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                up-projection GEMM (M=T, N=4E, K=E, GELU epilogue), measured with HIP events
                on the launch stream in an instrumented pass; `all_gemms` aggregates every
                GEMM launch of a step the same way.
+  multi_gpu    (launcher runs) RCCL world size actually seen, per-rank ms_per_step min / max, gather_ms.
   cpu_baseline the CPU oracle (torch-CPU restatement of the reference, bf16 like the
                reference's default) timed on this box's host cores on a bounded sample.
 """
@@ -54,7 +56,10 @@ def parse():
     ap.add_argument('--batch', choices=['uniform', 'proteome'], default='uniform')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-tokens', type=int, default=8000)
-    ap.add_argument('--no-gather', action='store_true', help='skip the logits all-gather when N>1')
+    ap.add_argument('--no-gather', action='store_true', help='skip the (separately timed) logits all-gather when N>1')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU rehearsal of the N-rank bookkeeping (gloo, NO kernel runs, logits are zeros): launcher, barriers, '
+                         'max-over-ranks timing, separate gather timing, JSON fields.  The line says "dry_run": true; never a result.')
     ap.add_argument('--auto-graph', action='store_true',
                     help='replay from a hipGraph when the forward is launch-bound (T x L <= 400 000)')
     ap.add_argument('--high-precision', action='store_true',
@@ -70,16 +75,18 @@ def parse():
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).
-    Counters cannot be read from inside the process, so this is the last profiled value, valid
-    for the default workload only; None otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
-    try:
-        with open(path) as f:
-            return int(json.load(f)['traffic_bytes_per_launch'])
-    except Exception:
-        return None
+    """(bytes, source): HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (newest
+    profiles/rNN_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  Counters cannot be read
+    from inside the process, so this is the last PROFILED value -- a static file, not an observation of this run -- valid
+    for the default workload only; (None, None) otherwise."""
+    for name in ('r03_traffic.json', 'r02_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            with open(path) as f:
+                return int(json.load(f)['traffic_bytes_per_launch']), f'profiles/{name} (separate rocprofv3 --pmc passes of this workload; static file, not observed in this run)'
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(weights, heads, kind, L, E, seq_len, sample_tokens, gpu_logits=None):
@@ -94,6 +101,11 @@ def cpu_baseline(weights, heads, kind, L, E, seq_len, sample_tokens, gpu_logits=
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     tokens, cu, max_len, lengths = syn.uniform_batch(sample_tokens, seq_len, seed=0)
+    if gpu_logits is not None:
+        gpu_logits, gpu_tokens = gpu_logits
+        # the sample must be the same residues the GPU rows belong to (whole sequences of the same generator stream)
+        if sample_tokens % seq_len != 0 or not torch.equal(gpu_tokens.cpu(), tokens):
+            gpu_logits = None
     t0 = time.time()
     with torch.no_grad():
         out = O.forward_logits(weights, heads, tokens, cu, max_len, torch.bfloat16)
@@ -137,6 +149,71 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def rank_timing(dist, elapsed, steps, dev):
+    """Every rank's wall time of the K timed steps -> the job's time (MAX over ranks) and the per-rank spread."""
+    mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    every = torch.empty(dist.get_world_size(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(every, mine)
+    every = every.cpu()
+    return {'world_size_seen': dist.get_world_size(), 'elapsed_max': float(every.max()),
+            'rank_ms_per_step': {'min': round(1e3 * float(every.min()) / steps, 3), 'max': round(1e3 * float(every.max()) / steps, 3)}}
+
+
+def time_gather(dist, gathered, logits, steps, sync, dev):
+    """The path's one collective, timed on its own: K all-gathers of the (T, V) logits between two
+    barrier + synchronize fences, max over ranks."""
+    dist.all_gather_into_tensor(gathered, logits)               # warm-up (communicator set-up)
+    dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dist.all_gather_into_tensor(gathered, logits)
+    dist.barrier(); sync()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {'gather_ms': round(1e3 * float(t.item()) / steps, 4)}
+
+
+def dry_run(args, launched, rank, world):
+    """CPU rehearsal of the multi-rank bookkeeping (gloo): no HIP kernel runs and nothing is measured -- the "forward" is a
+    zero tensor of the logits' shape.  It exists so that the first real N > 1 run cannot trip over the launcher, the fences,
+    the max-over-ranks reduction, the separately timed gather or the JSON fields (tests/test_host_cpu.py)."""
+    import torch.distributed as dist
+    from esme import synthetic as syn
+    assert launched, 'dry run goes through the launcher'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo')
+    dev = torch.device('cpu')
+    kind, L, E, H = syn.MODEL_ZOO[args.model]
+    tokens, cu, max_len, lengths = syn.uniform_batch(args.tokens, args.seq_len, seed=rank)
+    T, V = tokens.numel(), 33
+    step = lambda: torch.zeros(T, V, dtype=torch.bfloat16)
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    multi = rank_timing(dist, elapsed, args.steps, dev)
+    elapsed = multi.pop('elapsed_max')
+    multi['backend'] = dist.get_backend()
+    if not args.no_gather:
+        multi.update(time_gather(dist, torch.empty(world * T, V, dtype=torch.bfloat16), out, args.steps, lambda: None, dev))
+        multi['gather_bytes_per_rank'] = T * V * 2
+    ms = 1e3 * elapsed / args.steps
+    if 'gather_ms' in multi:
+        multi['ms_per_step_incl_gather'] = round(ms + multi['gather_ms'], 3)
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'metric': 'DRY RUN (CPU, gloo, no kernel ran): ' + metric_label(args.model, T, args.batch),
+                          'value': None, 'unit': 'residues/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'bf16', 'data': 'synthetic', 'config': {'workload': 'bookkeeping rehearsal', 'residues_per_gpu': T},
+                          'multi_gpu': multi}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def metric_label(model, T, batch):
     if model == 'esm2_650m' and T == 50000:
         return 'residues/sec ESM2-650M fwd, 50k packed tokens; % bf16 MFMA peak; 1/2/4/8 GPU'      # BASELINE.json's metric
@@ -146,7 +223,7 @@ def metric_label(model, T, batch):
 def main():
     args = parse()
     launched = 'RANK' in os.environ                 # under torch.distributed.run (driver's N>1 form, or self_launch)
-    if not launched and (args.gpus > 1 or args.spawn):
+    if not launched and (args.gpus > 1 or args.spawn or args.dry_run):
         self_launch(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -154,6 +231,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled run')
     dist = None
+    if args.dry_run:
+        return dry_run(args, launched, rank, world)
     if launched:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -191,14 +270,10 @@ def main():
     tokens, cu = tokens.to(dev), cu.to(dev)
     T = tokens.numel()
     V = model.vocab_size
-    gathered = torch.empty(world * T, V, dtype=torch.bfloat16, device=dev) if world > 1 else None
     use_graph = args.graph or (args.auto_graph and T * L <= 400_000)
 
-    def step():
-        logits = model.graphed(tokens, (cu, max_len), 'forward', clone=False) if use_graph else model(tokens, (cu, max_len))
-        if world > 1 and not args.no_gather:
-            dist.all_gather_into_tensor(gathered, logits)
-        return logits
+    def step():                                    # the timed step: logits materialised on the device
+        return model.graphed(tokens, (cu, max_len), 'forward', clone=False) if use_graph else model(tokens, (cu, max_len))
 
     def fence():
         if launched:
@@ -223,10 +298,15 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     step_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    multi = None
+    if launched:
+        multi = rank_timing(dist, elapsed, args.steps, dev)
+        elapsed = multi.pop('elapsed_max')
+        multi['backend'] = f'{dist.get_backend()} (RCCL over xGMI)' if dist.get_backend() == 'nccl' else dist.get_backend()
+        if not args.no_gather:
+            gathered = torch.empty(world * T, V, dtype=torch.bfloat16, device=dev)
+            multi.update(time_gather(dist, gathered, out, args.steps, lambda: torch.cuda.synchronize(), dev))
+            multi['gather_bytes_per_rank'] = T * V * 2
     assert torch.isfinite(out.float()).all()
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * T * args.steps / elapsed
@@ -256,6 +336,10 @@ def main():
                 'frac_bf16_mfma_peak': round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
     }
 
+    if multi is not None:
+        result['multi_gpu'] = multi
+        if 'gather_ms' in multi:
+            result['multi_gpu']['ms_per_step_incl_gather'] = round(ms_per_step + multi['gather_ms'], 3)
     if rank == 0:
         # ---- instrumented pass: HIP events around every launch on the launch stream
         with torch.no_grad():
@@ -269,6 +353,8 @@ def main():
             per_op.setdefault((op, meta), []).append(s.elapsed_time(e))
         key = ('gemm', (T, 4 * E if kind != 'esmc' else 2 * syn.swiglu_width(E), E,
                         _hip.EPI_GELU if kind != 'esmc' else _hip.EPI_SWIGLU))
+        traffic, traffic_src = pmc_traffic() if (args.model == 'esm2_650m' and T == 50000 and not args.high_precision
+                                                 and args.quantization == 'none') else (None, None)
         if key in per_op:
             ms = sum(per_op[key]) / len(per_op[key])
             fl = 2.0 * key[1][0] * key[1][1] * key[1][2]
@@ -281,7 +367,7 @@ def main():
                 'bound': 'mfma', 'kernel': f'gemm_bf16_kernel M={key[1][0]} N={key[1][1]} K={key[1][2]} (FFN up, fused epilogue)',
                 'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                'traffic': pmc_traffic() if (args.model == 'esm2_650m' and T == 50000 and not args.high_precision) else None,
+                'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': round(ms, 4), 'launches_timed': len(per_op[key]),
                 'all_gemms': {'achieved': round(g_fl / (g_ms * 1e-3) / 1e12, 1),
                               'frac': round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
@@ -298,6 +384,8 @@ def main():
         for (op, meta), v in per_op.items():
             by_op[op] = by_op.get(op, 0.0) + sum(v) / nsteps
         result['kernel_ms_per_step'] = {k: round(v, 3) for k, v in sorted(by_op.items())}
+        result['kernel_ms_per_step_source'] = ('instrumented module-by-module pass (HIP events around every launch, after the timed '
+                                               'region); the timed steps go through one esme_hip_forward call, so the sum may exceed ms_per_step')
         # HBM-bound kernels: algorithmic bytes / measured time
         hbm = {}
         for (op, meta), v in per_op.items():
@@ -317,8 +405,10 @@ def main():
         result['hbm_bound_GBps'] = hbm
         if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 of the single-GPU run only
             n = min(args.cpu_sample_tokens, T)
-            same = args.batch == 'uniform' and args.quantization == 'none'     # sample == first n residues of the batch
-            result['cpu_baseline'], parity = cpu_baseline(weights, H, kind, L, E, args.seq_len, n, out[:n] if same else None)
+            n = max(args.seq_len, n // args.seq_len * args.seq_len) if n >= args.seq_len else n      # whole sequences only
+            same = args.batch == 'uniform' and args.quantization == 'none' and n <= T      # sample == first n residues of the batch
+            result['cpu_baseline'], parity = cpu_baseline(weights, H, kind, L, E, args.seq_len, n,
+                                                          (out[:n], tokens[:n]) if same else None)
             if parity is not None:
                 result['parity'] = parity
         print(json.dumps(result), flush=True)

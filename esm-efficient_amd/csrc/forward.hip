@@ -26,7 +26,7 @@ int64_t carve(const esme_model_desc_t* m, int64_t T, Ws* w, char* base) {
     char* qkv = take(T * 3 * Ea * 2);
     char* attn = take(T * Ea * 2);
     char* mid = take(T * mid_cols * 2);
-    char* head = take(T * Ep * 2);
+    char* head = take(m->head_dense_w ? T * Ep * 2 : 0);      // LM-head scratch only when the descriptor carries the head (logits != NULL)
     char* sums = take(T * 2 * 4);
     char* pa = take(nblk * T * 2 * 4);
     char* pb = take(nblk * T * 2 * 4);

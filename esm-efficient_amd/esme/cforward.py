@@ -71,7 +71,15 @@ class ModelDescriptor:
 
     @staticmethod
     def signature(model):
-        return tuple((p.data_ptr(), p._version) for p in model.parameters())
+        """(storage, version) of every parameter: `load_state_dict`, `copy_`, optimiser steps and re-allocations all change
+        it, and the descriptor (which points at DERIVED copies: fused q/k/v, LayerNorm-folded weights) is rebuilt.  A write
+        through `p.data` (which bumps no version counter) is the one thing it cannot see: call `model.invalidate_graphs()`
+        after such a write -- it drops this descriptor together with the captured graphs.  The parameter list is cached on
+        the model (the module tree is fixed after construction), so the check is one tuple build, not a module walk."""
+        params = model.__dict__.get('_cparams')
+        if params is None:
+            params = model.__dict__['_cparams'] = list(model.parameters())
+        return tuple([(p.data_ptr(), p._version) for p in params])
 
     @staticmethod
     def supported(model) -> bool:

@@ -268,9 +268,12 @@ class ESM2(nn.Module):
         return self._graph_cache.run(what, tokens, pad_args, clone)
 
     def invalidate_graphs(self):
-        """Forget captured hipGraphs (after changing weights in place)."""
+        """Forget captured hipGraphs and the C-entry model descriptor (after changing weights in place, in particular
+        through `p.data`, which bumps no version counter)."""
         if getattr(self, '_graph_cache', None) is not None:
             self._graph_cache.clear()
+        self.__dict__.pop('_cdesc', None)
+        self.__dict__.pop('_cparams', None)
 
     # -- loading -------------------------------------------------------------------
     @classmethod

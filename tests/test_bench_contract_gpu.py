@@ -27,6 +27,9 @@ def test_bench_json_contract():
     assert abs(d['value'] - 16384 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 'traffic' in r
+    assert 'traffic_source' in r and (r['traffic'] is None) == (r['traffic_source'] is None)      # a static file, named; None off the headline
+    assert 'instrumented' in d['kernel_ms_per_step_source'] and 'multi_gpu' not in d
+    assert d['parity']['rows_vs_oracle_bf16'] == 512
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'residues/s' and c['cores'] >= 1 and c['value'] > 0 and c['sample']
 
@@ -42,6 +45,10 @@ def test_bench_self_launch_rccl_world1():
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['config']['launcher'] == 'torch.distributed.run (self-launched)'
+    m = d['multi_gpu']                                                           # launcher runs say what RCCL saw and time the gather apart
+    assert m['world_size_seen'] == 1 and m['backend'].startswith('nccl') and m['gather_ms'] > 0
+    assert m['gather_bytes_per_rank'] == 4096 * 33 * 2 and m['rank_ms_per_step']['min'] <= m['rank_ms_per_step']['max']
+    assert abs(m['ms_per_step_incl_gather'] - (d['ms_per_step'] + m['gather_ms'])) < 2e-3
     assert 'esm2_8m' in d['metric'] and 'ESM2-650M' not in d['metric']          # label follows --model
 
 

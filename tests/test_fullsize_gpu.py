@@ -5,8 +5,8 @@ sequences), plus alone-vs-packed bit equality at full size.
 
   config 2  ESM2-150M (L=30, E=640, H=20, d=32), 8 192 packed residues, proteome-like varlen
   config 3  ESM2-650M (L=33, E=1280, H=20), 50 000 packed residues, uniform-500           (headline)
-  config 4  ESM2-3B geometry (E=2560, H=40): a 4-layer slice at 50 000 residues per GPU   (the 8-GPU split is the
-            driver's job; one rank's share is exactly this shape)
+  config 4  ESM2-3B (L=36, E=2560, H=40) at full depth on 50 000 residues: one rank's share of the 8 x 50 000 batch
+            (workflow/config/config.yaml:18; the 8-GPU split itself is the driver's run)
   config 5  ESMC-600M (L=36, E=1152, H=18, SwiGLU) on 32 x 1 002 residues, bf16 and 4-bit, and
             predict_mask_margin on the 1 000-aa protein with quantization='4bit'
 
@@ -88,11 +88,13 @@ def test_config2_esm2_150m_8192_full_depth():
     assert torch.equal(g, out)
 
 
-def test_config4_esm2_3b_geometry_50k():
-    model, w, H = load('esm2_3b', L=4)
-    assert model.embed_dim == 2560 and model.attention_heads == 40
+def test_config4_esm2_3b_full_depth_50k():
+    """BASELINE config 4, one rank's share at the model's REAL depth (36 layers, 5.7 GB of bf16 weights): rank 3's batch
+    (generator seed 3) of the 8 x 50 000 job; two whole sequences against the oracle, alone-vs-packed bit equality."""
+    model, w, H = load('esm2_3b')
+    assert model.embed_dim == 2560 and model.attention_heads == 40 and len(model.layers) == 36
     tokens, cu, max_len, lengths = syn.uniform_batch(50000, 500, seed=3)
-    check_sequences(model, w, H, tokens, cu, max_len, [1, 98], 'ESM2-3B geometry (E=2560, H=40), 4 layers, 50 000 residues')
+    check_sequences(model, w, H, tokens, cu, max_len, [1, 98], 'ESM2-3B (E=2560, H=40), 36 layers, 50 000 residues')
 
 
 def test_config5_esmc_600m_full_depth_32x1002():

@@ -224,6 +224,25 @@ def test_bench_self_launches_n_ranks_without_a_launcher():
     assert out.stderr.count('--gpus 2 but only 0 HIP devices are visible') == 2, out.stderr[-3000:]
 
 
+def test_bench_two_rank_dry_run_fields():
+    """`bench.py --gpus 2 --dry-run`: the N > 1 bookkeeping end to end on CPU (gloo; no kernel runs, the line is marked
+    dry_run and carries no value): self-launch with 2 ranks, fences, max-over-ranks step time with the per-rank spread, the
+    logits all-gather timed SEPARATELY from the step, the world size the process group reports."""
+    import json
+    out = _run_bench(['--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1', '--model', 'esm2_8m', '--tokens', '1024',
+                      '--seq-len', '256'], timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['dry_run'] is True and d['value'] is None and d['n_gpus'] == 2 and d['steps'] == 3
+    m = d['multi_gpu']
+    assert m['world_size_seen'] == 2 and m['backend'] == 'gloo'
+    assert 0 < m['rank_ms_per_step']['min'] <= m['rank_ms_per_step']['max'] and abs(m['rank_ms_per_step']['max'] - d['ms_per_step']) < 1e-3
+    assert m['gather_ms'] > 0 and m['gather_bytes_per_rank'] == 1024 * 33 * 2
+    assert abs(m['ms_per_step_incl_gather'] - (d['ms_per_step'] + m['gather_ms'])) < 2e-3
+
+
 def test_gelu_polynomial_all_bf16_inputs():
     """The GEMM epilogue's GELU (csrc/common.h: gelu(x) = max(x, 0) - |x| 2^p(|x|), p a minimax polynomial of log2 Phi(-z))
     restated in numpy with the kernel's fp32 arithmetic (coefficients parsed from the header, fused multiply-adds) and
