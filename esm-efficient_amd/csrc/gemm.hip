@@ -317,34 +317,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     ESME_TRACE_MARK(1);
     if constexpr (PERSIST) set_sources();     // recomputed here so the 16 address registers are dead across the previous epilogue
     if constexpr (P8) {
-    // ---- 8-phase main loop (the CDNA4 guide's 256 x 256 template, rebuilt on this kernel's operand layout; lab version and
-    // ablations: tools/lab/gemm_8phase.hip, profiles/r03_gemm_8phase_lab.txt).  With 16-cycle MFMAs the lockstep schedule below
-    // is ISSUE-bound (two waves per SIMD each interleave a ds_read behind every MFMA: > 16 issue cycles per MFMA slot) and gains
-    // 2-3 % from the 16x16x32 form where this one gains 11 %.  A K-tile is FOUR half-tiles of 128 LDS rows:
+    // ---- staggered-group main loop: the CDNA4 guide's 256 x 256 "8-phase" template rebuilt on this kernel's operand layout,
+    // then merged to TWO phases per K-tile (lab versions and ablations: tools/lab/gemm_8phase.hip, profiles/r03_gemm_8phase_lab.txt,
+    // profiles/r03_gemm_4phase_lab.txt).  With 16-cycle MFMAs the lockstep schedule below is ISSUE-bound (two waves per SIMD
+    // each interleave a ds_read behind every MFMA: > 16 issue cycles per MFMA slot) and gains 2-3 % from the 16x16x32 form
+    // where the template's structure gains 11 %; halving its barriers (32-MFMA bursts instead of 16) adds another 6 %.
+    // A K-tile is FOUR half-tiles of 128 LDS rows:
     //   A-h = rows {wm * 128 + h * 64 + [0, 64)},  W-h = columns {wn * 64 + h * 32 + [0, 32)}      (h = 0, 1; all wm / wn)
     // so every half-tile is consumed by ALL waves in exactly ONE phase and is restaged right after it:
-    //   ph1: read W-h0 (4 x b128), A-h0 (8) | 16 MFMA acc[0..1][0..3] | stage A-h1 of tile t+1
-    //   ph2: read W-h1 (4)                  | 16 MFMA acc[2..3][0..3] | stage W-h0 of tile t+2  (its reads were retired by lgkmcnt(8) in ph1)
-    //   ph3: read A-h1 (8)                  | 16 MFMA acc[2..3][4..7] | stage A-h0 of tile t+2
-    //   ph4: -                              | 16 MFMA acc[0..1][4..7] | stage W-h1 of tile t+2, then vmcnt(6): tile t+1 has landed,
-    //                                                                   three half-tiles of t+2 stay in flight ACROSS the barriers
-    // Each phase = {reads, 2 LDS-DMAs} s_barrier {lgkmcnt(0), 16 MFMAs} s_barrier, raw barriers (no vmcnt drain), and the wave
+    //   phase A: read W-h0, W-h1 (8 x b128), A-h0 (8) | 32 MFMA acc[0..3][0..3] | stage A-h1 of tile t+1
+    //   phase B: read A-h1 (8)                        | 32 MFMA acc[0..3][4..7] | stage W-h0, A-h0, W-h1 of tile t+2, then
+    //            vmcnt(6): tile t+1 has landed, three half-tiles of t+2 stay in flight ACROSS the barriers
+    // Each phase = {reads, LDS-DMAs, lgkmcnt(0)} s_barrier {32 MFMAs} s_barrier -- raw barriers, no vmcnt drain -- and the wave
     // group of waves 4-7 runs ONE barrier behind waves 0-3: on every SIMD one wave issues its MFMAs back to back while its
-    // partner reads and stages.  A buffer is read one phase after the wait that retires it and restaged >= 2 phases after its
-    // last read (1 after for W-h0, whose reads are retired before the phase's first barrier).
-    if (KT > 1) {                             // first three half-tiles of K-tile 1 (W-h0, A-h0, W-h1); the fourth goes out in phase 1
+    // partner reads and stages.  The reads are retired BEFORE the phase's first barrier (the wait is free: the partner is
+    // inside a 512-cycle MFMA burst), so a half-tile may be restaged one phase after the phase that read it; a staged
+    // half-tile is read at the earliest one phase after the vmcnt that retires it.
+    if (KT > 1) {                             // first three half-tiles of K-tile 1 (W-h0, A-h0, W-h1); the fourth goes out in phase A
         stage_piece(1, par ^ 1, IA); stage_piece(1, par ^ 1, IA + 1);
         stage_piece(1, par ^ 1, 0); stage_piece(1, par ^ 1, 1);
         stage_piece(1, par ^ 1, IA + 2); stage_piece(1, par ^ 1, IA + 3);
     }
     if (wm == 1) __builtin_amdgcn_s_barrier();                         // stagger: waves 4-7 run one barrier behind
-    bf16x8 fa[FMH][2], fw0[FN / 2][2], fw1[FN / 2][2];
+    bf16x8 fa[FMH][2], fw[FN][2];
     constexpr int HALFB = (BM / 2) * 128;                              // bytes of a half-tile
-    auto rdWh = [&](bf16x8 (*f)[2], const char* base, const int h) {
+    static_assert(FN == 4 && FMH == 4, "P8 geometry");
+    auto rdW2 = [&](const char* base) {
 #pragma unroll
-        for (int w = 0; w < FN / 2; ++w)
+        for (int i = 0; i < FN; ++i)                                   // fragment i = half-tile i / 2, 16-row block i % 2
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) f[w][ks] = *reinterpret_cast<const bf16x8*>(base + rowW + h * HALFB + w * 16 * 128 + coff[ks]);
+            for (int ks = 0; ks < 2; ++ks) fw[i][ks] = *reinterpret_cast<const bf16x8*>(base + rowW + (i >> 1) * HALFB + (i & 1) * 16 * 128 + coff[ks]);
     };
     auto rdAh = [&](const char* base, const int h) {
 #pragma unroll
@@ -352,18 +354,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *reinterpret_cast<const bf16x8*>(base + rowA + h * HALFB + f * 16 * 128 + coff[ks]);
     };
-    auto mma = [&](const bf16x8 (*fw)[2], const int i0, const int j0) {       // W half-tile (fragments i0, i0 + 1) x A half-tile (j0 .. j0 + 3)
+    auto mma = [&](const int j0) {                                    // all W fragments x A half-tile (accumulator rows j0 .. j0 + 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int w = 0; w < FN / 2; ++w)
+            for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int f = 0; f < FMH; ++f)
-                    acc[i0 + w][j0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[w][ks], fa[f][ks], acc[i0 + w][j0 + f], 0, 0, 0);
+                    acc[i][j0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][ks], fa[f][ks], acc[i][j0 + f], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -372,25 +374,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const int buf = (kt + par) & 1;
         const char* base = smem + buf * STAGE;
         const bool m1 = kt + 1 < KT, m2 = kt + 2 < KT;
-        // ---- phase 1
-        rdWh(fw0, base, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase A
+        rdW2(base);
         rdAh(base, 0);
         if (m1) { stage_piece(kt + 1, buf ^ 1, 2); stage_piece(kt + 1, buf ^ 1, 3); }
         else rot_prefetch(buf ^ 1, 0);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");            // the four W-h0 reads have returned: W-h0 may be restaged in phase 2
-        mma(fw0, 0, 0);
-        // ---- phase 2
-        rdWh(fw1, base, 1);
-        if (m2) { stage_piece(kt + 2, buf, IA); stage_piece(kt + 2, buf, IA + 1); }
-        else if (!m1) rot_prefetch(buf ^ 1, 1);
-        mma(fw1, FN / 2, 0);
-        // ---- phase 3
+        mma(0);
+        // ---- phase B
         rdAh(base, 1);
-        if (m2) { stage_piece(kt + 2, buf, 0); stage_piece(kt + 2, buf, 1); }
-        mma(fw1, FN / 2, FMH);
-        // ---- phase 4
-        if (m2) { stage_piece(kt + 2, buf, IA + 2); stage_piece(kt + 2, buf, IA + 3); }
+        if (m2) {
+            stage_piece(kt + 2, buf, IA); stage_piece(kt + 2, buf, IA + 1);
+            stage_piece(kt + 2, buf, 0); stage_piece(kt + 2, buf, 1);
+            stage_piece(kt + 2, buf, IA + 2); stage_piece(kt + 2, buf, IA + 3);
+        } else if (!m1) rot_prefetch(buf ^ 1, 1);
 #ifdef ESME_GEMM_TRACE
         const unsigned long long bw0 = __builtin_readcyclecounter();
 #endif
@@ -399,7 +395,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #ifdef ESME_GEMM_TRACE
         trace_vm_wait += __builtin_readcyclecounter() - bw0;
 #endif
-        mma(fw0, 0, FMH);
+        mma(FMH);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                         // re-align the groups: every LDS read of the tile is done after this
     } else {
@@ -698,6 +694,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
         }
+        // PERSIST: the next tile's K-tile 0 (issued above, before the first pass's stores) is waited for HERE, before the last
+        // pass's stores go out, so that the barrier that ends the tile needs no vmcnt(0): a vmcnt(0) there would also wait for
+        // the ACKNOWLEDGEMENT of the stores issued just before it (~1 us of dead matrix pipe per tile).  The stores then
+        // drain under the next tile's main loop; its counted vmcnt(6) stays correct with stores in flight (loads return in
+        // order among loads: "at most 6 operations outstanding" leaves at most the 6 newest LDS-DMAs pending whatever the
+        // stores do -- they can only make the wait longer).
+        if constexpr (PERSIST) {
+            if (pass == NPASS - 1 && have_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
         const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
@@ -729,7 +734,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         if constexpr (STATS) {
             // the block's column waves combine as a tree ((w0 + w1) + (w2 + w3)): the canonical association the consumer
             // assumes (see the LN-fold prologue), whatever the tile width
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (LDS only: a __syncthreads() would also wait for the C stores' acks)
+            __builtin_amdgcn_s_barrier();
             if (tid < BM && em0 + tid < a.M) {
                 f32x2 acc2 = blkst[tid];
                 acc2[0] += blkst[BM + tid][0]; acc2[1] += blkst[BM + tid][1];
@@ -777,8 +783,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             for (int j = 0; j < FM; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        __syncthreads();                      // the next tile's K-tile 0 has landed (vmcnt) and its strips are published;
-                                              // every wave is done with this tile's slabs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // the next tile's K-tile 0 has landed (every wave waited for its pieces before its last
+                                              // stores), its strips are published, every wave is done with this tile's slabs
     }
     }   // tile loop
 }

@@ -140,6 +140,55 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr ((FLAGS & 32) != 0 && MF == 16) {
+    // ---- TWO phases per K-tile (32 MFMAs each): half the barriers.  Phase A: read W-h0, W-h1 (8), A-h0 (8) -> acc[0..3][0..3];
+    // phase B: read A-h1 (8) -> acc[0..3][4..7].  Every phase ends its read section with lgkmcnt(0) BEFORE the barrier (the
+    // partner wave is inside a 512-cycle MFMA burst: the wait is free), so each half-tile may be restaged one phase after
+    // its read: B(t) stages W-h0, W-h1, A-h0 of t+2 (6 DMAs), A(t+1) stages A-h1 of t+2 (2 DMAs); vmcnt(6) in B(t+1).
+    bf16x8 fw[4][KS];
+    auto rdW2 = [&](const char* base) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fw[h * 2 + w][ks] = *reinterpret_cast<const bf16x8*>(base + rowW + h * HALF + w * 16 * 128 + coff[ks]);
+    };
+    auto mma2 = [&](const int j) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(FLAGS & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int f = 0; f < FH; ++f)
+                    acc[i][j * FH + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][ks], fa[f][ks], acc[i][j * FH + f], 0, 0, 0);
+        if (!(FLAGS & 2)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // (prologue above issued tile 0 + W-h0, A-h0, W-h1 of tile 1 and waited for tile 0: matches this schedule's order)
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* base = smem + (kt & 1) * BUF;
+        const bool m1 = kt + 1 < KT, m2 = kt + 2 < KT;
+        // ---- phase A
+        rdW2(base);
+        rdA(base, 0);
+        if (m1) stageA(kt + 1, 1);
+        mma2(0);
+        // ---- phase B
+        rdA(base, 1);
+        if (m2) { stageW(kt + 2, 0); stageA(kt + 2, 0); stageW(kt + 2, 1); }
+        if (m2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mma2(1);
+    }
+    } else {
     for (int kt = 0; kt < KT; ++kt) {
         const char* base = smem + (kt & 1) * BUF;
         const bool m1 = kt + 1 < KT, m2 = kt + 2 < KT;
@@ -163,6 +212,7 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
         if ((FLAGS & 8) || !m2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile t+1 has landed; t+2's first three half-tiles stay in flight
         mma(fw0, 0, 1);
+    }
     }
     if (!(FLAGS & 4) && wm == 0) __builtin_amdgcn_s_barrier();          // re-align the groups: every LDS read is done after this
     if (FLAGS & 1) {
@@ -244,6 +294,9 @@ extern "C" int lab8_run(int flags, const void* A, const void* W, void* C, int64_
         case 17: return launch<1, 16>(a, s);
         case 18: return launch<2, 16>(a, s);
         case 20: return launch<4, 16>(a, s);
+        case 48: return launch<32, 16>(a, s);       // 2 phases per K-tile
+        case 49: return launch<33, 16>(a, s);
+        case 50: return launch<34, 16>(a, s);
         default: return -4;
     }
 }
