@@ -899,12 +899,14 @@ static unsigned long long* g_trace = nullptr;
 extern "C" void esme_hip_debug_set_gemm_trace(void* p) { g_trace = (unsigned long long*)p; }
 #endif
 
-// 256x256 tiles (one workgroup per CU) once they fill the chip about twice over; otherwise the
-// 128x128 configuration (2-3 workgroups per CU, 4x the tiles) keeps more CUs busy.
+// 256 x 256 tiles (one workgroup per CU) once they fill ~5/8 of the chip; otherwise the 128 x 128 configuration (2-3 workgroups
+// per CU, 4x the tiles) keeps more CUs busy.  Round 3 moved the threshold from 384 tiles (1.5 rounds) to 160: the
+// staggered-group loop keeps three half-tiles in flight and starts a cold single round far better than the round-2 loop did
+// (tools/gemm_small_m.py, ESM2-150M shapes: 160 ... 320 tiles 256-tiles win by 7-22 %, 96 ... 128 tiles 128-tiles by 19-24 %).
 static int pick_tile(int64_t M, int N, const esme_gemm_opts_t* opts) {
     if (opts && opts->tile) return opts->tile;
     const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    return (N >= 256 && big_tiles >= 384) ? 2 : 1;
+    return (N >= 256 && big_tiles >= 160) ? 2 : 1;
 }
 
 extern "C" int esme_hip_gemm_stats_blocks_opts(int64_t M, int N, const esme_gemm_opts_t* opts) {

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--m', type=int, default=8192)
 ap.add_argument('--e', type=int, default=640)
 ap.add_argument('--ffn', type=int, default=0)
-ap.add_argument('--tiles', default='1,2,3')
+ap.add_argument('--tiles', default='1,2')
 args = ap.parse_args()
 lib = _hip.load()
 dev = torch.device('cuda', 0)
