@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 

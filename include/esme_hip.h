@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 2
+#define ESME_HIP_ABI_VERSION 3
 
 enum {
     ESME_OK = 0,
