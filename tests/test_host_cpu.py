@@ -221,7 +221,11 @@ def test_bench_self_launches_n_ranks_without_a_launcher():
     two ranks were started with WORLD_SIZE=2 (the round-1 bug: it silently ran one rank and printed n_gpus 1)."""
     out = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], timeout=600)
     assert out.returncode != 0 and '{' not in out.stdout
-    assert out.stderr.count('--gpus 2 but only 0 HIP devices are visible') == 2, out.stderr[-3000:]
+    # every rank prints the message unless the launcher's SIGTERM (sent when the first rank exits) reaches it first: what
+    # must hold is that the device-count check fired and that a SECOND rank existed (its own message, or its entry in
+    # torch.distributed.run's failure report)
+    n = out.stderr.count('--gpus 2 but only 0 HIP devices are visible')
+    assert n >= 1 and (n == 2 or 'local_rank: 1' in out.stderr), out.stderr[-3000:]
 
 
 def test_bench_two_rank_dry_run_fields():
