@@ -45,11 +45,16 @@ struct GemmArgs {
 #endif
 
 #ifdef ESME_GEMM_TRACE
-#define ESME_TRACE_MARK(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-#define ESME_TRACE_REAL(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ESME_TRACE_STRIDE 32
+#define ESME_TRACE_MARK(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * ESME_TRACE_STRIDE + (i)] = __builtin_readcyclecounter(); } while (0)
+#define ESME_TRACE_REAL(i) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * ESME_TRACE_STRIDE + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// tile-seam timeline of a persistent workgroup (slots 16..31): stamps of wave 0 from the end of the main loop of its SECOND tile
+// (trace_tile == 1) to the first MFMA burst of its third (tools/gemm_seam_trace.py)
+#define ESME_TRACE_SEAM(i, t) do { if (a.trace && threadIdx.x == 0 && trace_tile == (t)) a.trace[(size_t)blockIdx.x * ESME_TRACE_STRIDE + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ESME_TRACE_MARK(i) do {} while (0)
 #define ESME_TRACE_REAL(i) do {} while (0)
+#define ESME_TRACE_SEAM(i, t) do {} while (0)
 #endif
 
 static constexpr int BK = 64;                 // k elements per LDS tile row (128 bytes)

@@ -312,9 +312,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     FragA a0, a1;
 #ifdef ESME_GEMM_TRACE
     unsigned long long trace_barrier_wait = 0, trace_vm_wait = 0;
+    int trace_tile = -1;
 #endif
     for (;;) {                                // PERSIST: one pass per tile; otherwise a single pass
     ESME_TRACE_MARK(1);
+#ifdef ESME_GEMM_TRACE
+    ++trace_tile;
+#endif
     if constexpr (PERSIST) set_sources();     // recomputed here so the 16 address registers are dead across the previous epilogue
     if constexpr (P8) {
     // ---- staggered-group main loop: the CDNA4 guide's 256 x 256 "8-phase" template rebuilt on this kernel's operand layout,
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         stage_piece(1, par ^ 1, 0); stage_piece(1, par ^ 1, 1);
         stage_piece(1, par ^ 1, IA + 2); stage_piece(1, par ^ 1, IA + 3);
     }
+    ESME_TRACE_SEAM(27, 2);
     if (wm == 1) __builtin_amdgcn_s_barrier();                         // stagger: waves 4-7 run one barrier behind
     bf16x8 fa[FMH][2], fw[FN][2];
     constexpr int HALFB = (BM / 2) * 128;                              // bytes of a half-tile
@@ -379,7 +384,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         rdAh(base, 0);
         if (m1) { stage_piece(kt + 1, buf ^ 1, 2); stage_piece(kt + 1, buf ^ 1, 3); }
         else rot_prefetch(buf ^ 1, 0);
+        if (kt == 0) ESME_TRACE_SEAM(28, 2);
         mma(0);
+        if (kt == 0) ESME_TRACE_SEAM(29, 2);
         // ---- phase B
         rdAh(base, 1);
         if (m2) {
@@ -397,7 +404,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #endif
         mma(FMH);
     }
+    ESME_TRACE_SEAM(16, 1);
     if (wm == 0) __builtin_amdgcn_s_barrier();                         // re-align the groups: every LDS read of the tile is done after this
+    ESME_TRACE_SEAM(17, 1);
     } else {
     rdW(w0, smem + par * STAGE, 0);
     rdA(a0, smem + par * STAGE, 0, 0);
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // memory is already free for the epilogue slabs.
     ESME_TRACE_MARK(2);
 #ifdef ESME_GEMM_TRACE
-    if (a.trace && threadIdx.x == 0) { a.trace[(size_t)blockIdx.x * 16 + 10] = trace_barrier_wait; a.trace[(size_t)blockIdx.x * 16 + 11] = trace_vm_wait; }   // wave 0: cycles in the loop's barrier / in the vmcnt(0) before it
+    if (a.trace && threadIdx.x == 0) { a.trace[(size_t)blockIdx.x * ESME_TRACE_STRIDE + 10] = trace_barrier_wait; a.trace[(size_t)blockIdx.x * ESME_TRACE_STRIDE + 11] = trace_vm_wait; }   // wave 0: cycles in the loop's barrier / in the vmcnt(0) before it
 #endif
 #ifdef ESME_GEMM_TRACE
     if (a.nt_store == 3) return;              // tuning hook: main loop only (results discarded)
@@ -597,6 +606,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     bool have_next = false;
     if constexpr (PERSIST && ROTD > 0) __syncthreads();      // (PERSIST: all tiles take the barrier) table reads done before the slab writes
     ESME_TRACE_MARK(3);
+    ESME_TRACE_SEAM(18, 1);
     if (a.vec_ok) {
         // Branch-free: every load of the epilogue (bias quads, residual quads) is issued up front
         // with clamped addresses (overhanging rows/columns are computed but never stored), so the
@@ -682,7 +692,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // stage buffer and the strips are refilled for the NEXT tile while this one's results are stored.
         if constexpr (PERSIST) {
             if (pass == 0) {
+                ESME_TRACE_SEAM(19, 1);
                 __syncthreads();
+                ESME_TRACE_SEAM(20, 1);
                 pid += pid_step;
                 have_next = pid < pid_end;
                 if (have_next) {
@@ -692,6 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     stage(0, par);
                     make_strips();
                 }
+                ESME_TRACE_SEAM(21, 1);
             }
         }
         // PERSIST: the next tile's K-tile 0 (issued above, before the first pass's stores) is waited for HERE, before the last
@@ -701,7 +714,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // order among loads: "at most 6 operations outstanding" leaves at most the 6 newest LDS-DMAs pending whatever the
         // stores do -- they can only make the wait longer).
         if constexpr (PERSIST) {
+            if (pass == 0) ESME_TRACE_SEAM(31, 1);            // (first-pass stores not issued yet: slot 22 is stamped after them)
+            if (pass == NPASS - 1) ESME_TRACE_SEAM(23, 1);
             if (pass == NPASS - 1 && have_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pass == NPASS - 1) ESME_TRACE_SEAM(24, 1);
         }
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
@@ -729,6 +745,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
         }
+        if constexpr (PERSIST) { if (pass == 0) ESME_TRACE_SEAM(22, 1); else ESME_TRACE_SEAM(25, 1); }
         }   // pass
         ESME_TRACE_MARK(6);
         if constexpr (STATS) {
@@ -784,6 +801,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ESME_TRACE_SEAM(26, 1);
         __builtin_amdgcn_s_barrier();         // the next tile's K-tile 0 has landed (every wave waited for its pieces before its last
                                               // stores), its strips are published, every wave is done with this tile's slabs
     }

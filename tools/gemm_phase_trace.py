@@ -45,12 +45,12 @@ names = ['prologue (K-tile 0 + LN strip)', 'main loop', 'LN fold / rotary math',
          'epilogue math -> slab', 'slab -> C stores (+row sums)', 'stats reduce / tail']
 for name, fn in fns.items():
     fn(); fn()
-    buf = torch.zeros(8192 * 16, dtype=torch.int64, device=dev)
+    buf = torch.zeros(8192 * 32, dtype=torch.int64, device=dev)
     lib.esme_hip_debug_set_gemm_trace(buf.data_ptr())
     fn()
     torch.cuda.synchronize()
     lib.esme_hip_debug_set_gemm_trace(None)
-    t = buf.cpu().numpy().reshape(-1, 16)
+    t = buf.cpu().numpy().reshape(-1, 32)
     t = t[t[:, 0] != 0]
     if os.environ.get('TRACE_DUMP'):
         np.save(os.path.join(os.environ['TRACE_DUMP'], 'trace_' + name.split()[0] + '.npy'), t)
