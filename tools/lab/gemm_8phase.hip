@@ -218,6 +218,27 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
     if (FLAGS & 1) {
         if (a.K > 0) return;
     }
+    if constexpr ((FLAGS & 64) != 0 && MF == 16) {
+        // ---- direct epilogue: no LDS.  Lane (l15, q) holds columns 4q..4q+3 of each 16-column fragment; v_permlane16_swap
+        // between fragments i and i+1 (16-lane rows 0<->1, 2<->3) leaves every lane with 8 CONSECUTIVE columns (16 B):
+        // rows q even: fragment i, columns 8 (q >> 1) ..; rows q odd: fragment i + 1.  One store instruction then covers 16 token
+        // rows x 64 contiguous bytes.
+        const int q = lane >> 4, l15 = lane & 15;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned int x0 = pack_bf16(acc[2 * ip][j][0], acc[2 * ip][j][1]), x1 = pack_bf16(acc[2 * ip][j][2], acc[2 * ip][j][3]);
+                unsigned int y0 = pack_bf16(acc[2 * ip + 1][j][0], acc[2 * ip + 1][j][1]), y1 = pack_bf16(acc[2 * ip + 1][j][2], acc[2 * ip + 1][j][3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+                const int64_t m = m0 + wm * 128 + j * 16 + l15;
+                const int n = n0 + wn * 64 + (2 * ip + (q & 1)) * 16 + (q >> 1) * 8;
+                if (m < a.M && n < a.N) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+            }
+        return;
+    }
     // ---- epilogue: wave-private slab (128 rows x 128 B, 16-B chunks XORed with row & 7), whole-line 16-B stores
     char* slab = smem + wave * 16384;
     if constexpr (MF == 32) {
@@ -297,6 +318,7 @@ extern "C" int lab8_run(int flags, const void* A, const void* W, void* C, int64_
         case 48: return launch<32, 16>(a, s);       // 2 phases per K-tile
         case 49: return launch<33, 16>(a, s);
         case 50: return launch<34, 16>(a, s);
+        case 112: return launch<96, 16>(a, s);      // 2 phases per K-tile, direct (no-LDS) epilogue
         default: return -4;
     }
 }

@@ -11,7 +11,7 @@ lab.lab8_run.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.
                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 names = {0: '8-phase', 1: '8-phase no store', 2: '8-phase no setprio', 4: '8-phase no stagger', 6: '8-phase lockstep, no setprio',
          8: '8-phase vmcnt(0)', 16: '8-phase 16x16x32', 17: '8-phase 16x16x32 no store', 18: '8-phase 16x16x32 no setprio',
-         20: '8-phase 16x16x32 no stagger', 48: '4-phase 16x16x32', 49: '4-phase 16x16x32 no store', 50: '4-phase 16x16x32 no setprio'}
+         20: '8-phase 16x16x32 no stagger', 48: '4-phase 16x16x32', 49: '4-phase 16x16x32 no store', 50: '4-phase 16x16x32 no setprio', 112: '4-phase 16x16x32 direct stores'}
 variants = [int(v) for v in os.environ.get('LAB8_VARIANTS', '0,1,16,17,48,50,49').split(',')]
 shapes = [('uniform', 4096, 4096, 4096), ('uniform', 8192, 8192, 8192), ('normal', 50000, 5120, 1280), ('normal', 50000, 3840, 1280),
           ('normal', 50000, 1280, 5120), ('normal', 50000, 1280, 1280)]
