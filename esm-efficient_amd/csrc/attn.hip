@@ -50,6 +50,7 @@ struct AttnArgs {
     int nhb;                     // ping-pong kernel: H * B (sequence, head) pairs
     float thr;                   // defer-max threshold in log2 units (0 = rescale whenever a row max grows)
     int spec;                    // ping-pong kernel: speculative softmax after a row's first key tile (see the kernel header)
+    const int32_t* order;        // optional: work item i belongs to sequence order[i] (longest first: esme_hip_seq_order); NULL = i
 };
 
 // swizzle of the 16-byte chunk index inside a K-tile row of D bf16 (CPR chunks per row)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
+    const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
     const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
     const int q0 = blockIdx.x * (QT * QB);
     if (q0 >= S) return;
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     const int qt = (int)(bi % (unsigned int)a.nqt);
     const unsigned int hb = (bi / (unsigned int)a.nqt) * 8u + xcd;
     if (hb >= (unsigned int)a.nhb) return;
-    const int h = (int)(hb % (unsigned int)a.H), b = (int)(hb / (unsigned int)a.H);
+    const int h = (int)(hb % (unsigned int)a.H), bi_seq = (int)(hb / (unsigned int)a.H);
+    const int b = a.order ? a.order[bi_seq] : bi_seq;       // (speed only: the longest sequences' work items are dispatched first)
     const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
     const int q0 = qt * ROWS;
     if (q0 >= S) return;
@@ -790,7 +792,8 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
                    "attn: misaligned");
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
-               softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec};
+               softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec,
+               opts ? opts->seq_order : nullptr};
     const hipStream_t s = (hipStream_t)stream;
     // (the ping-pong kernel addresses K / V with 32-bit byte offsets inside one sequence: (max_len + one tile) rows must fit)
     const bool fits32 = ((int64_t)max_len + KT) * ld_qkv * 2 < 0xffffffffLL;

@@ -5,6 +5,7 @@
 // through this library's own C entry points, so results are bit-identical to the module-by-module path.  What it
 // removes is the host: ~160 ctypes calls (3-10 ms of Python per forward) become one, which is what a small model
 // (ESM2-8M / 150M at a few thousand residues: less GPU work than that) needs when it is not replayed from a hipGraph.
+#include <cstdlib>
 #include "launch.h"
 
 using namespace esme;
@@ -12,7 +13,7 @@ using namespace esme;
 namespace {
 
 struct Ws {                        // carve-up of the caller's workspace
-    char* qkv; char* attn; char* mid; char* head; float* sums; float* part_a; float* part_b;
+    char* qkv; char* attn; char* mid; char* head; float* sums; float* part_a; float* part_b; int32_t* order;
 };
 
 inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
@@ -30,7 +31,8 @@ int64_t carve(const esme_model_desc_t* m, int64_t T, Ws* w, char* base) {
     char* sums = take(T * 2 * 4);
     char* pa = take(nblk * T * 2 * 4);
     char* pb = take(nblk * T * 2 * 4);
-    if (w) *w = Ws{qkv, attn, mid, head, (float*)sums, (float*)pa, (float*)pb};
+    char* ord = take(1024 * 4);              // dispatch order of the sequences for the attention launches (batches of <= 1024 sequences)
+    if (w) *w = Ws{qkv, attn, mid, head, (float*)sums, (float*)pa, (float*)pb, (int32_t*)ord};
     return off;
 }
 
@@ -61,6 +63,13 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
     const bool rot_fused = m->rotary && !m->qk_norm && (dp == 16 || dp == 32 || dp == 64) && Ea % 32 == 0;
     int rc;
 #define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
+    // longest sequences first in every attention launch (speed only; ragged batches), computed once per forward
+    esme_attn_opts_t aopts{(int)sizeof(esme_attn_opts_t), 0, 0, 8.0f, 1, nullptr};
+    static const bool use_order = [] { const char* e = getenv("ESME_ATTN_ORDER"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (use_order && B > 1 && B <= 1024 && m->n_layers > 0) {
+        ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));
+        aopts.seq_order = w.order;
+    }
     const float* stats = w.sums;            // statistics describing the current residual stream
     int stats_nblk = 1;
     if (m->n_layers > 0) ESME_TRY(esme_hip_row_sums(x, ldx, T, Ep, w.sums, stream));
@@ -78,7 +87,7 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
         } else if (m->rotary && !rot_fused) {
             ESME_TRY(esme_hip_rotary_varlen(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
         }
-        ESME_TRY(esme_hip_attn_varlen_fwd(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, scale, stream));
+        ESME_TRY(esme_hip_attn_varlen_fwd_opts(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, scale, &aopts, stream));
         esme_gemm_fusion_t fo{};
         fo.stats_out = w.part_b;
         ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, x, ldx, x, ldx, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));

@@ -61,6 +61,27 @@ __global__ __launch_bounds__(256) void seqpos_kernel(const int32_t* __restrict__
     if (seq) seq[t] = lo;
 }
 
+// order[rank] = i with rank = #{j : len_j > len_i or (len_j == len_i and j < i)}: longest sequence first, stable.  One
+// workgroup, lengths in LDS, B <= 1024 (each thread ranks one sequence against all others: <= 1024 LDS reads).
+__global__ __launch_bounds__(1024) void seq_order_kernel(const int32_t* __restrict__ cu, int B, int32_t* __restrict__ order) {
+    __shared__ int len[1024];
+    const int i = threadIdx.x;
+    if (B > 1024) {                       // too many for the rank sort: identity
+        for (int k = i; k < B; k += 1024) order[k] = k;
+        return;
+    }
+    if (i < B) len[i] = cu[i + 1] - cu[i];
+    __syncthreads();
+    if (i >= B) return;
+    const int li = len[i];
+    int rank = 0;
+    for (int j = 0; j < B; ++j) {
+        const int lj = len[j];
+        rank += (lj > li) || (lj == li && j < i);
+    }
+    order[rank] = i;
+}
+
 // ---------------------------------------------------------------- LayerNorm
 // One wave per row; the row stays in registers (NCH chunks of 8 bf16 per lane), so HBM
 // traffic is exactly one read + one write of the row: 4*E bytes.
@@ -501,6 +522,14 @@ extern "C" int esme_hip_seq_positions(const int32_t* cu_lens, int B, int64_t T, 
     hipLaunchKernelGGL(seqpos_kernel, dim3((unsigned int)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        cu_lens, B, T, pos, seq_id);
     return check_launch("seq_positions");
+}
+
+extern "C" int esme_hip_seq_order(const int32_t* cu_lens, int B, int32_t* order, void* stream) {
+    ESME_CHECK_ARG(B >= 0, "seq_order: bad B");
+    if (B == 0) return ESME_OK;
+    ESME_CHECK_ARG(cu_lens && order, "seq_order: null pointer");
+    hipLaunchKernelGGL(seq_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cu_lens, B, order);
+    return check_launch("seq_order");
 }
 
 extern "C" int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,

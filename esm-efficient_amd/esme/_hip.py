@@ -36,7 +36,8 @@ class GemmOpts(Structure):
 
 class AttnOpts(Structure):
     """esme_attn_opts_t (include/esme_hip.h)."""
-    _fields_ = [('struct_bytes', c_int), ('variant', c_int), ('q_blocks', c_int), ('defer_max_thr', c_float), ('speculative', c_int)]
+    _fields_ = [('struct_bytes', c_int), ('variant', c_int), ('q_blocks', c_int), ('defer_max_thr', c_float), ('speculative', c_int),
+                ('seq_order', c_void_p)]
 
 
 class LayerWeights(Structure):
@@ -62,6 +63,7 @@ SIGNATURES = {
     'esme_hip_embed_positions': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                                          c_int, c_int, c_void_p]),
     'esme_hip_seq_positions': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    'esme_hip_seq_order': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     'esme_hip_layernorm': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                    c_float, c_void_p]),
     'esme_hip_rotary_varlen': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
@@ -215,7 +217,7 @@ def set_attn_options(**kw) -> None:
     if not kw:
         _TLS.attn_opts = None
         return
-    o = _TLS.attn_opts or AttnOpts(ctypes.sizeof(AttnOpts), 0, 0, 8.0, 1)
+    o = _TLS.attn_opts or AttnOpts(ctypes.sizeof(AttnOpts), 0, 0, 8.0, 1, None)
     if 'variant' in kw: o.variant = int(kw['variant'])
     if 'q_blocks' in kw: o.q_blocks = int(kw['q_blocks'])
     if 'thr' in kw: o.defer_max_thr = float(kw['thr'])
@@ -229,7 +231,7 @@ class attn_options:
     speculative softmax)."""
 
     def __init__(self, variant: int = 0, q_blocks: int = 0, thr: float = 8.0, spec: int = 1):
-        self.opts = AttnOpts(ctypes.sizeof(AttnOpts), int(variant), int(q_blocks), float(thr), int(spec))
+        self.opts = AttnOpts(ctypes.sizeof(AttnOpts), int(variant), int(q_blocks), float(thr), int(spec), None)
 
     def __enter__(self):
         self.prev, _TLS.attn_opts = _TLS.attn_opts, self.opts
@@ -341,6 +343,18 @@ def seq_positions(cu_lens: torch.Tensor, total: int):
     return pos, seq
 
 
+def seq_order(cu_lens: torch.Tensor) -> Optional[torch.Tensor]:
+    """int32 (B): sequence indices sorted by length, longest first (device-side rank sort, no host sync): the dispatch
+    order `attn_varlen(..., order=)` takes.  None for B <= 1 or B > 1024 (no reordering)."""
+    B = cu_lens.numel() - 1
+    if B <= 1 or B > 1024:
+        return None
+    out = torch.empty(B, dtype=torch.int32, device=cu_lens.device)
+    _check(load().esme_hip_seq_order(_dev(cu_lens, 'cu_lens', torch.int32), B, _dev(out, 'order', torch.int32), _stream()),
+           'esme_hip_seq_order')
+    return out
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     shape = x.shape
@@ -392,9 +406,10 @@ def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torc
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
                 heads: int, softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
-                exact: bool = False) -> torch.Tensor:
+                exact: bool = False, order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q, k, v: (T, H*d) views sharing one row stride; returns (T, H*d).  `exact=True`: classic online softmax
-    with every row maximum exact (esme_hip_attn_varlen_fwd_exact; the high-precision mode)."""
+    with every row maximum exact (esme_hip_attn_varlen_fwd_exact; the high-precision mode).  `order` (seq_order(cu_lens)):
+    dispatch the longest sequences' work first -- speed only, the result is the same bit for bit."""
     qp, ld = _rows2d(q, 'attn q')
     kp, ld2 = _rows2d(k, 'attn k')
     vp, ld3 = _rows2d(v, 'attn v')
@@ -408,6 +423,10 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
     ao = _TLS.attn_opts
+    if order is not None and not exact:
+        base = ao
+        ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0,
+                      base.defer_max_thr if base else 8.0, base.speculative if base else 1, _dev(order, 'seq order', torch.int32))
     with _Traced('attn', (T, heads, d)):
         if ao is not None and not exact:
             _check(load().esme_hip_attn_varlen_fwd_opts(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32), cu.numel() - 1, T,

@@ -37,13 +37,14 @@ from esme.rotary import RotaryEmbedding
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order')
 
     def __init__(self, pos, cos, sin, fold=False, exact_attn=False):
         self.pos, self.cos, self.sin = pos, cos, sin
         self.fold = fold            # run the LN-folded fast path
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
         self.x32 = None             # high-precision mode: the fp32 residual stream (T, E_phys)
+        self.order = None           # dispatch order of the sequences for the attention launches (longest first; speed only)
         self.sums = None            # partial sums (nblk, T, 2) f32 describing the current residual stream
         self.part_a = None          # (stats_blocks, T, 2) f32 buffers the residual GEMMs write their row sums to
         self.part_b = None
@@ -236,7 +237,7 @@ class FlashMultiheadAttention(nn.Module):
         H, d = self.num_heads, self.head_pad
         return tuple(qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
 
-    def _attn(self, q, k, v, cu_lens, max_len, exact=False):
+    def _attn(self, q, k, v, cu_lens, max_len, exact=False, order=None):
         """(T, H, d) x 3 -> (T, E), the reference's `_attn` (esme/attention.py:112-124).  The kernel reads q, k, v with ONE
         row stride (the layer hands it column blocks of the fused (T, 3E) projection); a caller that passes separately
         allocated tensors, as the reference's call sites may, gets them repacked."""
@@ -245,7 +246,7 @@ class FlashMultiheadAttention(nn.Module):
         if not (q.stride(0) == k.stride(0) == v.stride(0)) or q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
             q, k, v = (t.reshape(T, E).contiguous() for t in (q, k, v))
         return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads,
-                                softmax_scale=self.head_dim ** -0.5, exact=exact)
+                                softmax_scale=self.head_dim ** -0.5, exact=exact, order=order)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None):
@@ -282,7 +283,8 @@ class FlashMultiheadAttention(nn.Module):
                     _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
                 else:
                     q, k = self.rot_emb(q, k, cu_lens, max_len, inplace=True)
-        a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn))
+        a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn),
+                       order=ctx.order if ctx is not None else None)
         wo, bo = self._weights_out()
         if resid is not None:
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)

@@ -229,6 +229,7 @@ class ESM2(nn.Module):
             from esme import cforward
             cforward.forward_layers(self, x, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin)
         else:
+            ctx.order = _hip.seq_order(cu_lens)     # longest sequences' attention work first (speed only; the C entry does the same)
             for i, layer in enumerate(self.layers):
                 x = layer(x, cu_lens, max_len, None, ctx, inplace=True)
                 if i in layers:

@@ -302,6 +302,36 @@ def test_attention_sequence_independence():
     assert torch.equal(alone, packed[333:483])          # bit-exact: same tiles, same order
 
 
+@pytest.mark.parametrize('lengths', [[5, 26, 61, 26, 1], [300], [7] * 40, list(range(1, 130)), [64] * 1024, [3] * 1025])
+def test_seq_order_is_a_stable_descending_sort(lengths):
+    """esme_hip_seq_order: sequence indices by length, longest first, ties in input order; None (no reordering) past 1024."""
+    from esme import _hip
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32).to(dev())
+    order = _hip.seq_order(cu)
+    if len(lengths) <= 1 or len(lengths) > 1024:
+        assert order is None
+        return
+    ref = np.argsort(-np.asarray(lengths), kind='stable')
+    assert np.array_equal(order.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('H,d,variant', [(20, 64, 0), (20, 64, 1), (20, 32, 0), (4, 128, 0), (3, 16, 0)])
+def test_attention_dispatch_order_changes_no_bit(H, d, variant):
+    """The longest-first dispatch order is a launch-geometry permutation: every output bit equals the identity order's."""
+    from esme import _hip
+    lengths = [37, 512, 1, 64, 300, 65, 129, 700, 2, 300]
+    T, E = sum(lengths), H * d
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32).to(dev())
+    g = rnd((T, 3 * E), 77).to(dev())
+    with _hip.attn_options(variant=variant):
+        plain = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu, max(lengths), H)
+        order = _hip.seq_order(cu)
+        sorted_ = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu, max(lengths), H, order=order)
+        rev = torch.flip(order, [0]).contiguous()
+        reversed_ = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu, max(lengths), H, order=rev)
+    assert torch.equal(plain, sorted_) and torch.equal(plain, reversed_)
+
+
 @pytest.mark.parametrize('V', [33, 64])
 def test_softmax_rows(V):
     from esme import _hip

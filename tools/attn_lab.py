@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--variants', default='1,4,8')
     ap.add_argument('--thr', default='8')
     ap.add_argument('--scale', type=float, default=1.0, help='std of q and k (scores ~ scale^2 * sqrt(d) * N(0,1) / sqrt(d))')
+    ap.add_argument('--order', action='store_true', help='also time every variant with the longest-first dispatch order')
     args = ap.parse_args()
     lib = _hip.load()
     dev = torch.device('cuda', 0)
@@ -88,6 +89,19 @@ def main():
             e.record()
             torch.cuda.synchronize()
             times[var].append(s.elapsed_time(e) / args.iters * 1e3)
+    if args.order:
+        order = _hip.seq_order(cu)
+        for mode, od in (('identity', None), ('longest-first', order), ('identity', None), ('longest-first', order)):
+            for var in variants:
+                _hip.set_attn_options(variant=var)
+                _hip.attn_varlen(q, k, v, cu, max_len, H, out=out, order=od)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(args.iters):
+                    _hip.attn_varlen(q, k, v, cu, max_len, H, out=out, order=od)
+                e.record()
+                torch.cuda.synchronize()
+                print(f'variant {var} order {mode}: {s.elapsed_time(e) / args.iters * 1e3:.1f} us')
     for var in variants:
         t = sorted(times[var])
         med = t[len(t) // 2]
