@@ -96,6 +96,36 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-z, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
 
+// Two elements at a time on the packed fp32 pipe (v_pk_fma_f32: the same IEEE fma per half, so every result bit equals
+// gelu_erf's).  The polynomial and the last fma cost half an instruction per element; |x| (no abs modifier on packed
+// operands), v_exp_f32 and the max stay per element: 6 instead of 8 VALU per element.  Used by the GEMM epilogue, where the
+// matrix pipe is idle (next to MFMAs packed fp32 is an anti-lever: MI355X_MICROARCH 'price of one filler').
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    const f32x2_t z = __builtin_elementwise_abs(x);
+    auto k = [](float c) { return f32x2_t{c, c}; };
+#if ESME_GELU_DEG == 7
+    f32x2_t p = __builtin_elementwise_fma(z, k(-1.8348100638831966e-06f), k(6.159828626550734e-05f));
+    p = __builtin_elementwise_fma(z, p, k(-0.0009305249550379813f));
+    p = __builtin_elementwise_fma(z, p, k(0.008507892489433289f));
+    p = __builtin_elementwise_fma(z, p, k(-0.05396007373929024f));
+    p = __builtin_elementwise_fma(z, p, k(-0.4584643840789795f));
+    p = __builtin_elementwise_fma(z, p, k(-1.1512510776519775f));
+    p = __builtin_elementwise_fma(z, p, k(-0.9999952912330627f));
+#else
+    f32x2_t p = __builtin_elementwise_fma(z, k(-0.00020168392802588642f), k(0.004467579070478678f));
+    p = __builtin_elementwise_fma(z, p, k(-0.04283246025443077f));
+    p = __builtin_elementwise_fma(z, p, k(-0.47278666496276855f));
+    p = __builtin_elementwise_fma(z, p, k(-1.1443983316421509f));
+    p = __builtin_elementwise_fma(z, p, k(-1.0005322694778442f));
+#endif
+    const f32x2_t e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+    f32x2_t m;                                                      // plain v_max: fmaxf() would add a canonicalising v_max per element
+    asm("v_max_f32 %0, 0, %1" : "=v"(m[0]) : "v"(x[0]));
+    asm("v_max_f32 %0, 0, %1" : "=v"(m[1]) : "v"(x[1]));
+    return __builtin_elementwise_fma(-z, e, m);
+}
+
 // Observed dispatcher policy: block b runs on XCD b % 8.  Remap so each XCD (own L2)
 // walks a contiguous range of tile ids.  Bijective for any grid size.  Speed only.
 __device__ __forceinline__ unsigned int xcd_remap(unsigned int bid, unsigned int nblk) {

@@ -25,6 +25,9 @@
 // M/N edges: loads clamp the row index (re-reading a valid row), stores are guarded; the
 // only shape requirement is K % 64 == 0.
 #include "gemm.h"
+#ifndef ESME_GELU_PACKED
+#define ESME_GELU_PACKED 1
+#endif
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -528,10 +531,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             const int q4 = (wn * WTN + i * 16 + 4 * lq) >> 2;          // float4 index inside the tile
             const f32x4 c1q = c1s[q4], c2q = c2s[q4];
 #pragma unroll
-            for (int j = 0; j < FM; ++j)
+            for (int j = 0; j < FM; ++j) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[i][j][e] = fmaf(st[j][0], acc[i][j][e], fmaf(-st[j][1], c1q[e], c2q[e]));
+            }
         }
     }
 
@@ -669,10 +673,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] + bv[e];
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (ROTD == 0 && !LNF) o[e] = acc[i][j][e] + bv[e];
+                        else o[e] = acc[i][j][e];                       // bias already inside (rotary section / folded LayerNorm's c2)
+                    }
                     if constexpr (EPI == ESME_EPI_GELU) {
+#if ESME_GELU_PACKED
+                        const f32x2_t g0 = gelu_erf2(f32x2_t{o[0], o[1]}), g1 = gelu_erf2(f32x2_t{o[2], o[3]});
+                        o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
+#else
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+#endif
                     }
                     if constexpr (EPI == ESME_EPI_RESIDUAL) {
                         const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));

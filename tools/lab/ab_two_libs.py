@@ -39,6 +39,12 @@ if os.environ.get('ATTN', '0') == '1':          # attention instead of the GEMMs
         q_ = torch.randn(sum(ln_), 3 * E, device=dev).bfloat16()
         cu_ = cu_.cuda()
         fns[f'attention S={S_}'] = (lambda q_=q_, cu_=cu_, ml_=ml_: _hip.attn_varlen(q_[:, :E], q_[:, E:2 * E], q_[:, 2 * E:], cu_, ml_, 20))
+if os.environ.get('ATTN', '0') != '1':             # do the two builds produce the same bits?
+    for k, (fn, outp) in {'qkv +rot+lnf': (fns['qkv +rot+lnf'], qkv), 'ffn1 gelu+lnf': (fns['ffn1 gelu+lnf'], u)}.items():
+        _hip._lib = libA; fn(); torch.cuda.synchronize(); ra = outp.clone()
+        _hip._lib = libB; fn(); torch.cuda.synchronize()
+        print(f'{k:18s} A and B bit-identical: {torch.equal(ra, outp)}')
+    _hip._lib = libA
 times = {(k, l): [] for k in fns for l in 'AB'}
 for r in range(int(os.environ.get('ROUNDS', 5))):
     for k, fn in fns.items():
