@@ -41,9 +41,10 @@
 
 namespace esme {
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
+    static_assert(!R32 || EPI == ESME_EPI_RESIDUAL, "the fp32 residual stream belongs to the residual epilogue");
     static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64 && (WN == 2 || WN == 4)), "row statistics are emitted by the residual epilogue");
     static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
                   "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     constexpr int RPI = 64 / CH;                                       // rows per store instruction
     // PERSIST: the epilogue runs in two passes of WTM / 2 rows through slabs in the stage buffer that held the LAST K-tile
     // (64 KB in all), so that the other stage buffer can already receive the next tile's first K-tile.
-    constexpr int NPASS = PERSIST ? 2 : 1;
+    constexpr int NPASS = (PERSIST || (R32 && BM == 256)) ? 2 : 1;      // (fp32 stream: a pass's quads live in registers -- 64 rows per pass)
     constexpr int RPP = WTM / NPASS;                                   // slab rows per pass
     constexpr int FMP = FM / NPASS;                                    // 16-row fragments per pass
     static_assert(!PERSIST || (FM % 2 == 0), "two-pass epilogue");
@@ -635,10 +636,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // address), then read back per accumulator quad -- instead of 8-B loads scattered over 32
         // rows per instruction (measured ~20 us per tile for the scattered form).
         f32x2* blkst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);      // STATS: [wn][tile row] partial sums
+        // fp32 residual stream (high-precision mode): x32 += alpha * (acc + bias) in place, C = bf16(x32).  A lane owns the 16-B
+        // quad (row j*16 + l15, columns i*16 + 4 lq ..) of every fragment, so the stream is read and written straight from the
+        // accumulator layout (16 rows x 64 B per instruction); all quads of a pass are in flight together, and the next
+        // pass's are issued as soon as this pass's accumulators are packed.
+        f32x4 xr[R32 ? FNE : 1][R32 ? FMP : 1];
+        auto load_x32 = [&](const int pass) {
+            if constexpr (R32) {
+#pragma unroll
+                for (int i = 0; i < FNE; ++i) {
+                    int n = nw0 + i * 16 + 4 * lq;
+                    n = n < a.N - 4 ? n : a.N - 4;
+#pragma unroll
+                    for (int jj = 0; jj < FMP; ++jj) {
+                        int64_t m = mw0 + pass * RPP + jj * 16 + l15;
+                        m = m < a.M ? m : a.M - 1;
+                        xr[i][jj] = *reinterpret_cast<const f32x4*>(a.resid32 + m * a.ld32 + n);
+                    }
+                }
+            }
+        };
+        load_x32(0);
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
         if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slab
-        if constexpr (EPI == ESME_EPI_RESIDUAL) {
+        if constexpr (EPI == ESME_EPI_RESIDUAL && !R32) {
 #pragma unroll
             for (int it = 0; it < RPP / 8; ++it) {
                 const int r = it * 8 + (lane >> 3);
@@ -686,7 +708,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
 #endif
                     }
-                    if constexpr (EPI == ESME_EPI_RESIDUAL) {
+                    if constexpr (R32) {
+                        const int n = nw0 + cl;
+                        const int64_t m = mw0 + pass * RPP + r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaf(a.alpha, o[e], xr[i][jj][e]);
+                        if (m < a.M && n < a.N) *reinterpret_cast<f32x4*>(a.resid32 + m * a.ld32 + n) = f32x4{o[0], o[1], o[2], o[3]};
+                    } else if constexpr (EPI == ESME_EPI_RESIDUAL) {
                         const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));
                         o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
                         o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
@@ -695,8 +723,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
                 *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = pk;
             }
-            if constexpr (EPI == ESME_EPI_RESIDUAL) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later fragments from being hoisted (VGPRs)
+            if constexpr (EPI == ESME_EPI_RESIDUAL && !R32) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later fragments from being hoisted (VGPRs)
         }
+        if (pass + 1 < NPASS) load_x32(pass + 1);
         __builtin_amdgcn_wave_barrier();
         ESME_TRACE_MARK(5);
         // ---- PERSIST, after the first pass is packed (half of the accumulators are dead: the registers the address
@@ -794,7 +823,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         if (n + e < a.N) {
                             float v = acc[i][j][e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
                             if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
-                            if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
+                            if constexpr (R32) { float* xp = a.resid32 + m * a.ld32 + n + e; v = fmaf(a.alpha, v, *xp); *xp = v; }
+                            else if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
                             a.C[m * a.ldc + n + e] = f2bf(v);
                         }
                     }
@@ -853,7 +883,7 @@ static void set_raster(GemmArgs& a) {
     if (a.gn < 1) a.gn = 1;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false>
 static int launch_one(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
@@ -864,10 +894,11 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
         const bool want = a.opt_persist < 0 ? persist_default() != 0 : a.opt_persist != 0;
-        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true>(a, s);
+        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32>(a, s);
+
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32>;
     if (smem >= 64 * 1024) {
         // the attribute is per (kernel, device): one bit per device ordinal, set once, safe from any host thread
         static std::atomic<unsigned long long> done{0ull};
@@ -899,7 +930,10 @@ static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hip
             }
         case ESME_EPI_GELU: return lnf ? ESME_L(ESME_EPI_GELU, 0, true, false) : ESME_L(ESME_EPI_GELU, 0, false, false);
         case ESME_EPI_SWIGLU: return lnf ? ESME_L(ESME_EPI_SWIGLU, 0, true, false) : ESME_L(ESME_EPI_SWIGLU, 0, false, false);
-        case ESME_EPI_RESIDUAL: return stats ? ESME_L(ESME_EPI_RESIDUAL, 0, false, true) : ESME_L(ESME_EPI_RESIDUAL, 0, false, false);
+        case ESME_EPI_RESIDUAL:
+            if (a.resid32) return stats ? launch_one<BM, BN, WM, WN, ESME_EPI_RESIDUAL, 0, false, true, false, true>(a, s)
+                                        : launch_one<BM, BN, WM, WN, ESME_EPI_RESIDUAL, 0, false, false, false, true>(a, s);
+            return stats ? ESME_L(ESME_EPI_RESIDUAL, 0, false, true) : ESME_L(ESME_EPI_RESIDUAL, 0, false, false);
         default: return fail(ESME_ERR_ARG, "gemm: unknown epilogue");
     }
 #undef ESME_L
@@ -963,7 +997,12 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     // The coalesced epilogue stores 16 B per lane: it needs ldc % 8 == 0, a 16-B aligned C and
     // N % 8 == 0; otherwise (e.g. the (T, 33) vocab projection) it falls back to 2-byte accesses.
     int vec_ok = (ldc % 8 == 0) && aligned16(C) && (n_out % 8 == 0) && N >= 8;
-    if (epilogue == ESME_EPI_RESIDUAL) {
+    const bool r32 = fu && fu->resid32;
+    if (r32) {
+        ESME_CHECK_ARG(epilogue == ESME_EPI_RESIDUAL, "gemm: resid32 belongs to the residual epilogue");
+        ESME_CHECK_ARG(fu->ld32 >= N && fu->ld32 % 4 == 0 && aligned16(fu->resid32), "gemm: resid32 needs ld32 >= N, ld32 % 4 == 0, 16-byte alignment");
+        if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: the fp32 residual stream needs a 16-byte addressable C and N % 8 == 0");
+    } else if (epilogue == ESME_EPI_RESIDUAL) {
         ESME_CHECK_ARG(resid && ldr >= N, "gemm: residual epilogue needs resid with ldr >= N");
         vec_ok = vec_ok && (ldr % 8 == 0) && aligned16(resid) && N >= 8;
     }
@@ -976,6 +1015,7 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     if (opts) { a.opt_gm = opts->raster_gm; a.opt_gn = opts->raster_gn; a.opt_persist = opts->persist; }
     int rotd = 0;
     bool lnf = false, stats = false;
+    if (r32) { a.resid32 = fu->resid32; a.ld32 = fu->ld32; }
     if (fu) {
         if (fu->head_dim != 0) {                                     // fused rotary
             ESME_CHECK_ARG(epilogue == ESME_EPI_NONE, "gemm: fused rotary needs ESME_EPI_NONE");

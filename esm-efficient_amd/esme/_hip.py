@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -26,7 +26,7 @@ class GemmFusion(Structure):
     """esme_gemm_fusion_t (include/esme_hip.h)."""
     _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
-                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int)]
+                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64)]
 
 
 class GemmOpts(Structure):
@@ -527,11 +527,13 @@ def stats_blocks(M: int, N: int) -> int:
 
 def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-               ln=None, stats_out: Optional[torch.Tensor] = None, rot=None) -> torch.Tensor:
+               ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
-    epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue)."""
+    epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue); `resid32` (M, N) f32 is the
+    high-precision residual stream: updated in place from the fp32 accumulators, `out` gets its bf16 rounding
+    (residual epilogue; `resid` is then ignored)."""
     ap, lda = _rows2d(a, 'gemm a')
     if not w.is_contiguous():
         raise ValueError('gemm: weight must be contiguous (N, K)')
@@ -544,9 +546,13 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
     cp, ldc = _rows2d(out, 'gemm out')
     rp, ldr = (None, 0)
-    if epilogue == EPI_RESIDUAL:
-        rp, ldr = _rows2d(resid, 'gemm resid')
     fu = GemmFusion()
+    if resid32 is not None:
+        if epilogue != EPI_RESIDUAL or resid32.shape != (M, N) or resid32.stride(1) != 1:
+            raise ValueError('gemm: resid32 must be an (M, N) float32 tensor with unit column stride (residual epilogue)')
+        fu.resid32, fu.ld32 = _dev(resid32, 'gemm resid32', torch.float32), resid32.stride(0)
+    elif epilogue == EPI_RESIDUAL:
+        rp, ldr = _rows2d(resid, 'gemm resid')
     tag = epilogue
     if ln is not None:
         part, dim, eps, c1, c2 = ln
@@ -564,6 +570,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
         tag = 'qkv_rotary'
     go = _TLS.gemm_opts
+    if resid32 is not None:
+        tag = 'residual_f32'
     with _Traced('gemm', (M, N, K, tag)):
         if go is not None:
             _check(load().esme_hip_gemm_bf16_opts(ap, lda, _dev(w, 'gemm w', torch.bfloat16),

@@ -249,11 +249,12 @@ class FlashMultiheadAttention(nn.Module):
                                 softmax_scale=self.head_dim ** -0.5, exact=exact, order=order)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
-                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None):
+                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
         resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid).
         `x_stats` ((nblk, T, 2) f32 partial row sums of x) selects the LN-folded projection;
-        `stats_out` makes the out-projection emit the statistics of its output."""
+        `stats_out` makes the out-projection emit the statistics of its output.  `resid32` (high-precision mode): the fp32
+        residual stream, updated in place by the out-projection's epilogue; `out` receives its bf16 rounding."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
         T = x.shape[0]
         E = self.attn_dim                                   # width of each of q, k, v (H * padded head dim)
@@ -286,8 +287,8 @@ class FlashMultiheadAttention(nn.Module):
         a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn),
                        order=ctx.order if ctx is not None else None)
         wo, bo = self._weights_out()
-        if resid is not None:
-            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
+        if resid is not None or resid32 is not None:
+            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)
         return _hip.gemm(a, wo, bo, out=out)
 
 
@@ -409,7 +410,7 @@ class FlashTransformerLayer(nn.Module):
             return self._down_pad
         return down.weight, down.bias
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None):
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_up(True)
@@ -418,22 +419,23 @@ class FlashTransformerLayer(nn.Module):
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
         wd, bd = self._weights_down()
-        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out)
+        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)
 
     def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext):
         """One layer with the residual stream in fp32 (`ctx.x32`, updated in place).  `x16` = bf16(stream) is the MFMA
-        operand of the LayerNorm-folded GEMMs (statistics `ctx.sums` come from the fp32 values); the branch outputs leave
-        their GEMMs in bf16 and are accumulated into the stream by esme_hip_residual_f32.  Returns nothing: x16 / ctx.sums
-        are refreshed in place."""
+        operand of the LayerNorm-folded GEMMs.  The two residual GEMMs add their fp32 accumulators straight into the stream
+        (`esme_gemm_fusion_t.resid32`: the branch output is never rounded to bf16 on the way), write the stream's bf16
+        rounding back to x16 and emit its row statistics for the next folded LayerNorm -- the same four GEMM launches per
+        layer as the fast mode, no extra pass.  Returns nothing: x16 / ctx.sums are refreshed in place."""
         alpha = 1.0 / self.residue_scaling
-        o = self.self_attn(x16, cu_lens, max_len, None, ctx, x_stats=ctx.sums)          # plain epilogue, bf16
-        _hip.residual_f32_(ctx.x32, o, alpha, x16, ctx.sums)
-        epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
-        wf, _, c1, c2 = self._weights_up(True)
-        u = _hip.gemm_fused(x16, wf, None, epi, ln=(ctx.sums, self.embed_dim, self.final[0].eps, c1, c2))
-        wd, bd = self._weights_down()
-        y = _hip.gemm(u, wd, bd)
-        _hip.residual_f32_(ctx.x32, y, alpha, x16, ctx.sums)
+        T, E = x16.shape
+        if ctx.part_a is None:
+            ctx.part_a = torch.empty(_hip.stats_blocks(T, E), T, 2, dtype=torch.float32, device=x16.device)
+            ctx.part_b = torch.empty_like(ctx.part_a)
+        self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
+                       resid32=ctx.x32)
+        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=ctx.x32)
+        ctx.sums = ctx.part_a
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 inplace: bool = False):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 3
+#define ESME_HIP_ABI_VERSION 4
 
 enum {
     ESME_OK = 0,
@@ -197,7 +197,12 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              64-column wave partials combine as ((w0 + w1) + (w2 + w3)) inside a 256-column block, blocks add
  *              left to right, and a consumer that is handed 128-column partials pairs them up first -- so a row's
  *              statistics do not depend on the tile configuration a launch picks, i.e. on the number of rows in
- *              the batch: a sequence's logits are bit-identical alone or packed. */
+ *              the batch: a sequence's logits are bit-identical alone or packed.
+ *  - resid32 != NULL (ESME_EPI_RESIDUAL only; the high-precision mode): the residual stream is the fp32 tensor resid32
+ *              (M, N) with row stride ld32, updated IN PLACE from the fp32 accumulators,
+ *              resid32[m,n] += alpha * (acc[m,n] + bias[n]), and C receives its bf16 rounding (the next GEMM's operand);
+ *              `resid` is ignored.  Replaces the same adds (esme/attention.py:253-255) with the stream kept in fp32:
+ *              the branch output is never rounded to bf16 on its way into the stream. */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;
@@ -212,6 +217,8 @@ typedef struct esme_gemm_fusion {
     int head_dim;
     int max_len;
     int rot_cols;
+    float* resid32;              /* see above: fp32 residual stream, updated in place (ESME_EPI_RESIDUAL only); NULL = bf16 `resid` */
+    int64_t ld32;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */

@@ -166,4 +166,4 @@ def test_high_precision_mode_full_depth():
           f'{float((high - ref32).abs().max()):.3e}')
     assert torch.isfinite(high).all()
     assert e_high <= 0.6 * e_fast, (e_high, e_fast)          # measured 0.45x at this depth
-    assert e_high <= 7.5e-3, e_high                           # measured 5.5-6e-3: bf16 MFMA operands, not the stream, bound it
+    assert e_high <= 7.5e-3, e_high                           # measured 5.4e-3 (5.5-6e-3 with the separate fp32 pass of rounds 1-2): bf16 MFMA operands, not the stream, bound it

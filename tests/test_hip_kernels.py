@@ -564,6 +564,44 @@ def test_gemm_persistent_workgroups_equal_per_tile(K, epi):
         check(outs[1][0][-300:], ref, what='persistent gemm')
 
 
+@pytest.mark.parametrize('M,N,K', [(300, 640, 192), (4100, 1280, 320), (27001, 1280, 256)])
+@pytest.mark.parametrize('stats', [False, True])
+def test_gemm_fp32_residual_stream(M, N, K, stats):
+    """esme_gemm_fusion_t.resid32 (high-precision mode): x32 += alpha * (A W^T + b) in place from the fp32 accumulators,
+    C = bf16(x32), statistics of the rounded C; every tile configuration / persistent form writes the same bits."""
+    from esme import _hip
+    x = rnd((M, K), 71).to(dev())
+    w = rnd((N, K), 72, 1 / math.sqrt(K)).to(dev())
+    b = rnd((N,), 73, 0.1).to(dev())
+    x32_0 = (rnd((M, N), 74).float() * 3.0 + 1e-3 * rnd((M, N), 75).float()).to(dev())      # not bf16-representable
+    ref32 = x32_0.cpu() + 0.5 * (x.cpu().float() @ w.cpu().float().T + b.cpu().float())
+    outs = []
+    configs = [(1, -1), (2, 0), (2, 1)] if M * N >= 160 * 65536 else [(1, -1), (2, 0)]
+    for tile, persist in configs:
+        with _hip.gemm_options(tile=tile, persist=persist):
+            x32 = x32_0.clone()
+            part = torch.zeros(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=dev()) if stats else None
+            y = _hip.gemm_fused(x, w, b, _hip.EPI_RESIDUAL, None, 0.5, stats_out=part, resid32=x32)
+            torch.cuda.synchronize()
+            outs.append((x32, y, part))
+    x32, y, part = outs[0]
+    err = (x32.cpu() - ref32).abs()
+    assert float(err.max()) <= 2e-5 * float(ref32.abs().max()) + 1e-5, float(err.max())      # fp32 sums in another order
+    assert torch.equal(y, x32.to(torch.bfloat16)), 'C must be the bf16 rounding of the updated stream'
+    if stats:
+        yf = y.float()
+        s = part.sum(0).cpu()
+        assert torch.allclose(s[:, 0], yf.sum(1).cpu(), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(s[:, 1], (yf * yf).sum(1).cpu(), rtol=1e-4, atol=1e-2)
+    for x32b, yb, partb in outs[1:]:
+        assert torch.equal(x32b, x32) and torch.equal(yb, y)
+        if stats:
+            if partb.shape == part.shape:
+                assert torch.equal(partb, part)
+            else:                                    # 128- vs 256-column partials: the same sums, split differently
+                assert torch.allclose(partb.sum(0), part.sum(0), rtol=1e-5, atol=1e-3)
+
+
 def test_two_host_threads_two_streams_different_options():
     """SURVEY 8b 'Threading / streams': the library holds no mutable global state and per-call options are per call.  Two host
     threads drive GEMMs and attention on two streams at the same time, each with ITS OWN kernel options (128- vs 256-tiles,
