@@ -6,6 +6,7 @@ exec < /dev/null            # nothing here reads stdin: a stray read must fail, 
 cd /root/repo
 O=gpurun_out/r03
 mkdir -p $O
+make -C esm-efficient_amd/csrc TRACE=1 > $O/make_trace.log 2>&1      # the instrumented library must match the sources (it is not built by __graft_entry__.build())
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 python bench.py --gpus 1 --spawn --no-cpu-baseline > $O/bench_spawn.json 2>/dev/null
 timeout 900 python bench.py --batch proteome --no-cpu-baseline > $O/bench_proteome.json 2>/dev/null
