@@ -31,6 +31,47 @@ def test_header_symbols_exported_and_bound():
     assert int(m.group(1)) == _hip.ABI_VERSION
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The Python binding restates five structs of include/esme_hip.h by hand; a field added on one side only would shift every
+    later field silently.  gcc prints sizeof / offsetof of every field from the header itself; the ctypes mirrors must agree."""
+    import shutil
+    import subprocess
+    from esme import _hip
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc in this environment')
+    structs = {'esme_gemm_fusion_t': _hip.GemmFusion, 'esme_gemm_opts_t': _hip.GemmOpts, 'esme_attn_opts_t': _hip.AttnOpts,
+               'esme_layer_weights_t': _hip.LayerWeights, 'esme_model_desc_t': _hip.ModelDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "esme_hip.h")}"', 'int main(void) {']
+    for cname, py in structs.items():
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in py._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run([gcc, '-std=c99', '-o', str(exe), str(src)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, field, value = line.split()
+        py = structs[cname]
+        expect = ctypes.sizeof(py) if field == 'sizeof' else getattr(py, field).offset
+        assert int(value) == expect, f'{cname}.{field}: header {value}, ctypes {expect}'
+        seen += 1
+    assert seen == sum(len(py._fields_) + 1 for py in structs.values())
+    # and the header has no field the mirrors lack (same field count per struct)
+    header = open(os.path.join(ROOT, 'include', 'esme_hip.h')).read()
+    for cname, py in structs.items():
+        end = header.index('} ' + cname + ';')
+        start = header.rfind('typedef struct', 0, end)
+        body = header[header.index('{', start) + 1:end]
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        n = sum(len(decl.split(',')) for decl in body.split(';') if decl.strip())
+        assert n == len(py._fields_), f'{cname}: {n} fields in the header, {len(py._fields_)} in the ctypes mirror'
+
+
 def test_argument_validation_without_gpu():
     """Host-side checks of the C entry points reject bad arguments before any launch."""
     from esme import _hip
