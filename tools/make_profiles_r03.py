@@ -73,7 +73,23 @@ def main():
                        'kernel': key[0] + ' M=50000 N=5120 K=1280', 'fetch_size_kib_raw': fk, 'write_size_kib': wk,
                        'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': 653107200}, open(os.path.join(P, 'r03_traffic.json'), 'w'), indent=1)
             print('traffic', traffic)
-    pmc(['pmc_sq', 'pmc_sq2'], 'r03_pmc_counters.md', 'SQ / LDS / MFMA / L2 counters per kernel (round 3)')
+    sq = pmc(['pmc_sq', 'pmc_sq2'], 'r03_pmc_counters.md', 'SQ / LDS / MFMA / L2 counters per kernel (round 3)')
+    # derived ratios (1 024 SIMDs, 8 XCDs: GRBM_GUI_ACTIVE is summed over the XCDs)
+    mean = lambda v: sum(v) / len(v)
+    lines = ['', '## Derived (mean per dispatch)', '',
+             '| kernel | launch cycles (GRBM_GUI_ACTIVE / 8) | matrix pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / 1 024 / launch cycles) | SQ_WAIT_ANY / SQ_WAVE_CYCLES | '
+             'LDS bank-conflict cycles / LDS cycles | L2 hit rate |', '|---|---:|---:|---:|---:|---:|']
+    for k, cs in sorted(sq.items(), key=lambda kv: -sum(kv[1].get('GRBM_GUI_ACTIVE', [0]))):
+        need = ('GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAVE_CYCLES', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'TCC_HIT_sum', 'TCC_MISS_sum')
+        if not k.startswith(('gemm', 'attn')) or any(c not in cs for c in need):
+            continue
+        cyc = mean(cs['GRBM_GUI_ACTIVE']) / 8
+        lds = mean(cs['SQ_LDS_IDX_ACTIVE'])
+        lines.append(f"| `{k}` | {cyc:,.0f} | {100 * mean(cs['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024 / cyc:.1f} % | "
+                     f"{100 * mean(cs['SQ_WAIT_ANY']) / mean(cs['SQ_WAVE_CYCLES']):.1f} % | "
+                     f"{100 * mean(cs['SQ_LDS_BANK_CONFLICT']) / lds if lds else 0:.1f} % | "
+                     f"{100 * mean(cs['TCC_HIT_sum']) / (mean(cs['TCC_HIT_sum']) + mean(cs['TCC_MISS_sum'])):.1f} % |")
+    open(os.path.join(P, 'r03_pmc_counters.md'), 'a').write('\n'.join(lines) + '\n')
     rows = [('ESM2-650M, 50 000 residues, 100 x 500 (headline, configs[2])', 'bench.json'),
             ('same, self-launched through torch.distributed.run (--gpus 1 --spawn, RCCL world 1)', 'bench_spawn.json'),
             ('ESM2-650M, 50 000 residues, proteome-like lengths', 'bench_proteome.json'),
