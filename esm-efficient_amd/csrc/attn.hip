@@ -372,7 +372,13 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
 // overlaps the other's main loop), NW = 8 stays behind the tuning hook.  The row sum exchange with lane^32
 // is a v_permlane32_swap (VALU), not an LDS permute; results leave through a wave-private LDS slab as
 // whole 128-byte rows (16 B per lane).
-template <int NW>
+// QP ("q prescaled"): q arrives multiplied by softmax_scale * log2(e) (the QKV projection's epilogue does it in fp32 before its
+// one bf16 rounding: esme_gemm_fusion_t.q_scale), so a score IS its exponent: the speculative pass computes P = exp2(s) straight
+// from the accumulators -- no reference maximum at all, not even on the first tile, and 5 instead of 7 VALU instructions per
+// score pair in a loop that is bound by the VALU port (-5 % at S = 500, -8 % at S = 1 002).  fp32 / bf16 hold P from 2^-126 to
+// 2^127; a row sum that overflows (>= 1e30) or vanishes (<= 1e-30) flags the work item, which is redone with the classic online
+// softmax (the row maximum subtracted before the pipelined region), exactly as for the speculative pass of the plain form.
+template <int NW, bool QP = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
     constexpr int D = 64, DS = 4, NT = NW * 64;
     constexpr int K_BYTES = KT * D * 2;          // 8 KB
@@ -548,14 +554,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             if (p & 1) { ps2 += q0; ps3 += q1; } else { ps0 += q0; ps1 += q1; }
         };
         auto softmax_slot = [&](const int m, const float nm) {      // m = 0..15
-            const float x0 = xa0, x1 = xa1;                  // x of pair m (from slot m - 1)
             const float q0 = pa0, q1 = pa1;                  // P of pair m - 1
-            if (m + 1 < 16) pair_fma(m + 1, nm);
-            pa0 = __builtin_amdgcn_exp2f(x0);
-            pa1 = __builtin_amdgcn_exp2f(x1);
-            if (m >= 1) pair_sum_pack(m - 1, q0, q1);
-            const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
-            asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(xa0), "+v"(xa1), "+v"(pa0), "+v"(pa1));
+            if constexpr (QP) {                              // the scores are the exponents (the exact pass has subtracted the maximum already)
+                const int kb2 = m >> 3, r2 = (2 * m) & 15;
+                pa0 = __builtin_amdgcn_exp2f(sacc[bs][kb2][r2]);
+                pa1 = __builtin_amdgcn_exp2f(sacc[bs][kb2][r2 + 1]);
+                if (m >= 1) pair_sum_pack(m - 1, q0, q1);
+                const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
+                asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(pa0), "+v"(pa1));
+            } else {
+                const float x0 = xa0, x1 = xa1;              // x of pair m (from slot m - 1)
+                if (m + 1 < 16) pair_fma(m + 1, nm);
+                pa0 = __builtin_amdgcn_exp2f(x0);
+                pa1 = __builtin_amdgcn_exp2f(x1);
+                if (m >= 1) pair_sum_pack(m - 1, q0, q1);
+                const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
+                asm volatile("" : "+v"(pw[bs][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(xa0), "+v"(xa1), "+v"(pa0), "+v"(pa1));
+            }
         };
         // exact tile maximum of block bs's rows (both key halves), in log2 units
         auto tile_max = [&]() -> float {
@@ -595,11 +610,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             asm volatile("" ::: "memory");                   // keep it a branch (no if-conversion into the hot path)
             const float tmc = tile_max();
             if (__any(tmc > mc[bs] + thr)) rescale_to(tmc);  // thr = 0: the maximum is always exact
+            if constexpr (QP) {                              // (exact pass only: c = 1, the pipelined slots take exp2 of the accumulators as they are)
+                const float mref = mc[bs];
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[bs][kbk][r] -= mref;
+            }
         }
         // 16 x { 1 MFMA (+ the LDS read of the fragment two MFMAs ahead), 7 VALU of three different score pairs }
         ps0 = ps1 = ps2 = ps3 = 0.f;
         const float nm = -mc[bs];
-        pair_fma(0, nm);
+        if constexpr (!QP) pair_fma(0, nm);
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             mfma_step(m);
@@ -626,7 +648,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         // it by P = 0: no NaN / Inf patterns)
     #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-            mc[bb] = -1e30f; lrun[bb] = 0.f;
+            mc[bb] = -1e30f; lrun[bb] = (QP && !wave_active) ? 1.f : 0.f;      // (QP: an idle wave must not trip the vanished-sum check)
     #pragma unroll
             for (int i = 0; i < 2; ++i) {
     #pragma unroll
@@ -684,7 +706,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 const char* prv = smem + ((t + 3) & 3) * SLOT;
                 const char* nxt = smem + ((t + 1) & 3) * SLOT;
                 const bool tail = t == nt - 1 && ragged;
-                const bool need_max = exact || t == 0;
+                const bool need_max = exact || (!QP && t == 0);
                 phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT, [&](const int m) {
                     if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_k) dma_piece(0, t + 3, kslot, 0); if (m == ESME_ATTN_DMA1 && pf_k) dma_piece(0, t + 3, kslot, KI - 1); }
                     else if (m == 7 && pf_k) dma_piece(0, t + 3, kslot, 0);
@@ -716,6 +738,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                     oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks >> 1][ks & 1]),
                                                                           oacc[1][db], 0, 0, 0);
                 }
+        }
+        if constexpr (QP) {
+            // no reference maximum: a row whose every score sits below ~-100 (log2 units) has lost its sum -- redo it exactly.
+            // (Per-lane partial sums: a lane whose half of the keys is entirely masked -- sequences of <= 8 residues -- also trips it.)
+            if (!exact && (__any(!(lrun[0] > 1e-30f)) || __any(!(lrun[1] > 1e-30f)))) ovf = 1;      // (idle waves carry lrun = 1)
         }
         if (exact || !__syncthreads_or(ovf)) break;
         exact = true;
@@ -754,10 +781,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 
 using namespace esme;
 
-template <int NW>
+template <int NW, bool QP = false>
 static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     constexpr int smem = 4 * (KT * 64 * 2 + 64 * 128);
-    auto kern = attn_pp64_kernel<NW>;
+    auto kern = attn_pp64_kernel<NW, QP>;
     static std::atomic<unsigned long long> done{0ull};         // dynamic-LDS attribute: per (kernel, device)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -791,8 +818,11 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0,
                    "attn: misaligned");
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
+    // q_prescaled: q already carries softmax_scale * log2(e) (esme_gemm_fusion_t.q_scale): every kernel then runs with c = 1, and
+    // the 4-wave head-dim-64 kernel in its no-reference-maximum form
+    const bool qp = opts && opts->q_prescaled;
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
-               softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec,
+               qp ? 1.0f : softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec,
                opts ? opts->seq_order : nullptr};
     const hipStream_t s = (hipStream_t)stream;
     // (the ping-pong kernel addresses K / V with 32-bit byte offsets inside one sequence: (max_len + one tile) rows must fit)
@@ -802,6 +832,7 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
         // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
         const int nw = g_attn_variant == 8 ? 8 : 4;
+        if (qp && nw == 4) return launch_pp64<4, true>(a, B, max_len, s);
         return nw == 8 ? launch_pp64<8>(a, B, max_len, s) : launch_pp64<4>(a, B, max_len, s);
     }
     // two 32-row q-blocks per wave when the longest sequence fills at least one 256-row tile

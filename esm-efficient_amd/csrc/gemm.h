@@ -34,6 +34,7 @@ struct GemmArgs {
                                  // a launch may cover a row range of it (tail split, see esme_hip_gemm_bf16_fused)
     unsigned long long* trace = nullptr;      // ESME_GEMM_TRACE builds only: per-block phase timestamps (16 per block)
     int opt_gm = 0, opt_gn = 0, opt_persist = -1;   // host side: per-call options (esme_gemm_opts_t); 0 / -1 = heuristic
+    float q_scale = 0.f; int q_cols = 0;            // fused rotary: columns < q_cols leave multiplied by q_scale (softmax scale folded into q)
     float* resid32 = nullptr; int64_t ld32 = 0;     // residual epilogue on an fp32 stream (in place): x32 += alpha * (acc + bias), C = bf16(x32)
 };
 

@@ -605,6 +605,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
         }
+        // q columns leave pre-multiplied by softmax_scale * log2(e) (fp32, before the one bf16 rounding): the attention kernel then
+        // takes exp2 of its scores as they are (esme_attn_opts_t.q_prescaled).  Wave-uniform: q_cols is a multiple of 64.
+        if (a.q_scale != 0.f && nw0 < a.q_cols) {
+            const float qs = a.q_scale;
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] *= qs;
+        }
         // the result slabs overlay the table region: every wave must be done reading tables before any slab write
         if (!PERSIST && n0 < a.rot_cols) __syncthreads();
     }
@@ -1028,6 +1039,10 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
             a.cosT = (const u16*)fu->cos; a.sinT = (const u16*)fu->sin; a.pos = fu->pos;
             a.max_len = fu->max_len; a.rot_cols = fu->rot_cols;
             rotd = fu->head_dim;
+            if (fu->q_scale != 0.f) {
+                ESME_CHECK_ARG(fu->q_cols > 0 && fu->q_cols % 64 == 0 && fu->q_cols <= fu->rot_cols, "gemm: q_scale needs q_cols, a multiple of 64 within rot_cols");
+                a.q_scale = fu->q_scale; a.q_cols = fu->q_cols;
+            }
         }
         if (fu->ln_partial) {                                        // LayerNorm folded into this GEMM
             ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL, "gemm: LN fold does not combine with the residual epilogue");

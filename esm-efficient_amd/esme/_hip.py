@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -26,7 +26,7 @@ class GemmFusion(Structure):
     """esme_gemm_fusion_t (include/esme_hip.h)."""
     _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
-                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64)]
+                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int)]
 
 
 class GemmOpts(Structure):
@@ -37,7 +37,7 @@ class GemmOpts(Structure):
 class AttnOpts(Structure):
     """esme_attn_opts_t (include/esme_hip.h)."""
     _fields_ = [('struct_bytes', c_int), ('variant', c_int), ('q_blocks', c_int), ('defer_max_thr', c_float), ('speculative', c_int),
-                ('seq_order', c_void_p)]
+                ('seq_order', c_void_p), ('q_prescaled', c_int)]
 
 
 class LayerWeights(Structure):
@@ -217,7 +217,7 @@ def set_attn_options(**kw) -> None:
     if not kw:
         _TLS.attn_opts = None
         return
-    o = _TLS.attn_opts or AttnOpts(ctypes.sizeof(AttnOpts), 0, 0, 8.0, 1, None)
+    o = _TLS.attn_opts or AttnOpts(ctypes.sizeof(AttnOpts), 0, 0, 8.0, 1, None, 0)
     if 'variant' in kw: o.variant = int(kw['variant'])
     if 'q_blocks' in kw: o.q_blocks = int(kw['q_blocks'])
     if 'thr' in kw: o.defer_max_thr = float(kw['thr'])
@@ -231,7 +231,7 @@ class attn_options:
     speculative softmax)."""
 
     def __init__(self, variant: int = 0, q_blocks: int = 0, thr: float = 8.0, spec: int = 1):
-        self.opts = AttnOpts(ctypes.sizeof(AttnOpts), int(variant), int(q_blocks), float(thr), int(spec), None)
+        self.opts = AttnOpts(ctypes.sizeof(AttnOpts), int(variant), int(q_blocks), float(thr), int(spec), None, 0)
 
     def __enter__(self):
         self.prev, _TLS.attn_opts = _TLS.attn_opts, self.opts
@@ -406,10 +406,12 @@ def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torc
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torch.Tensor, max_len: int,
                 heads: int, softmax_scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
-                exact: bool = False, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                exact: bool = False, order: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
     """q, k, v: (T, H*d) views sharing one row stride; returns (T, H*d).  `exact=True`: classic online softmax
     with every row maximum exact (esme_hip_attn_varlen_fwd_exact; the high-precision mode).  `order` (seq_order(cu_lens)):
-    dispatch the longest sequences' work first -- speed only, the result is the same bit for bit."""
+    dispatch the longest sequences' work first -- speed only, the result is the same bit for bit.  `q_prescaled`: q already
+    carries softmax_scale * log2(e) (gemm_fused(..., q_scale=)); `softmax_scale` is ignored and the head-dim-64 kernel runs its
+    no-reference-maximum form."""
     qp, ld = _rows2d(q, 'attn q')
     kp, ld2 = _rows2d(k, 'attn k')
     vp, ld3 = _rows2d(v, 'attn v')
@@ -423,10 +425,13 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
     ao = _TLS.attn_opts
-    if order is not None and not exact:
+    if q_prescaled and exact:
+        raise ValueError('attn: q_prescaled is not available through the exact entry (pass the unscaled q)')
+    if (order is not None or q_prescaled) and not exact:
         base = ao
         ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0,
-                      base.defer_max_thr if base else 8.0, base.speculative if base else 1, _dev(order, 'seq order', torch.int32))
+                      base.defer_max_thr if base else 8.0, base.speculative if base else 1,
+                      _dev(order, 'seq order', torch.int32) if order is not None else None, 1 if q_prescaled else 0)
     with _Traced('attn', (T, heads, d)):
         if ao is not None and not exact:
             _check(load().esme_hip_attn_varlen_fwd_opts(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32), cu.numel() - 1, T,
@@ -527,13 +532,15 @@ def stats_blocks(M: int, N: int) -> int:
 
 def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
-               ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None) -> torch.Tensor:
+               ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None,
+               q_scale: float = 0.0) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
     epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue); `resid32` (M, N) f32 is the
     high-precision residual stream: updated in place from the fp32 accumulators, `out` gets its bf16 rounding
-    (residual epilogue; `resid` is then ignored)."""
+    (residual epilogue; `resid` is then ignored); `q_scale` (with `rot`): the first rot_cols / 2 output columns (q) leave
+    multiplied by it -- softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True)."""
     ap, lda = _rows2d(a, 'gemm a')
     if not w.is_contiguous():
         raise ValueError('gemm: weight must be contiguous (N, K)')
@@ -568,6 +575,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         cos, sin, pos, head_dim, rot_cols = rot
         fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16), _dev(pos, 'pos', torch.int32)
         fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
+        if q_scale:
+            fu.q_scale, fu.q_cols = float(q_scale), int(rot_cols) // 2
         tag = 'qkv_rotary'
     go = _TLS.gemm_opts
     if resid32 is not None:

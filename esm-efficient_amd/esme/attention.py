@@ -24,6 +24,7 @@ unfused kernels (LN kernel, plain GEMM, rotary kernel) and are what the stage-ta
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -32,6 +33,16 @@ from torch import nn
 from esme import _hip
 from esme.nn import GELU, LayerNorm, Linear
 from esme.rotary import RotaryEmbedding
+
+# head dim 64 with fused rotary: softmax_scale * log2(e) folded into q by the QKV epilogue, attention without a reference maximum
+# (ESME_ATTN_QP=0: the plain form; the C entry esme_hip_forward reads the same variable)
+_ATTN_QP = os.environ.get('ESME_ATTN_QP', '1') != '0'
+
+
+def _q_scale(head_dim: int) -> float:
+    """softmax_scale * log2(e) in float32 arithmetic, exactly as esme_hip_forward forms it (the two paths must agree to the bit)."""
+    import numpy as np
+    return float(np.float32(head_dim ** -0.5) * np.float32(1.4426950408889634))
 
 
 class ForwardContext:
@@ -237,7 +248,7 @@ class FlashMultiheadAttention(nn.Module):
         H, d = self.num_heads, self.head_pad
         return tuple(qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
 
-    def _attn(self, q, k, v, cu_lens, max_len, exact=False, order=None):
+    def _attn(self, q, k, v, cu_lens, max_len, exact=False, order=None, q_prescaled=False):
         """(T, H, d) x 3 -> (T, E), the reference's `_attn` (esme/attention.py:112-124).  The kernel reads q, k, v with ONE
         row stride (the layer hands it column blocks of the fused (T, 3E) projection); a caller that passes separately
         allocated tensors, as the reference's call sites may, gets them repacked."""
@@ -246,7 +257,7 @@ class FlashMultiheadAttention(nn.Module):
         if not (q.stride(0) == k.stride(0) == v.stride(0)) or q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1:
             q, k, v = (t.reshape(T, E).contiguous() for t in (q, k, v))
         return _hip.attn_varlen(q.view(T, E), k.view(T, E), v.view(T, E), cu_lens, max_len, self.num_heads,
-                                softmax_scale=self.head_dim ** -0.5, exact=exact, order=order)
+                                softmax_scale=self.head_dim ** -0.5, exact=exact, order=order, q_prescaled=q_prescaled)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None):
@@ -262,9 +273,11 @@ class FlashMultiheadAttention(nn.Module):
         rot_fusable = (self.rot_emb is not None and ctx is not None and not self.pre_layernorm
                        and d in (16, 32, 64) and E % 32 == 0)
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
+        qp = bool(_ATTN_QP and rot_fusable and d == 64 and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True)
-            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot)
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,
+                                  q_scale=_q_scale(self.head_dim) if qp else 0.0)
         else:
             if self.padded:
                 raise NotImplementedError('padded layouts run the LayerNorm-folded path only')
@@ -285,7 +298,7 @@ class FlashMultiheadAttention(nn.Module):
                 else:
                     q, k = self.rot_emb(q, k, cu_lens, max_len, inplace=True)
         a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn),
-                       order=ctx.order if ctx is not None else None)
+                       order=ctx.order if ctx is not None else None, q_prescaled=qp)
         wo, bo = self._weights_out()
         if resid is not None or resid32 is not None:
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)

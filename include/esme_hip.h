@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 4
+#define ESME_HIP_ABI_VERSION 5
 
 enum {
     ESME_OK = 0,
@@ -137,7 +137,12 @@ int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_
  *   speculative:   head-dim-64 kernel: 1 = speculative softmax (default), 0 = classic online softmax
  *   seq_order:     NULL, or int32 (B): the order in which the sequences' work items are dispatched (esme_hip_seq_order:
  *                  longest first).  Speed only -- results do not depend on it, bit for bit; on ragged batches the long
- *                  proteins' workgroups no longer start last (-6 % on a proteome-like 50 000-residue batch). */
+ *                  proteins' workgroups no longer start last (-6 % on a proteome-like 50 000-residue batch).
+ *   q_prescaled:   1 = q already carries softmax_scale * log2(e) (the QKV projection folded it in before its bf16 rounding:
+ *                  esme_gemm_fusion_t.q_scale; `softmax_scale` is then ignored).  The 4-wave head-dim-64 kernel computes
+ *                  P = exp2(score) with no reference maximum (5 instead of 7 VALU instructions per score pair; a row sum
+ *                  that overflows or vanishes sends the work item through the classic online softmax); every other kernel
+ *                  simply runs with a unit scale. */
 typedef struct esme_attn_opts {
     int struct_bytes;            /* sizeof(esme_attn_opts_t) */
     int variant;
@@ -145,6 +150,7 @@ typedef struct esme_attn_opts {
     float defer_max_thr;
     int speculative;
     const int32_t* seq_order;
+    int q_prescaled;
 } esme_attn_opts_t;
 int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv,
                                   void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
@@ -198,6 +204,10 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              left to right, and a consumer that is handed 128-column partials pairs them up first -- so a row's
  *              statistics do not depend on the tile configuration a launch picks, i.e. on the number of rows in
  *              the batch: a sequence's logits are bit-identical alone or packed.
+ *  - q_scale != 0 (with fused rotary): output columns < q_cols (the q third of a fused QKV projection) are multiplied by q_scale
+ *              = softmax_scale * log2(e) in fp32, after the rotation and before the bf16 rounding, so that the attention
+ *              kernel's scores are exponents of 2 as they leave the MFMA (esme_attn_opts_t.q_prescaled): the `* d^-1/2` of
+ *              esme/attention.py:115-123 moved from the scores to q.
  *  - resid32 != NULL (ESME_EPI_RESIDUAL only; the high-precision mode): the residual stream is the fp32 tensor resid32
  *              (M, N) with row stride ld32, updated IN PLACE from the fp32 accumulators,
  *              resid32[m,n] += alpha * (acc[m,n] + bias[n]), and C receives its bf16 rounding (the next GEMM's operand);
@@ -219,6 +229,8 @@ typedef struct esme_gemm_fusion {
     int rot_cols;
     float* resid32;              /* see above: fp32 residual stream, updated in place (ESME_EPI_RESIDUAL only); NULL = bf16 `resid` */
     int64_t ld32;
+    float q_scale;               /* see above: fused rotary only; 0 = off */
+    int q_cols;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */

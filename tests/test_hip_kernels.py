@@ -510,6 +510,80 @@ def test_attention_speculative_overflow_is_redone_exactly():
     check(exact, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='overflow case, exact entry point')
 
 
+def test_gemm_qkv_rotary_q_scale():
+    """esme_gemm_fusion_t.q_scale: the q third of the fused QKV + rotary projection leaves multiplied by softmax_scale * log2(e)
+    (fp32, before the one bf16 rounding); k and v are untouched bit for bit."""
+    from esme import _hip
+    from esme.attention import _q_scale
+    T, E, H = 1300, 256, 4
+    d = E // H
+    x = rnd((T, E), 51).to(dev())
+    w = rnd((3 * E, E), 52, 1 / math.sqrt(E)).to(dev())
+    b = rnd((3 * E,), 53, 0.1).to(dev())
+    lengths = [700, 600]
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    cos, sin = O.rotary_tables(max(lengths), d, torch.bfloat16)
+    pos = O.culen_positions(cu).to(torch.int32)
+    rot = (cos.to(dev()), sin.to(dev()), pos.to(dev()), d, 2 * E)
+    c = _q_scale(d)
+    y0 = _hip.gemm_fused(x, w, b, rot=rot)
+    y1 = _hip.gemm_fused(x, w, b, rot=rot, q_scale=c)
+    assert torch.equal(y1[:, E:], y0[:, E:])
+    # bf16(x * c) against bf16(x) * c: one rounding apart
+    check(y1[:, :E], y0[:, :E].float() * c, rtol=2.0 ** -7, atol_scale=2.0 ** -9, what='q_scale')
+
+
+@pytest.mark.parametrize('lengths,H', [([37, 300, 1, 64, 513, 9, 3], 4), ([500] * 6, 20), ([1253, 130], 2)])
+def test_attention_prescaled_q_without_reference_maximum(lengths, H):
+    """esme_attn_opts_t.q_prescaled: q carries softmax_scale * log2(e); the 4-wave head-dim-64 kernel takes P = exp2(score) with
+    no reference maximum.  Against the fp32 oracle on the SAME (pre-scaled, bf16) q with softmax scale ln 2, and against every
+    other kernel form run with a unit scale."""
+    from esme import _hip
+    d, T = 64, sum(lengths)
+    E = H * d
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    qkv = rnd((T, 3 * E), 55)
+    c = d ** -0.5 * 1.4426950408889634
+    qkv[:, :E] = (qkv[:, :E].float() * c).to(torch.bfloat16)
+    q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    ref = O.varlen_attention(q, k, v, cu, softmax_scale=math.log(2.0)).view(T, E)
+    g = qkv.to(dev())
+    got = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H, q_prescaled=True)
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -5.5, what='prescaled q, no reference maximum')
+    for variant, spec in ((4, 0), (8, 1), (1, 0)):
+        with _hip.attn_options(variant=variant, spec=spec):
+            other = _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H, q_prescaled=True)
+        check(other, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -5.5, what=f'prescaled q, variant {variant} spec {spec}')
+
+
+def test_attention_prescaled_q_overflow_and_vanishing_sums_are_redone_exactly():
+    """No reference maximum means exp2 can overflow (a score above 127) or a whole row can vanish (every score below -126): the
+    row sum says so, and the work item is redone with the classic online softmax -- bit-identical to running that from the start."""
+    from esme import _hip
+    H, d = 2, 64
+    E = H * d
+    lengths = [900, 130, 300]
+    T = sum(lengths)
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    qkv = rnd((T, 3 * E), 57)
+    qkv[:, :E] = (qkv[:, :E].float() * 0.18).to(torch.bfloat16)
+    qkv[5, :E] = 1.0                                   # query row 5: all +1
+    qkv[700, E:2 * E] = 8.0                            # key 700: all +8 -> score 512 (log2 units): overflow
+    qkv[1030 + 7, :E] = -1.0                           # a query of the third sequence ...
+    qkv[1030:1330, E:2 * E] = 4.0                      # ... whose every key gives -256: the row sum vanishes
+    q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    ref = O.varlen_attention(q, k, v, cu, softmax_scale=math.log(2.0)).view(T, E)
+    g = qkv.to(dev())
+    run = lambda: _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H, q_prescaled=True)
+    got = run()
+    assert torch.isfinite(got.float()).all()
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='prescaled q: overflow / vanished sums redone')
+    with _hip.attn_options(variant=4, spec=0):
+        classic = run()
+    assert torch.equal(got[:256], classic[:256]) and torch.equal(got[1030:1030 + 256], classic[1030:1030 + 256])      # the work items that were redone
+    assert torch.allclose(got[5].float().cpu(), qkv[700, 2 * E:].float(), atol=2.0 ** -6)         # row 5 attends to key 700 alone
+
+
 def test_attention_defer_max_threshold_error_report():
     """quantify the defer-max threshold.  Max / Frobenius error vs the fp32 oracle for thr = 0 (row maxima
     always exact) and thr = 8 (the fast default) and the speculative softmax, on sharp (3x scaled) and plain scores."""
