@@ -68,7 +68,7 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
     // head dim 64 with fused rotary (ESM2-650M / 3B): softmax_scale * log2(e) rides in the QKV epilogue and the attention kernel
     // runs without a reference maximum (esme_attn_opts_t.q_prescaled).  ESME_ATTN_QP=0: the plain form, for A/B runs.
     static const bool use_qp = [] { const char* e = getenv("ESME_ATTN_QP"); return !(e && e[0] == '0'); }();
-    const bool qp = use_qp && rot_fused && dp == 64 && Ea % 64 == 0;
+    const bool qp = use_qp && m->rotary && dp == 64 && Ea % 64 == 0 && (rot_fused || m->qk_norm);      // (ESM-C: the q/k-norm pass folds the scale in)
     aopts.q_prescaled = qp ? 1 : 0;
     static const bool use_order = [] { const char* e = getenv("ESME_ATTN_ORDER"); return !(e && e[0] == '0'); }();   // A/B switch
     if (use_order && B > 1 && B <= 1024 && m->n_layers > 0) {
@@ -84,12 +84,12 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
         esme_gemm_fusion_t fu{};
         fu.ln_partial = stats; fu.ln_nblk = stats_nblk; fu.ln_dim = E; fu.ln_eps = m->ln_eps; fu.ln_c1 = L.qkv_c1; fu.ln_c2 = L.qkv_c2;
         if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
-        if (qp) { fu.q_scale = scale * 1.4426950408889634f; fu.q_cols = (int)Ea; }
+        if (qp && rot_fused) { fu.q_scale = scale * 1.4426950408889634f; fu.q_cols = (int)Ea; }
         ESME_TRY(esme_hip_gemm_bf16_fused(x, ldx, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Ep, ESME_EPI_NONE, 1.0f, &fu, stream));
         char* q = w.qkv; char* k = w.qkv + Ea * 2; char* v = w.qkv + 2 * Ea * 2;
         if (m->qk_norm) {
-            ESME_TRY(esme_hip_qk_norm_rotary(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp,
-                                             m->table_len, stream));
+            ESME_TRY(esme_hip_qk_norm_rotary_scaled(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp,
+                                                    m->table_len, qp ? scale * 1.4426950408889634f : 1.0f, stream));
         } else if (m->rotary && !rot_fused) {
             ESME_TRY(esme_hip_rotary_varlen(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
         }

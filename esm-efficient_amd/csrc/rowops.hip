@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
                                                              const u16* __restrict__ bq, const u16* __restrict__ bk,
                                                              float eps, const u16* __restrict__ cosT,
                                                              const u16* __restrict__ sinT, const int32_t* __restrict__ pos,
-                                                             int64_t T, int E, int d, int max_len) {
+                                                             int64_t T, int E, int d, int max_len, float q_scale) {
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;                     // waves 0, 1: q; 2, 3: k
     const bool is_k = wv >= 2;
@@ -405,6 +405,10 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
                 for (int j = 0; j < 8; ++j) {
                     const float t = __fmul_rn(o2[j], sn[j]);
                     r[j] = fmaf(a[j], cs[j], lower ? -t : t);
+                }
+                if (!is_k && q_scale != 1.0f) {              // softmax_scale * log2(e) folded into q (fp32, before the rounding): attention's q_prescaled
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] *= q_scale;
                 }
                 *reinterpret_cast<u32x4*>(xr + e0) = pack8(r);
             }
@@ -678,9 +682,10 @@ extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* 
     return check_launch("segment_mean");
 }
 
-extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
-                                       const void* bk, float eps, const void* cosT, const void* sinT,
-                                       const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, void* stream) {
+extern "C" int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                              const void* bk, float eps, const void* cosT, const void* sinT,
+                                              const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, float q_scale,
+                                              void* stream) {
     ESME_CHECK_ARG(T >= 0 && heads > 0 && head_dim > 0 && max_len > 0, "qk_norm_rotary: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && wq && wk && cosT && sinT && pos, "qk_norm_rotary: null pointer");
@@ -700,7 +705,7 @@ extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void*
     const hipStream_t s = (hipStream_t)stream;
 #define ESME_QKN(N)                                                                                                 \
     hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
-                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len)
+                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale)
     if (E <= 512) ESME_QKN(1);
     else if (E <= 1024) ESME_QKN(2);
     else if (E <= 1536) ESME_QKN(3);
@@ -708,6 +713,12 @@ extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void*
     else ESME_QKN(10);
 #undef ESME_QKN
     return check_launch("qk_norm_rotary");
+}
+
+extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                       const void* bk, float eps, const void* cosT, const void* sinT,
+                                       const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, void* stream) {
+    return esme_hip_qk_norm_rotary_scaled(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, 1.0f, stream);
 }
 
 extern "C" int esme_hip_embed_positions(const int64_t* tokens, const void* table, const void* pos_table,

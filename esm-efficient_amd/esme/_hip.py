@@ -70,6 +70,8 @@ SIGNATURES = {
                                        c_int, c_int, c_void_p]),
     'esme_hip_qk_norm_rotary': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                         c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_qk_norm_rotary_scaled': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                               c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_attn_varlen_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                          c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_attn_varlen_fwd_opts': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
@@ -387,21 +389,22 @@ def rotary_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
 
 
 def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, bq, bk, eps: float,
-                    cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, heads: int) -> None:
+                    cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, heads: int, q_scale: float = 1.0) -> None:
     """In place on the (T, H*d) views q and k: LayerNorm over H*d (weights wq / wk, optional biases), bf16
-    rounding, rotary -- one pass instead of three (ESM-C's q/k normalisation)."""
+    rounding, rotary -- one pass instead of three (ESM-C's q/k normalisation).  `q_scale` != 1: q leaves multiplied by it
+    (softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True))."""
     qp, ld = _rows2d(q, 'qk_norm_rotary q')
     kp, ldk = _rows2d(k, 'qk_norm_rotary k')
     if ld != ldk:
         raise ValueError('qk_norm_rotary: q and k must share a row stride')
     T, E = q.shape
     with _Traced('qk_norm_rotary', (T, E)):
-        _check(load().esme_hip_qk_norm_rotary(
+        _check(load().esme_hip_qk_norm_rotary_scaled(
             qp, kp, ld, _dev(wq, 'wq', torch.bfloat16), _dev(wk, 'wk', torch.bfloat16),
             _dev(bq, 'bq', torch.bfloat16) if bq is not None else None,
             _dev(bk, 'bk', torch.bfloat16) if bk is not None else None, float(eps),
             _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16), _dev(pos, 'pos', torch.int32),
-            T, heads, E // heads, cos.shape[0], _stream()), 'esme_hip_qk_norm_rotary')
+            T, heads, E // heads, cos.shape[0], float(q_scale), _stream()), 'esme_hip_qk_norm_rotary_scaled')
 
 
 def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torch.Tensor, max_len: int,

@@ -273,22 +273,22 @@ class FlashMultiheadAttention(nn.Module):
         rot_fusable = (self.rot_emb is not None and ctx is not None and not self.pre_layernorm
                        and d in (16, 32, 64) and E % 32 == 0)
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
-        qp = bool(_ATTN_QP and rot_fusable and d == 64 and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
+        qk_pass = (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128) and E <= 5120)
+        qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d == 64 and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,
-                                  q_scale=_q_scale(self.head_dim) if qp else 0.0)
+                                  q_scale=_q_scale(self.head_dim) if (qp and rot_fusable) else 0.0)
         else:
             if self.padded:
                 raise NotImplementedError('padded layouts run the LayerNorm-folded path only')
             w, b, _, _ = self._weights_qkv(False)
             qkv = _hip.gemm_fused(self.norm(x), w, b, rot=rot)
-        if (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128)
-                and E <= 5120):
-            # ESM-C: q/k LayerNorm over the full width + rotary in ONE in-place pass over q and k
+        if qk_pass:
+            # ESM-C: q/k LayerNorm over the full width + rotary in ONE in-place pass over q and k (+ the softmax scale on q)
             _hip.qk_norm_rotary_(qkv[:, :E], qkv[:, E:2 * E], self.layernorm_q.weight, self.layernorm_k.weight,
                                  self.layernorm_q.bias, self.layernorm_k.bias, self.layernorm_q.eps,
-                                 ctx.cos, ctx.sin, ctx.pos, H)
+                                 ctx.cos, ctx.sin, ctx.pos, H, q_scale=_q_scale(self.head_dim) if qp else 1.0)
             q, k, v = (qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
         else:
             q, k, v = self._split_qkv(qkv)                  # ESM-C: q/k LayerNorm in place

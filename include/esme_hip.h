@@ -117,6 +117,12 @@ int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const 
                             const void* bq, const void* bk, float eps, const void* cos,
                             const void* sin, const int32_t* pos, int64_t T, int H, int d,
                             int max_len, void* stream);
+/* The same, with q (not k) multiplied by q_scale in fp32 before the final bf16 rounding: softmax_scale * log2(e) folded
+ * into q for esme_attn_opts_t.q_prescaled (the `* d^-1/2` of esme/attention.py:115-123 moved from the scores to q). */
+int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, const void* wq, const void* wk,
+                                   const void* bq, const void* bk, float eps, const void* cos,
+                                   const void* sin, const int32_t* pos, int64_t T, int H, int d,
+                                   int max_len, float q_scale, void* stream);
 
 /* Varlen (block-diagonal) multi-head self-attention, non-causal, no dropout:
  * per sequence i and head h, O = softmax(Q K^T * softmax_scale) V over that sequence's

@@ -397,6 +397,11 @@ def test_qk_norm_rotary_fused_equals_unfused(T, H, d, bias):
                                            bb.float().cpu() if bb is not None else None)
         r = O.apply_rotary(y.view(T, H, d), cos.float().cpu(), sin.float().cpu(), pos.cpu().long()).reshape(T, E)
         assert rel_fro(b[:, part * E:(part + 1) * E].float().cpu(), r) < 6e-3
+    # q_scale: q (only) leaves multiplied by it, in fp32 before the rounding (softmax scale folded into q)
+    c2 = qkv.clone()
+    _hip.qk_norm_rotary_(c2[:, :E], c2[:, E:2 * E], wq, wk, bq, bk, 1e-5, cos, sin, pos, H, q_scale=0.18033688)
+    assert torch.equal(c2[:, E:], b[:, E:])
+    check(c2[:, :E], b[:, :E].float() * 0.18033688, rtol=2.0 ** -7, atol_scale=2.0 ** -9, what='qk_norm_rotary q_scale')
 
 
 # ------------------------------------------------------------------ LN-fold robustness
