@@ -37,8 +37,10 @@ if os.environ.get('ATTN', '0') == '1':          # attention instead of the GEMMs
     for S_ in (500, 1002, 2000):
         _, cu_, ml_, ln_ = syn.uniform_batch(50000 if S_ != 1002 else 32064, S_, seed=0)
         q_ = torch.randn(sum(ln_), 3 * E, device=dev).bfloat16()
+        if os.environ.get('QP', '0') == '1': q_[:, :E] *= 0.18            # (QP=1: q pre-scaled, the no-reference-maximum kernel)
         cu_ = cu_.cuda()
-        fns[f'attention S={S_}'] = (lambda q_=q_, cu_=cu_, ml_=ml_: _hip.attn_varlen(q_[:, :E], q_[:, E:2 * E], q_[:, 2 * E:], cu_, ml_, 20))
+        fns[f'attention S={S_}'] = (lambda q_=q_, cu_=cu_, ml_=ml_: _hip.attn_varlen(q_[:, :E], q_[:, E:2 * E], q_[:, 2 * E:], cu_, ml_, 20,
+                                                                                        q_prescaled=os.environ.get('QP', '0') == '1'))
 if os.environ.get('ATTN', '0') != '1':             # do the two builds produce the same bits?
     for k, (fn, outp) in {'qkv +rot+lnf': (fns['qkv +rot+lnf'], qkv), 'ffn1 gelu+lnf': (fns['ffn1 gelu+lnf'], u)}.items():
         _hip._lib = libA; fn(); torch.cuda.synchronize(); ra = outp.clone()
