@@ -64,6 +64,10 @@ def parse():
                     help='replay from a hipGraph when the forward is launch-bound (T x L <= 400 000)')
     ap.add_argument('--high-precision', action='store_true',
                     help="model.set_precision('high'): fp32 residual stream (not the headline mode; see DESIGN.md section 4)")
+    ap.add_argument('--precision', choices=['fast', 'high', 'exact'], default=None,
+                    help="model.set_precision(...): 'fast' = the headline mode (bf16 storage at the reference's rounding points); 'high' = fp32 "
+                         "residual stream; 'exact' = split (hi, lo) bf16 operand pairs, fp32 logits: the reference's fp32 forward to ~1e-5 "
+                         "at ~2.3x the time (DESIGN.md section 4).  Not the headline; the line says which mode ran.")
     ap.add_argument('--spawn', action='store_true',
                     help='go through the torch.distributed.run self-launch even for --gpus 1 (exercises the RCCL '
                          'init + launcher path on a single-GPU box)')
@@ -71,7 +75,11 @@ def parse():
                     help='replay the forward from a hipGraph (esme/graph.py); matters for small models / batches')
     ap.add_argument('--quantization', choices=['none', '4bit', '8bit'], default='none',
                     help="'4bit': layer projections resident in the esme-q4 format (not the headline config)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.precision is None:
+        args.precision = 'high' if args.high_precision else 'fast'
+    args.high_precision = args.precision == 'high'
+    return args
 
 
 def pmc_traffic():
@@ -259,8 +267,8 @@ def main():
         save_file(weights, path, metadata=syn.checkpoint_metadata(args.model, L, E, H))
         model = ESM.from_pretrained(path, quantization=None if args.quantization == 'none' else args.quantization,
                                     device=str(dev))
-    if args.high_precision:
-        model.set_precision('high')
+    if args.precision != 'fast':
+        model.set_precision(args.precision)
 
     # ---- this rank's packed batch (resident in HBM before the timed region)
     if args.batch == 'uniform':
@@ -304,9 +312,9 @@ def main():
         elapsed = multi.pop('elapsed_max')
         multi['backend'] = f'{dist.get_backend()} (RCCL over xGMI)' if dist.get_backend() == 'nccl' else dist.get_backend()
         if not args.no_gather:
-            gathered = torch.empty(world * T, V, dtype=torch.bfloat16, device=dev)
+            gathered = torch.empty(world * T, V, dtype=out.dtype, device=dev)
             multi.update(time_gather(dist, gathered, out, args.steps, lambda: torch.cuda.synchronize(), dev))
-            multi['gather_bytes_per_rank'] = T * V * 2
+            multi['gather_bytes_per_rank'] = T * V * out.element_size()
     assert torch.isfinite(out.float()).all()
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * T * args.steps / elapsed
@@ -326,7 +334,9 @@ def main():
                               else 'eager (one ctypes launch per kernel)'),
                    'launcher': 'torch.distributed.run (self-launched)' if os.environ.get('ESME_BENCH_SPAWNED') else
                                ('torch.distributed.run' if launched else 'plain python'),
-                   'precision': 'high (fp32 residual stream)' if args.high_precision else 'fast (bf16 residual stream)',
+                   'precision': {'fast': 'fast (bf16 residual stream)', 'high': 'high (fp32 residual stream)',
+                                 'exact': 'exact (split (hi, lo) bf16 operand pairs, fp32 residual stream, fp32 logits; 2 MFMA passes per '
+                                          'projection, 3 per attention product)'}[args.precision],
                    'setup': '2 untimed forwards before the warm-up steps (weight packing / LN folding, module load)',
                    'weights': 'synthetic (numpy PCG64), reference checkpoint layout'
                               + ('' if args.quantization == 'none' else f', layer projections {args.quantization} (esme/quantization.py)')},
@@ -353,7 +363,9 @@ def main():
             per_op.setdefault((op, meta), []).append(s.elapsed_time(e))
         key = ('gemm', (T, 4 * E if kind != 'esmc' else 2 * syn.swiglu_width(E), E,
                         _hip.EPI_GELU if kind != 'esmc' else _hip.EPI_SWIGLU))
-        traffic, traffic_src = pmc_traffic() if (args.model == 'esm2_650m' and T == 50000 and not args.high_precision
+        if args.precision == 'exact':              # the same launch in pair form: K doubled ([hi | lo]); MFMA FLOPs are counted as executed
+            key = ('gemm', (T, 4 * E, 2 * E, f'split:{_hip.EPI_GELU}'))
+        traffic, traffic_src = pmc_traffic() if (args.model == 'esm2_650m' and T == 50000 and args.precision == 'fast'
                                                  and args.quantization == 'none') else (None, None)
         if key in per_op:
             ms = sum(per_op[key]) / len(per_op[key])
@@ -373,8 +385,8 @@ def main():
                               'frac': round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
             }
         for (op, meta), v in per_op.items():
-            if op == 'attn':                     # 4*S*E flops per residue per launch (QK^T + PV)
-                afl = 4.0 * (E // meta[1]) * meta[1] * sum(s * s for s in lengths)
+            if op in ('attn', 'attn_split'):     # 4*S*E flops per residue per launch (QK^T + PV); the split form executes 3x that on the MFMAs
+                afl = 4.0 * (E // meta[1]) * meta[1] * sum(s * s for s in lengths) * (3.0 if op == 'attn_split' else 1.0)
                 ams = sum(v) / len(v)
                 result['attention'] = {'achieved': round(afl / (ams * 1e-3) / 1e12, 1), 'unit': 'TFLOP/s',
                                        'frac': round(afl / (ams * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

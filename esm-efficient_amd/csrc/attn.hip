@@ -328,6 +328,274 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
 
 
 // =============================================================================================
+// Split-operand ('exact') mode: the same contraction with every MFMA operand carried as a (hi, lo) bf16 pair
+// (x = hi + lo to ~2^-17 relative):
+//     S  = Q K^T  ~  Qh Kh^T + Qh Kl^T + Ql Kh^T                       (3 MFMA passes; the Ql Kl^T term is 2^-18 relative)
+//     O  = P V    ~  Ph Vh   + Ph Vl   + Pl Vh        with  Ph = bf16(P), Pl = bf16(P - Ph)  formed in registers
+// fp32 scores, classic online softmax with every row maximum exact, fp32 row sums of the UNROUNDED P, and the result leaves as
+// a pair as well (the out-projection's K-doubled operand).  q / k / v: hi at the given pointer, lo `lo_in` elements further
+// right in the same row (the QKV projection's pair epilogue); o: lo at `lo_out`.  Structure of attn_varlen_kernel<D, 1> (one
+// 32-row query block per wave, register-staged double-buffered tiles, V transposed while staging) with both halves of the
+// K / V^T tiles side by side in LDS.  An accuracy mode: 3x the MFMA work of the fast kernels, not tuned beyond that.
+struct AttnSplitArgs {
+    AttnArgs a;
+    int64_t lo_in, lo_out;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs sa) {
+    const AttnArgs& a = sa.a;
+    constexpr int DS = D / 16;
+    constexpr int DB = (D + 31) / 32;
+    constexpr int CPR = D / 8;
+    constexpr int KCH = KT * CPR;
+    constexpr int KI = (KCH + 255) / 256;
+    constexpr int DQ = D / 4;
+    constexpr int DQ_HI_BITS = (D == 16 ? 0 : D == 32 ? 1 : 2);
+    constexpr int VI = (16 * DQ + 255) / 256;
+    constexpr int K_BYTES = KT * D * 2;
+    constexpr int V_BYTES = D * 128;
+    constexpr int BUF = 2 * (K_BYTES + V_BYTES);       // [K hi | K lo | V^T hi | V^T lo]
+    static_assert(D == 16 || D == 32 || D == 64, "split-operand attention: head dims 16, 32, 64");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_split[];
+    char* smem = smem_split;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
+    const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
+    const int q0 = blockIdx.x * QT;
+    if (q0 >= S) return;
+
+    const unsigned int ld = (unsigned int)a.ld;
+    const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
+    const u16* kb = a.k + (int64_t)s0 * a.ld + h * D;
+    const u16* vb = a.v + (int64_t)s0 * a.ld + h * D;
+
+    const int qrow = q0 + wave * 32 + l31;
+    const bool wave_active = q0 + wave * 32 < S;
+    bf16x8 qf[2][DS];
+    {
+        const unsigned int qc = qrow < S ? qrow : S - 1;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds)
+                qf[pt][ds] = *reinterpret_cast<const bf16x8*>(qb + pt * sa.lo_in + (qc * ld + ds * 16 + hi * 8));
+    }
+
+    unsigned int koff[KI];
+    int krow[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+        const int c = i * 256 + tid;
+        krow[i] = c / CPR;
+        koff[i] = (unsigned int)(c % CPR) * 8u;
+    }
+    int v_dq[VI], v_kq[VI];
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int rest = (lane >> 4) | (wave << 2) | (i << 4);
+        v_dq[i] = (lane & 3) | ((rest & ((1 << DQ_HI_BITS) - 1)) << 2);
+        v_kq[i] = ((lane >> 2) & 3) | ((rest >> DQ_HI_BITS) << 2);
+    }
+    u32x4 kreg[2][KI];
+    u32x2 vreg[2][VI][4];
+    auto load_tile = [&](int kv0) {
+        const bool full = kv0 + KT <= S;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                if (KCH >= 256 * KI || krow[i] < KT) {
+                    unsigned int row = kv0 + krow[i];
+                    if (!full) row = row < (unsigned int)S ? row : S - 1;
+                    kreg[pt][i] = *reinterpret_cast<const u32x4*>(kb + pt * sa.lo_in + (row * ld + koff[i]));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VI; ++i) {
+                if (v_kq[i] < 16) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        unsigned int row = kv0 + v_kq[i] * 4 + kk;
+                        if (!full) row = row < (unsigned int)S ? row : S - 1;
+                        vreg[pt][i][kk] = *reinterpret_cast<const u32x2*>(vb + pt * sa.lo_in + (row * ld + v_dq[i] * 4));
+                    }
+                }
+            }
+        }
+    };
+    auto store_tile = [&](char* buf) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            char* Ks = buf + pt * K_BYTES;
+            char* Vt = buf + 2 * K_BYTES + pt * V_BYTES;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                if (KCH >= 256 * KI || krow[i] < KT) {
+                    const int row = krow[i], ch = (int)(koff[i] >> 3);
+                    *reinterpret_cast<u32x4*>(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4)) = kreg[pt][i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VI; ++i) {
+                if (v_kq[i] < 16) {
+                    const int dq = v_dq[i], kq = v_kq[i];
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) {
+                        const int w = dd >> 1;
+                        unsigned int e0, e1;
+                        if (dd & 1) {
+                            e0 = __builtin_amdgcn_perm(vreg[pt][i][1][w], vreg[pt][i][0][w], 0x07060302u);
+                            e1 = __builtin_amdgcn_perm(vreg[pt][i][3][w], vreg[pt][i][2][w], 0x07060302u);
+                        } else {
+                            e0 = __builtin_amdgcn_perm(vreg[pt][i][1][w], vreg[pt][i][0][w], 0x05040100u);
+                            e1 = __builtin_amdgcn_perm(vreg[pt][i][3][w], vreg[pt][i][2][w], 0x05040100u);
+                        }
+                        const int drow = dq * 4 + dd;
+                        const int ch = kq >> 1;
+                        u32x2 out = {e0, e1};
+                        *reinterpret_cast<u32x2*>(Vt + drow * 128 + ((ch ^ ((drow >> 1) & 7)) << 4) + (kq & 1) * 8) = out;
+                    }
+                }
+            }
+        }
+    };
+
+    const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
+
+    f32x16 oacc[DB];
+    float mc = -1e30f, l_run = 0.f;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    const float c = a.scale_log2;
+
+    const int ntiles = (S + KT - 1) / KT;
+    load_tile(0);
+    store_tile(smem);
+    if (ntiles > 1) load_tile(KT);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * KT;
+        const char* buf = smem + (t & 1) * BUF;
+        if (wave_active) {
+            f32x16 sacc[2];
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
+                const int row = kbk * 32 + krow_perm;
+                const char* rp = buf + row * (D * 2);
+                const int sw = kswz<D>(row);
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(rp + K_BYTES + (((ds * 2 + hi) ^ sw) << 4));
+                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ds], sacc[kbk], 0, 0, 0);      // small terms first
+                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][ds], sacc[kbk], 0, 0, 0);
+                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ds], sacc[kbk], 0, 0, 0);
+                }
+            }
+            if (kv0 + KT > S) {
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kbk * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) >= S) sacc[kbk][r] = -1e30f;
+            }
+            float tmax = sacc[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[1][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float tmc = tmax * c;
+            if (__any(tmc > mc)) {                         // every row maximum exact
+                const float mn = fmaxf(mc, tmc);
+                const float alpha = __builtin_amdgcn_exp2f(mc - mn);
+                mc = mn;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+            bf16x8 pf[2][2][2];                            // [hi / lo][key block][k-step]
+            float psum = 0.f;
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float p[8], ph[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p[j] = __builtin_amdgcn_exp2f(fmaf(sacc[kbk][8 * s + j], c, -mc));
+                        psum += p[j];
+                    }
+                    const u32x4 pk = pack8(p);
+                    unpack8(pk, ph);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) p[j] -= ph[j];
+                    pf[0][kbk][s] = __builtin_bit_cast(bf16x8, pk);
+                    pf[1][kbk][s] = __builtin_bit_cast(bf16x8, pack8(p));
+                }
+            l_run += psum;
+
+            const char* Vt = buf + 2 * K_BYTES;
+#pragma unroll
+            for (int i = 0; i < DB; ++i) {
+                int drow = i * 32 + l31;
+                if (D < 32) drow &= (D - 1);
+                const char* rp = Vt + drow * 128;
+                const int sw = (drow >> 1) & 7;
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
+                        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
+                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pf[0][kbk][s], oacc[i], 0, 0, 0);
+                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[1][kbk][s], oacc[i], 0, 0, 0);
+                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[0][kbk][s], oacc[i], 0, 0, 0);
+                    }
+            }
+        }
+        if (t + 1 < ntiles) {
+            store_tile(smem + ((t + 1) & 1) * BUF);
+            if (t + 2 < ntiles) load_tile(kv0 + 2 * KT);
+        }
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < S) {
+        u16* op = a.o + (int64_t)(s0 + qrow) * a.ldo + h * D;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = i * 32 + 8 * g + 4 * hi;
+                if (d < D) {
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = oacc[i][4 * g + e] * inv;
+                    const u32x2 pk = {pack_bf16(o4[0], o4[1]), pack_bf16(o4[2], o4[3])};
+                    *reinterpret_cast<u32x2*>(op + d) = pk;
+                    const u32x2 pl = {pack_bf16(o4[0] - bf_lo(pk[0]), o4[1] - bf_hi(pk[0])), pack_bf16(o4[2] - bf_lo(pk[1]), o4[3] - bf_hi(pk[1]))};
+                    *reinterpret_cast<u32x2*>(op + sa.lo_out + d) = pl;
+                }
+            }
+    }
+}
+
+
+// =============================================================================================
 // Head dim 64: software-pipelined ("ping-pong") kernel.
 //
 // Same math and MFMA operand layouts as attn_varlen_kernel above; what changes is the schedule, the data
@@ -855,6 +1123,47 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     }
 #undef ESME_ATTN
     return check_launch("attn_varlen_fwd");
+}
+
+template <int D>
+static int launch_split(const AttnSplitArgs& sa, const dim3 grid, hipStream_t s) {
+    constexpr int smem = 2 * 2 * (KT * D * 2 + D * 128);
+    auto kern = attn_split_kernel<D>;
+    if (smem >= 64 * 1024) {
+        static std::atomic<unsigned long long> done{0ull};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+                return fail(ESME_ERR_LAUNCH, "attn_split: cannot raise the dynamic LDS limit");
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, sa);
+    return check_launch("attn_varlen_fwd_split");
+}
+
+extern "C" int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qkv, void* o,
+                                              int64_t ld_o, int64_t lo_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                              int max_len, float softmax_scale, const int32_t* seq_order, void* stream) {
+    ESME_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && d > 0 && max_len >= 0, "attn_split: bad sizes");
+    if (T == 0 || B == 0) return ESME_OK;
+    ESME_CHECK_ARG(q && k && v && o && cu_lens, "attn_split: null pointer");
+    ESME_CHECK_ARG(ld_qkv % 8 == 0 && lo_qkv % 8 == 0 && lo_qkv > 0 && ld_o % 4 == 0 && lo_o % 4 == 0 && lo_o >= (int64_t)H * d &&
+                   ld_o >= lo_o + (int64_t)H * d, "attn_split: bad row strides / pair offsets");
+    ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0, "attn_split: misaligned");
+    ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn_split: max_len must be > 0, H and B <= 65535");
+    AttnSplitArgs sa{{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H, softmax_scale * 1.4426950408889634f, 1, H * B,
+                      0.0f, 0, seq_order}, lo_qkv, lo_o};
+    const dim3 grid((unsigned int)((max_len + QT - 1) / QT), (unsigned int)H, (unsigned int)B);
+    const hipStream_t s = (hipStream_t)stream;
+    switch (d) {
+        case 16: return launch_split<16>(sa, grid, s);
+        case 32: return launch_split<32>(sa, grid, s);
+        case 64: return launch_split<64>(sa, grid, s);
+        default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn_split: head dim must be 16, 32 or 64");
+    }
 }
 
 extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,

@@ -76,24 +76,32 @@ __device__ __forceinline__ float dpp_f32(float v) {
 #ifndef ESME_GELU_DEG
 #define ESME_GELU_DEG 5
 #endif
+// DEG = 5: the LayerNorm-folded FFN up-projection (the hot launch).  DEG = 7: every other GELU site -- the LM head's dense layer and
+// the split-operand ('exact') mode -- where two more FMAs per element cost nothing measurable and the result is exact to 0.002 of
+// half a bf16 ulp.  z is clamped at 64 (2^p(64) underflows to exactly 0 long before): gelu(+inf) = +inf like torch, not
+// fma(-inf, 0, inf) = NaN; v_min with an |x| source modifier costs what the bare |x| cost.
+template <int DEG>
+__device__ __forceinline__ float gelu_poly(const float z) {
+    if constexpr (DEG == 7) {
+        float p = fmaf(z, -1.8348100638831966e-06f, 6.159828626550734e-05f);
+        p = fmaf(z, p, -0.0009305249550379813f);
+        p = fmaf(z, p, 0.008507892489433289f);
+        p = fmaf(z, p, -0.05396007373929024f);
+        p = fmaf(z, p, -0.4584643840789795f);
+        p = fmaf(z, p, -1.1512510776519775f);
+        return fmaf(z, p, -0.9999952912330627f);
+    } else {
+        float p = fmaf(z, -0.00020168392802588642f, 0.004467579070478678f);
+        p = fmaf(z, p, -0.04283246025443077f);
+        p = fmaf(z, p, -0.47278666496276855f);
+        p = fmaf(z, p, -1.1443983316421509f);
+        return fmaf(z, p, -1.0005322694778442f);
+    }
+}
+template <int DEG = ESME_GELU_DEG>
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x);
-#if ESME_GELU_DEG == 7
-    float p = fmaf(z, -1.8348100638831966e-06f, 6.159828626550734e-05f);
-    p = fmaf(z, p, -0.0009305249550379813f);
-    p = fmaf(z, p, 0.008507892489433289f);
-    p = fmaf(z, p, -0.05396007373929024f);
-    p = fmaf(z, p, -0.4584643840789795f);
-    p = fmaf(z, p, -1.1512510776519775f);
-    p = fmaf(z, p, -0.9999952912330627f);
-#else
-    float p = fmaf(z, -0.00020168392802588642f, 0.004467579070478678f);
-    p = fmaf(z, p, -0.04283246025443077f);
-    p = fmaf(z, p, -0.47278666496276855f);
-    p = fmaf(z, p, -1.1443983316421509f);
-    p = fmaf(z, p, -1.0005322694778442f);
-#endif
-    return fmaf(-z, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
+    const float z = fminf(fabsf(x), 64.0f);
+    return fmaf(-z, __builtin_amdgcn_exp2f(gelu_poly<DEG>(z)), fmaxf(x, 0.0f));
 }
 
 // Two elements at a time on the packed fp32 pipe (v_pk_fma_f32: the same IEEE fma per half, so every result bit equals
@@ -101,24 +109,28 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // operands), v_exp_f32 and the max stay per element: 6 instead of 8 VALU per element.  Used by the GEMM epilogue, where the
 // matrix pipe is idle (next to MFMAs packed fp32 is an anti-lever: MI355X_MICROARCH 'price of one filler').
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int DEG = ESME_GELU_DEG>
 __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
-    const f32x2_t z = __builtin_elementwise_abs(x);
+    f32x2_t z;                                                      // min(|x|, 64): one v_min per element with the abs source modifier
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(z[0]) : "v"(x[0]), "v"(64.0f));
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(z[1]) : "v"(x[1]), "v"(64.0f));
     auto k = [](float c) { return f32x2_t{c, c}; };
-#if ESME_GELU_DEG == 7
-    f32x2_t p = __builtin_elementwise_fma(z, k(-1.8348100638831966e-06f), k(6.159828626550734e-05f));
-    p = __builtin_elementwise_fma(z, p, k(-0.0009305249550379813f));
-    p = __builtin_elementwise_fma(z, p, k(0.008507892489433289f));
-    p = __builtin_elementwise_fma(z, p, k(-0.05396007373929024f));
-    p = __builtin_elementwise_fma(z, p, k(-0.4584643840789795f));
-    p = __builtin_elementwise_fma(z, p, k(-1.1512510776519775f));
-    p = __builtin_elementwise_fma(z, p, k(-0.9999952912330627f));
-#else
-    f32x2_t p = __builtin_elementwise_fma(z, k(-0.00020168392802588642f), k(0.004467579070478678f));
-    p = __builtin_elementwise_fma(z, p, k(-0.04283246025443077f));
-    p = __builtin_elementwise_fma(z, p, k(-0.47278666496276855f));
-    p = __builtin_elementwise_fma(z, p, k(-1.1443983316421509f));
-    p = __builtin_elementwise_fma(z, p, k(-1.0005322694778442f));
-#endif
+    f32x2_t p;
+    if constexpr (DEG == 7) {
+        p = __builtin_elementwise_fma(z, k(-1.8348100638831966e-06f), k(6.159828626550734e-05f));
+        p = __builtin_elementwise_fma(z, p, k(-0.0009305249550379813f));
+        p = __builtin_elementwise_fma(z, p, k(0.008507892489433289f));
+        p = __builtin_elementwise_fma(z, p, k(-0.05396007373929024f));
+        p = __builtin_elementwise_fma(z, p, k(-0.4584643840789795f));
+        p = __builtin_elementwise_fma(z, p, k(-1.1512510776519775f));
+        p = __builtin_elementwise_fma(z, p, k(-0.9999952912330627f));
+    } else {
+        p = __builtin_elementwise_fma(z, k(-0.00020168392802588642f), k(0.004467579070478678f));
+        p = __builtin_elementwise_fma(z, p, k(-0.04283246025443077f));
+        p = __builtin_elementwise_fma(z, p, k(-0.47278666496276855f));
+        p = __builtin_elementwise_fma(z, p, k(-1.1443983316421509f));
+        p = __builtin_elementwise_fma(z, p, k(-1.0005322694778442f));
+    }
     const f32x2_t e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
     f32x2_t m;                                                      // plain v_max: fmaxf() would add a canonicalising v_max per element
     asm("v_max_f32 %0, 0, %1" : "=v"(m[0]) : "v"(x[0]));

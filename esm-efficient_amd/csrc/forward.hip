@@ -5,7 +5,6 @@
 // through this library's own C entry points, so results are bit-identical to the module-by-module path.  What it
 // removes is the host: ~160 ctypes calls (3-10 ms of Python per forward) become one, which is what a small model
 // (ESM2-8M / 150M at a few thousand residues: less GPU work than that) needs when it is not replayed from a hipGraph.
-#include <cstdlib>
 #include "launch.h"
 
 using namespace esme;
@@ -66,12 +65,11 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
     // longest sequences first in every attention launch (speed only; ragged batches), computed once per forward
     esme_attn_opts_t aopts{(int)sizeof(esme_attn_opts_t), 0, 0, 8.0f, 1, nullptr, 0};
     // head dim 64 with fused rotary (ESM2-650M / 3B): softmax_scale * log2(e) rides in the QKV epilogue and the attention kernel
-    // runs without a reference maximum (esme_attn_opts_t.q_prescaled).  ESME_ATTN_QP=0: the plain form, for A/B runs.
-    static const bool use_qp = [] { const char* e = getenv("ESME_ATTN_QP"); return !(e && e[0] == '0'); }();
-    const bool qp = use_qp && m->rotary && dp == 64 && Ea % 64 == 0 && (rot_fused || m->qk_norm);      // (ESM-C: the q/k-norm pass folds the scale in)
+    // runs without a reference maximum (esme_attn_opts_t.q_prescaled); the caller says so in the descriptor (no environment
+    // switch in the library: the module-by-module path must take the same decision to stay bit-identical).
+    const bool qp = m->attn_q_prescale && m->rotary && dp == 64 && Ea % 64 == 0 && (rot_fused || m->qk_norm);      // (ESM-C: the q/k-norm pass folds the scale in)
     aopts.q_prescaled = qp ? 1 : 0;
-    static const bool use_order = [] { const char* e = getenv("ESME_ATTN_ORDER"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (use_order && B > 1 && B <= 1024 && m->n_layers > 0) {
+    if (B > 1 && B <= 1024 && m->n_layers > 0) {
         ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));
         aopts.seq_order = w.order;
     }

@@ -36,6 +36,10 @@ struct GemmArgs {
     int opt_gm = 0, opt_gn = 0, opt_persist = -1;   // host side: per-call options (esme_gemm_opts_t); 0 / -1 = heuristic
     float q_scale = 0.f; int q_cols = 0;            // fused rotary: columns < q_cols leave multiplied by q_scale (softmax scale folded into q)
     float* resid32 = nullptr; int64_t ld32 = 0;     // residual epilogue on an fp32 stream (in place): x32 += alpha * (acc + bias), C = bf16(x32)
+    // split-operand ('exact') mode, DESIGN.md section 4: A = [hi | lo] with K doubled against ONE copy of W whose K-tile index wraps
+    // (kt_wrap = K-tiles of W, 0 = no wrap); PAIR kernels write the result as a (hi, lo) bf16 pair, lo at column offset pair_off of
+    // the same C row; c32: fp32 result through the scalar store path (the (T, V) logits)
+    int kt_wrap = 0; int64_t pair_off = 0; float* c32 = nullptr; int64_t ldc32 = 0;
 };
 
 // The tuning hooks (start skew, "no C store", "loop only") exist only in the instrumented build (`make TRACE=1`);

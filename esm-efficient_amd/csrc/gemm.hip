@@ -41,10 +41,11 @@
 
 namespace esme {
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false, bool PAIR = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
     static_assert(!R32 || EPI == ESME_EPI_RESIDUAL, "the fp32 residual stream belongs to the residual epilogue");
+    static_assert(!PAIR || (EPI != ESME_EPI_RESIDUAL && !LNF && !STATS && !PERSIST), "(hi, lo) pair output: plain / GELU / SwiGLU epilogues of the split-operand mode");
     static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64 && (WN == 2 || WN == 4)), "row statistics are emitted by the residual epilogue");
     static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
                   "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
@@ -139,20 +140,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             const int tcol = P8 ? ((row >> 5) & 3) * WTN + (row >> 7) * (WTN / 2) + (row & 31) : row;      // LDS row (h, wn', rr) = tile column wn' * WTN + h * WTN/2 + rr
             int gr = n0 + tcol;
             gr = gr < a.N ? gr : a.N - 1;
-            srcW[i] = a.W + (int64_t)gr * a.K + c * 8;
+            srcW[i] = a.W + (int64_t)gr * (a.kt_wrap > 0 ? a.kt_wrap * BK : a.K) + c * 8;      // (row stride of W = its own K)
         }
     };
     set_sources();
 
+    // split-operand mode: A = [hi | lo] (K doubled) runs against ONE copy of W -- the K-tile index of W wraps at kt_wrap (scalar)
+    auto w_k0 = [&](const int kt) { return ((a.kt_wrap > 0 && kt >= a.kt_wrap) ? kt - a.kt_wrap : kt) * BK; };
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
-        const int k0 = kt * BK;
+        const int k0 = kt * BK, k0w = w_k0(kt);
 #pragma unroll
         for (int i = 0; i < IA; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(base + (i * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < IW; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0),
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[i] + k0w),
                                              (lptr_t)(base + A_ROWS_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
     };
 
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         char* base = smem + buf * STAGE;
         const int k0 = kt * BK;
         if (p < IA) __builtin_amdgcn_global_load_lds((gptr_t)(srcA[p] + k0), (lptr_t)(base + (p * NW + wave) * 1024), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr_t)(srcW[p - IA] + k0),
+        else __builtin_amdgcn_global_load_lds((gptr_t)(srcW[p - IA] + w_k0(kt)),
                                               (lptr_t)(base + A_ROWS_BYTES + ((p - IA) * NW + wave) * 1024), 16, 0, 0);
     };
     f32x2* lnst = reinterpret_cast<f32x2*>(smem + 2 * STAGE);
@@ -668,9 +671,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         };
         load_x32(0);
+        // PAIR (split-operand mode): every pass runs twice -- first the bf16 rounding hi of the fp32 results (the residuals o - hi
+        // replace the accumulators), then lo = bf16(o - hi), stored pair_off columns further right in the same C row.
+        constexpr int NHALF = PAIR ? 2 : 1;
+        constexpr int GELU_DEG = LNF ? ESME_GELU_DEG : 7;  // degree 5 only where it is hot (the LN-folded FFN up-projection): common.h
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-        if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slab
+#pragma unroll
+        for (int half = 0; half < NHALF; ++half) {
+        if (pass || half) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slab
         if constexpr (EPI == ESME_EPI_RESIDUAL && !R32) {
 #pragma unroll
             for (int it = 0; it < RPP / 8; ++it) {
@@ -698,7 +707,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int j = pass * FMP + jj;
                 const int r = jj * 16 + l15;                            // row inside this pass's slab
                 float o[4];
-                if constexpr (EPI == ESME_EPI_SWIGLU) {
+                if (PAIR && half == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e];      // o - bf16(o), left there by the first half
+                } else if constexpr (EPI == ESME_EPI_SWIGLU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gate = acc[i][j][e], fc = acc[i + FN / 2][j][e];
@@ -712,11 +724,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
                     if constexpr (EPI == ESME_EPI_GELU) {
 #if ESME_GELU_PACKED
-                        const f32x2_t g0 = gelu_erf2(f32x2_t{o[0], o[1]}), g1 = gelu_erf2(f32x2_t{o[2], o[3]});
+                        const f32x2_t g0 = gelu_erf2<GELU_DEG>(f32x2_t{o[0], o[1]}), g1 = gelu_erf2<GELU_DEG>(f32x2_t{o[2], o[3]});
                         o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
 #else
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(o[e]);
+                        for (int e = 0; e < 4; ++e) o[e] = gelu_erf<GELU_DEG>(o[e]);
 #endif
                     }
                     if constexpr (R32) {
@@ -732,11 +744,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     }
                 }
                 u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                if (PAIR && half == 0) {
+                    acc[i][j][0] = o[0] - bf_lo(pk[0]); acc[i][j][1] = o[1] - bf_hi(pk[0]);
+                    acc[i][j][2] = o[2] - bf_lo(pk[1]); acc[i][j][3] = o[3] - bf_hi(pk[1]);
+                }
                 *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = pk;
             }
             if constexpr (EPI == ESME_EPI_RESIDUAL && !R32) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later fragments from being hoisted (VGPRs)
         }
-        if (pass + 1 < NPASS) load_x32(pass + 1);
+        if (pass + 1 < NPASS && half == NHALF - 1) load_x32(pass + 1);
         __builtin_amdgcn_wave_barrier();
         ESME_TRACE_MARK(5);
         // ---- PERSIST, after the first pass is packed (half of the accumulators are dead: the registers the address
@@ -780,7 +796,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + pass * RPP + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
-                if (col_ok && m < a.M && ESME_TUNE_STORE_OK) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+                if (col_ok && m < a.M && ESME_TUNE_STORE_OK) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n + (PAIR ? half * a.pair_off : 0)) = v;
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
@@ -798,6 +814,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
         if constexpr (PERSIST) { if (pass == 0) ESME_TRACE_SEAM(22, 1); else ESME_TRACE_SEAM(25, 1); }
+        }   // half
         }   // pass
         ESME_TRACE_MARK(6);
         if constexpr (STATS) {
@@ -833,10 +850,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     for (int e = 0; e < 4; ++e) {
                         if (n + e < a.N) {
                             float v = acc[i][j][e] + ((a.bias && ROTD == 0 && !LNF) ? bf2f(a.bias[n + e]) : 0.f);
-                            if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf(v);
+                            if constexpr (EPI == ESME_EPI_GELU) v = gelu_erf<LNF ? ESME_GELU_DEG : 7>(v);
                             if constexpr (R32) { float* xp = a.resid32 + m * a.ld32 + n + e; v = fmaf(a.alpha, v, *xp); *xp = v; }
                             else if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
-                            a.C[m * a.ldc + n + e] = f2bf(v);
+                            if (a.c32) a.c32[m * a.ldc32 + n + e] = v;             // fp32 result (the split-operand mode's logits)
+                            else a.C[m * a.ldc + n + e] = f2bf(v);
                         }
                     }
                 }
@@ -894,13 +912,13 @@ static void set_raster(GemmArgs& a) {
     if (a.gn < 1) a.gn = 1;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false, bool PAIR = false>
 static int launch_one(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
     int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
-    if constexpr (!PERSIST && BM == 256 && BN == 256 && (ROTD == 0 || ESME_GEMM_PERSIST_ROT)) {     // (fused rotary: the epilogue's tables + the address set-up spill)
+    if constexpr (!PERSIST && !PAIR && BM == 256 && BN == 256 && (ROTD == 0 || ESME_GEMM_PERSIST_ROT)) {     // (fused rotary: the epilogue's tables + the address set-up spill)
         // Big tiles run one workgroup per CU (128 KB of LDS): once a launch is several rounds long, ONE persistent
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
@@ -909,7 +927,7 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
 
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32, PAIR>;
     if (smem >= 64 * 1024) {
         // the attribute is per (kernel, device): one bit per device ordinal, set once, safe from any host thread
         static std::atomic<unsigned long long> done{0ull};
@@ -930,6 +948,23 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hipStream_t s) {
 #define ESME_L(E, R, L, S) launch_one<BM, BN, WM, WN, E, R, L, S>(a, s)
+    if (a.pair_off) {                               // split-operand mode: (hi, lo) pair output (checked by the caller: no LN fold, no residual)
+#define ESME_LP(E, R) launch_one<BM, BN, WM, WN, E, R, false, false, false, false, true>(a, s)
+        switch (epi) {
+            case ESME_EPI_NONE:
+                switch (rotd) {
+                    case 0: return ESME_LP(ESME_EPI_NONE, 0);
+                    case 16: return ESME_LP(ESME_EPI_NONE, 16);
+                    case 32: return ESME_LP(ESME_EPI_NONE, 32);
+                    case 64: return ESME_LP(ESME_EPI_NONE, 64);
+                    default: return fail(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs head dim 16, 32 or 64");
+                }
+            case ESME_EPI_GELU: return ESME_LP(ESME_EPI_GELU, 0);
+            case ESME_EPI_SWIGLU: return ESME_LP(ESME_EPI_SWIGLU, 0);
+            default: return fail(ESME_ERR_ARG, "gemm: pair output does not combine with the residual epilogue");
+        }
+#undef ESME_LP
+    }
     switch (epi) {
         case ESME_EPI_NONE:
             switch (rotd) {
@@ -1027,6 +1062,23 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     int rotd = 0;
     bool lnf = false, stats = false;
     if (r32) { a.resid32 = fu->resid32; a.ld32 = fu->ld32; }
+    if (fu && (fu->w_k || fu->pair_off || fu->c32)) {               // split-operand ('exact') mode
+        if (fu->w_k) {
+            ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && K % fu->w_k == 0, "gemm: w_k (the K of W) must be a multiple of 64 that divides K");
+            if (fu->w_k < K) a.kt_wrap = fu->w_k / BK;
+        }
+        if (fu->pair_off) {
+            ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL && !fu->ln_partial && !fu->stats_out, "gemm: pair output belongs to the plain / GELU / SwiGLU epilogues without LN fold");
+            ESME_CHECK_ARG(fu->pair_off >= n_out && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + n_out, "gemm: pair_off must be a multiple of 8 with n_out <= pair_off <= ldc - n_out");
+            if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: pair output needs a 16-byte addressable C and N % 8 == 0");
+            a.pair_off = fu->pair_off;
+        }
+        if (fu->c32) {
+            ESME_CHECK_ARG(!fu->pair_off && epilogue != ESME_EPI_SWIGLU && fu->ldc32 >= N && (reinterpret_cast<uintptr_t>(fu->c32) & 3u) == 0, "gemm: c32 needs ldc32 >= N, no pair output, no SwiGLU");
+            a.c32 = fu->c32; a.ldc32 = fu->ldc32;
+            a.vec_ok = 0;                                            // fp32 results leave through the scalar store path
+        }
+    }
     if (fu) {
         if (fu->head_dim != 0) {                                     // fused rotary
             ESME_CHECK_ARG(epilogue == ESME_EPI_NONE, "gemm: fused rotary needs ESME_EPI_NONE");

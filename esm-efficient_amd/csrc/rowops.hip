@@ -233,6 +233,82 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------- split-operand ('exact') mode: LayerNorm into a (hi, lo) bf16 pair
+// y = LayerNorm(x) in fp32, written as hi = bf16(y), lo = bf16(y - hi) (lo at column out_off + e of the same row): the MFMA
+// operand pair of the next K-doubled GEMM, optionally also as fp32 (y32: the representation the model
+// returns).  Input: the fp32 residual stream (IN = 0) or a (hi, lo) pair read as hi + lo (IN = 1: the LM head's LayerNorm).
+// One wave per row, two-pass fp32 statistics with the row in registers; 4 + 4 (+ 4) bytes per element.
+template <int NCH, int IN>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const void* __restrict__ xv, int64_t ldx, int64_t in_off,
+                                                              const u16* __restrict__ w, const u16* __restrict__ b,
+                                                              u16* __restrict__ y, int64_t ldy, int64_t out_off,
+                                                              float* __restrict__ y32, int64_t ld32, int64_t T, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            if constexpr (IN == 0) {
+                const float* xr = reinterpret_cast<const float*>(xv) + row * ldx;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + e0), a1 = *reinterpret_cast<const f32x4*>(xr + e0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[c][j] = a0[j]; v[c][4 + j] = a1[j]; }
+            } else {
+                const u16* xr = reinterpret_cast<const u16*>(xv) + row * ldx;
+                float lo[8];
+                unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
+                unpack8(*reinterpret_cast<const u32x4*>(xr + in_off + e0), lo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[c][j] += lo[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[c][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float inv_e = 1.0f / (float)E;
+    const float mean = wave_sum(s) * inv_e;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_e + eps);       // (correctly rounded forms: this mode is about accuracy)
+    u16* yr = y + row * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            float wf[8], o[8], bfv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hi[8];
+            unpack8(*reinterpret_cast<const u32x4*>(w + e0), wf);
+            if (b) unpack8(*reinterpret_cast<const u32x4*>(b + e0), bfv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+            const u32x4 ph = pack8(o);
+            unpack8(ph, hi);
+            *reinterpret_cast<u32x4*>(yr + e0) = ph;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hi[j] = o[j] - hi[j];
+            *reinterpret_cast<u32x4*>(yr + out_off + e0) = pack8(hi);
+            if (y32) {
+                float* zr = y32 + row * ld32 + e0;
+                *reinterpret_cast<f32x4*>(zr) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(zr + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------- LayerNorm statistics
 // sums[row] = {sum x, sum x^2}: one wave per row (the first layer's input; later layers get
 // their statistics from the residual GEMM epilogues)
@@ -296,6 +372,55 @@ __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* _
     }
 }
 
+
+// ------------------------------------------- split-operand ('exact') mode: rotary on (hi, lo) pairs with fp32 tables
+// The reference's fp32 forward rotates with fp32 cos / sin (esme/rotary.py:144-149 casts the tables to the activation dtype), so
+// this mode cannot use the bf16 tables of the fused QKV epilogue (their rounding alone costs 5e-4 on the logits).  In place on
+// `nheads` consecutive heads of width d (the q and k blocks of the projection's pair output): x = hi + lo in fp32,
+// x[j] <- x[j] cos - x[j + d/2] sin, x[j + d/2] <- x[j + d/2] cos + x[j] sin, written back as a pair.  One lane per 8-wide chunk
+// pair (j, j + d/2); HBM-bound: 16 B per element (hi and lo, read and written).
+__global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, int64_t ld, int64_t lo_off,
+                                                           const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                           const int32_t* __restrict__ pos, int64_t T, int nheads, int d, int max_len) {
+    const int cph = d >> 4;                               // chunk pairs per head
+    const int64_t total = T * nheads * cph;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int c = (int)(it % cph);
+        const int64_t th = it / cph;
+        const int h = (int)(th % nheads);
+        const int64_t t = th / nheads;
+        int p = pos[t];
+        p = p < max_len ? p : max_len - 1;
+        u16* xp = x + t * ld + h * d + c * 8;
+        float lh[8], ll[8], uh[8], ul[8], cs[8], sn[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xp), lh);
+        unpack8(*reinterpret_cast<const u32x4*>(xp + lo_off), ll);
+        unpack8(*reinterpret_cast<const u32x4*>(xp + (d >> 1)), uh);
+        unpack8(*reinterpret_cast<const u32x4*>(xp + (d >> 1) + lo_off), ul);
+        const float* cp = cosT + (int64_t)p * d + c * 8;
+        const float* sp = sinT + (int64_t)p * d + c * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cs[j] = c0[j]; cs[4 + j] = c1[j]; sn[j] = s0[j]; sn[4 + j] = s1[j]; }
+        float olo[8], oup[8], rl[8], ru[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float lo = lh[j] + ll[j], up = uh[j] + ul[j];
+            olo[j] = fmaf(lo, cs[j], -__fmul_rn(up, sn[j]));
+            oup[j] = fmaf(up, cs[j], __fmul_rn(lo, sn[j]));
+        }
+        const u32x4 plo = pack8(olo), pup = pack8(oup);
+        unpack8(plo, rl);
+        unpack8(pup, ru);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rl[j] = olo[j] - rl[j]; ru[j] = oup[j] - ru[j]; }
+        *reinterpret_cast<u32x4*>(xp) = plo;
+        *reinterpret_cast<u32x4*>(xp + lo_off) = pack8(rl);
+        *reinterpret_cast<u32x4*>(xp + (d >> 1)) = pup;
+        *reinterpret_cast<u32x4*>(xp + (d >> 1) + lo_off) = pack8(ru);
+    }
+}
 
 // ------------------------------------------- q/k LayerNorm + rotary (ESM-C)
 // ESM-C normalises q and k over the FULL embedding width between the projection and the rotary
@@ -429,6 +554,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* __restrict
     const float e = lane < V ? __expf(v - m) : 0.f;
     const float sum = wave_sum(e);
     if (lane < V) y[row * ldy + lane] = f2bf(log_flag ? (v - m) - __logf(sum) : e / sum);
+}
+
+// fp32 in / fp32 out (the split-operand mode's logits)
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               float* __restrict__ y, int64_t ldy, int64_t T, int V,
+                                                               int log_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float v = lane < V ? x[row * ldx + lane] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < V ? expf(v - m) : 0.f;
+    const float sum = wave_sum(e);
+    if (lane < V) y[row * ldy + lane] = log_flag ? (v - m) - logf(sum) : e / sum;
 }
 
 // ------------------------------------------------------ row gather / scatter
@@ -600,6 +739,53 @@ extern "C" int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm_f32: E > 5120 unsupported");
 #undef ESME_LNF
     return check_launch("layernorm_f32");
+}
+
+extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b, void* y,
+                                        int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E, float eps, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "layernorm_split: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && w && y, "layernorm_split: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && ldy % 8 == 0 && out_off % 8 == 0 && out_off >= E && ldy >= out_off + E, "layernorm_split: bad output layout");
+    if (in_pair) ESME_CHECK_ARG(ldx % 8 == 0 && in_off % 8 == 0 && in_off >= E && ldx >= in_off + E, "layernorm_split: bad pair input layout");
+    else ESME_CHECK_ARG(ldx % 4 == 0 && ldx >= E, "layernorm_split: bad fp32 input layout");
+    ESME_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(w) && (!b || aligned16(b)) && (!y32 || (aligned16(y32) && ld32 % 4 == 0 && ld32 >= E)),
+                   "layernorm_split: misaligned");
+    const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_LNS(N) do { if (in_pair) hipLaunchKernelGGL((layernorm_split_kernel<N, 1>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); \
+                         else hipLaunchKernelGGL((layernorm_split_kernel<N, 0>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); } while (0)
+    if (E <= 512) ESME_LNS(1);
+    else if (E <= 1024) ESME_LNS(2);
+    else if (E <= 1536) ESME_LNS(3);
+    else if (E <= 2560) ESME_LNS(5);
+    else if (E <= 5120) ESME_LNS(10);
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm_split: E > 5120 unsupported");
+#undef ESME_LNS
+    return check_launch("layernorm_split");
+}
+
+extern "C" int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const float* cosT, const float* sinT, const int32_t* pos,
+                                     int64_t T, int nheads, int d, int max_len, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && nheads > 0 && d > 0 && max_len > 0, "rotary_split: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && cosT && sinT && pos, "rotary_split: null pointer");
+    if (d % 16 != 0) ESME_FAIL(ESME_ERR_UNSUPPORTED, "rotary_split: head dim must be a multiple of 16");
+    ESME_CHECK_ARG(ld % 8 == 0 && lo_off % 8 == 0 && lo_off >= (int64_t)nheads * d && ld >= lo_off + (int64_t)nheads * d, "rotary_split: bad row stride / pair offset");
+    ESME_CHECK_ARG(aligned16(x) && aligned16(cosT) && aligned16(sinT), "rotary_split: misaligned");
+    const int64_t items = T * nheads * (d / 16);
+    hipLaunchKernelGGL(rotary_split_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)x, ld, lo_off, cosT, sinT, pos,
+                       T, nheads, d, max_len);
+    return check_launch("rotary_split");
+}
+
+extern "C" int esme_hip_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t T, int V, int log_flag, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && V > 0, "softmax_rows_f32: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && y && ldx >= V && ldy >= V, "softmax_rows_f32: null pointer or bad stride");
+    if (V > 64) ESME_FAIL(ESME_ERR_UNSUPPORTED, "softmax_rows_f32: V > 64 unsupported");
+    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned int)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, T, V, log_flag);
+    return check_launch("softmax_rows_f32");
 }
 
 extern "C" int esme_hip_row_sums(const void* x, int64_t ldx, int64_t T, int E, float* sums, void* stream) {

@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -26,7 +26,8 @@ class GemmFusion(Structure):
     """esme_gemm_fusion_t (include/esme_hip.h)."""
     _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
-                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int)]
+                ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int),
+                ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64)]
 
 
 class GemmOpts(Structure):
@@ -50,7 +51,8 @@ class ModelDesc(Structure):
     """esme_model_desc_t (include/esme_hip.h)."""
     _fields_ = ([(n, c_int) for n in ('struct_bytes', 'n_layers', 'embed_dim', 'phys_dim', 'heads', 'head_dim', 'head_pad',
                                       'ffn_dim', 'vocab', 'swiglu', 'rotary', 'qk_norm', 'table_len')]
-                + [('ln_eps', c_float), ('alpha', c_float), ('softmax_scale', c_float), ('layers', POINTER(LayerWeights))]
+                + [('ln_eps', c_float), ('alpha', c_float), ('softmax_scale', c_float), ('attn_q_prescale', c_int),
+                   ('layers', POINTER(LayerWeights))]
                 + [(n, c_void_p) for n in ('final_ln_w', 'final_ln_b', 'head_dense_w', 'head_dense_b', 'head_ln_w',
                                            'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')])
 
@@ -82,6 +84,12 @@ SIGNATURES = {
                                       c_int64, c_int, c_void_p]),
     'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                        c_float, c_void_p]),
+    'esme_hip_layernorm_split': (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                         c_int64, c_int64, c_int, c_float, c_void_p]),
+    'esme_hip_attn_varlen_fwd_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                               c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'esme_hip_rotary_split': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_softmax_rows_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gemm_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_gemm_qkv_rotary': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
@@ -428,6 +436,8 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
     ao = _TLS.attn_opts
+    if order is not None and order.numel() != cu.numel() - 1:
+        raise ValueError('attn: `order` must be a permutation of the B sequence indices (seq_order(cu_lens))')
     if q_prescaled and exact:
         raise ValueError('attn: q_prescaled is not available through the exact entry (pass the unscaled q)')
     if (order is not None or q_prescaled) and not exact:
@@ -472,6 +482,68 @@ def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
         _check(load().esme_hip_layernorm_f32(xp, ldx, _dev(weight, 'layernorm weight', torch.bfloat16),
                                              _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
                                              yp, ldy, T, E, eps, _stream()), 'esme_hip_layernorm_f32')
+    return out
+
+
+def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, dim: int,
+                    out: Optional[torch.Tensor] = None, out32: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Split-operand ('exact') mode: LayerNorm over `dim` features in fp32 -> (T, 2*dim) bf16 pair [hi | lo] (+ fp32 copy in
+    `out32`).  x: fp32 (T, dim), or a bf16 pair (T, 2*dim) read as hi + lo."""
+    T = x.shape[0]
+    pair_in = x.dtype == torch.bfloat16
+    if pair_in:
+        xp, ldx = _rows2d(x, 'layernorm_split x')
+        if x.shape[1] != 2 * dim:
+            raise ValueError('layernorm_split: a pair input is (T, 2 * dim)')
+    else:
+        xp, ldx = _rows2d(x, 'layernorm_split x', torch.float32)
+        if x.shape[1] != dim:
+            raise ValueError('layernorm_split: an fp32 input is (T, dim)')
+    if out is None:
+        out = torch.empty(T, 2 * dim, dtype=torch.bfloat16, device=x.device)
+    yp, ldy = _rows2d(out, 'layernorm_split out')
+    zp, ldz = (None, 0)
+    if out32 is not None:
+        zp, ldz = _rows2d(out32, 'layernorm_split out32', torch.float32)
+    with _Traced('layernorm_split', (T, dim)):
+        _check(load().esme_hip_layernorm_split(xp, ldx, 1 if pair_in else 0, dim, _dev(weight, 'layernorm weight', torch.bfloat16),
+                                               _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
+                                               yp, ldy, dim, zp, ldz, T, dim, float(eps), _stream()), 'esme_hip_layernorm_split')
+    return out
+
+
+def rotary_split_(x: torch.Tensor, lo_off: int, cos32: torch.Tensor, sin32: torch.Tensor, pos: torch.Tensor, nheads: int, head_dim: int) -> None:
+    """Split-operand ('exact') mode: in-place rotary on `nheads` consecutive heads of a pair buffer (hi at column c, lo at
+    lo_off + c) with FP32 cos / sin tables (max_len, head_dim)."""
+    xp, ld = _rows2d(x, 'rotary_split x')
+    T = x.shape[0]
+    with _Traced('rotary_split', (T, nheads * head_dim)):
+        _check(load().esme_hip_rotary_split(xp, ld, int(lo_off), _dev(cos32, 'cos', torch.float32), _dev(sin32, 'sin', torch.float32),
+                                            _dev(pos, 'pos', torch.int32), T, int(nheads), int(head_dim), int(cos32.shape[0]), _stream()),
+               'esme_hip_rotary_split')
+
+
+def attn_varlen_split(qkv: torch.Tensor, cu_lens: torch.Tensor, max_len: int, heads: int, head_dim: int,
+                      softmax_scale: float, out: Optional[torch.Tensor] = None, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Split-operand ('exact') mode: qkv (T, 6*E) bf16 = [q k v hi | q k v lo] (the pair epilogue of the QKV projection) ->
+    (T, 2*E) attention output pair [hi | lo]."""
+    E = heads * head_dim
+    T = qkv.shape[0]
+    if qkv.shape[1] != 6 * E:
+        raise ValueError('attn_varlen_split: qkv must be (T, 6 * H * d)')
+    qp, ld = _rows2d(qkv, 'attn_split qkv')
+    if out is None:
+        out = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=qkv.device)
+    op, ldo = _rows2d(out, 'attn_split out')
+    cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
+    B = cu.numel() - 1
+    if order is not None and order.numel() != B:
+        raise ValueError('attn: `order` must be a permutation of the B sequence indices (seq_order(cu_lens))')
+    with _Traced('attn_split', (T, heads, head_dim)):
+        _check(load().esme_hip_attn_varlen_fwd_split(qp, qp + 2 * E, qp + 4 * E, ld, 3 * E, op, ldo, E, _dev(cu, 'cu_lens', torch.int32),
+                                                     B, T, heads, head_dim, int(max_len), float(softmax_scale),
+                                                     _dev(order, 'seq order', torch.int32) if order is not None else None, _stream()),
+               'esme_hip_attn_varlen_fwd_split')
     return out
 
 
@@ -536,27 +608,40 @@ def stats_blocks(M: int, N: int) -> int:
 def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None,
-               q_scale: float = 0.0) -> torch.Tensor:
+               q_scale: float = 0.0, split_a: bool = False, pair_out: bool = False, out32: Optional[torch.Tensor] = None) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
     epilogue); `rot` = (cos, sin, pos, head_dim, rot_cols) fuses rotary (plain epilogue); `resid32` (M, N) f32 is the
     high-precision residual stream: updated in place from the fp32 accumulators, `out` gets its bf16 rounding
     (residual epilogue; `resid` is then ignored); `q_scale` (with `rot`): the first rot_cols / 2 output columns (q) leave
-    multiplied by it -- softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True)."""
+    multiplied by it -- softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True).
+    Split-operand ('exact') mode: `split_a`: a is (M, 2K) = [hi | lo] against w (N, K) (K doubled, W's K index wraps);
+    `pair_out`: the result is written as a pair, out (M, 2 * n_out) = [hi | lo]; `out32` (M, N) fp32 receives the result instead
+    of `out` (scalar store path: the vocab projection)."""
     ap, lda = _rows2d(a, 'gemm a')
     if not w.is_contiguous():
         raise ValueError('gemm: weight must be contiguous (N, K)')
     M, K = a.shape
     N = w.shape[0]
-    if w.shape[1] != K:
+    if w.shape[1] != (K // 2 if split_a else K):
         raise ValueError(f'gemm: K mismatch {a.shape} x {w.shape}')
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out is None:
-        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=a.device)
-    cp, ldc = _rows2d(out, 'gemm out')
-    rp, ldr = (None, 0)
+        out = torch.empty(M, 2 * n_out if pair_out else n_out, dtype=torch.bfloat16, device=a.device) if out32 is None else out32
     fu = GemmFusion()
+    if out32 is not None:
+        fu.c32, fu.ldc32 = _dev(out32, 'gemm out32', torch.float32), out32.stride(0)
+        cp, ldc = fu.c32, out32.stride(0)               # (C itself is not written)
+    else:
+        cp, ldc = _rows2d(out, 'gemm out')
+    if split_a:
+        fu.w_k = K // 2
+    if pair_out:
+        if out.shape[1] != 2 * n_out:
+            raise ValueError('gemm: a pair output is (M, 2 * n_out)')
+        fu.pair_off = n_out
+    rp, ldr = (None, 0)
     if resid32 is not None:
         if epilogue != EPI_RESIDUAL or resid32.shape != (M, N) or resid32.stride(1) != 1:
             raise ValueError('gemm: resid32 must be an (M, N) float32 tensor with unit column stride (residual epilogue)')
@@ -584,6 +669,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     go = _TLS.gemm_opts
     if resid32 is not None:
         tag = 'residual_f32'
+    if split_a or pair_out or out32 is not None:
+        tag = f'split:{tag}'
     with _Traced('gemm', (M, N, K, tag)):
         if go is not None:
             _check(load().esme_hip_gemm_bf16_opts(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
@@ -613,8 +700,13 @@ def row_sums(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
 def softmax_rows(x: torch.Tensor, log: bool) -> torch.Tensor:
     shape = x.shape
     x2 = x.reshape(-1, shape[-1])
-    xp, ldx = _rows2d(x2, 'softmax x')
     out = torch.empty_like(x2, memory_format=torch.contiguous_format)
+    if x.dtype == torch.float32:                          # split-operand ('exact') mode: fp32 logits
+        xp, ldx = _rows2d(x2, 'softmax x', torch.float32)
+        _check(load().esme_hip_softmax_rows_f32(xp, ldx, out.data_ptr(), out.stride(0), x2.shape[0], x2.shape[1],
+                                                1 if log else 0, _stream()), 'esme_hip_softmax_rows_f32')
+        return out.view(shape)
+    xp, ldx = _rows2d(x2, 'softmax x')
     _check(load().esme_hip_softmax_rows(xp, ldx, out.data_ptr(), out.stride(0), x2.shape[0], x2.shape[1],
                                         1 if log else 0, _stream()), 'esme_hip_softmax_rows')
     return out.view(shape)

@@ -35,7 +35,7 @@ from esme.nn import GELU, LayerNorm, Linear
 from esme.rotary import RotaryEmbedding
 
 # head dim 64 with fused rotary: softmax_scale * log2(e) folded into q by the QKV epilogue, attention without a reference maximum
-# (ESME_ATTN_QP=0: the plain form; the C entry esme_hip_forward reads the same variable)
+# (ESME_ATTN_QP=0: the plain form, an A/B switch read HERE only; the C entry gets the decision in esme_model_desc_t.attn_q_prescale)
 _ATTN_QP = os.environ.get('ESME_ATTN_QP', '1') != '0'
 
 
@@ -48,7 +48,7 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch')
 
     def __init__(self, pos, cos, sin, fold=False, exact_attn=False):
         self.pos, self.cos, self.sin = pos, cos, sin
@@ -56,6 +56,7 @@ class ForwardContext:
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
         self.x32 = None             # high-precision mode: the fp32 residual stream (T, E_phys)
         self.order = None           # dispatch order of the sequences for the attention launches (longest first; speed only)
+        self.scratch = {}           # split-operand ('exact') mode: activation-pair buffers shared by all layers
         self.sums = None            # partial sums (nblk, T, 2) f32 describing the current residual stream
         self.part_a = None          # (stats_blocks, T, 2) f32 buffers the residual GEMMs write their row sums to
         self.part_b = None
@@ -449,6 +450,48 @@ class FlashTransformerLayer(nn.Module):
                        resid32=ctx.x32)
         self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=ctx.x32)
         ctx.sums = ctx.part_a
+
+    def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):
+        """One ESM-2 / ESM-1 layer of the split-operand ('exact') mode on the fp32 residual stream `ctx.x32` (updated in place).
+        Every activation that feeds a matrix product travels as a (hi, lo) bf16 pair [hi | lo] (x = hi + lo to 2^-17), every
+        GEMM runs over the doubled K against ONE copy of the bf16 weight, the LayerNorms are NOT folded (their gain would have
+        to be rounded into the weight) and run in fp32 on the stream, attention multiplies pairs (3 MFMA passes) with exact
+        row maxima, and both branch outputs are added to the stream from the fp32 accumulators.  Reproduces the reference's
+        fp32 forward (`dtype=torch.float32`, esme/esm.py:132-141) to ~1e-5 relative instead of bf16's ~1e-2; ~2.3x the time
+        of the fast mode."""
+        att = self.self_attn
+        if self.padded or att.pre_layernorm or self.final_activation != 'gelu' or att.head_pad not in (16, 32, 64):
+            raise NotImplementedError("precision='exact' covers the ESM-2 / ESM-1 block (GELU FFN, head dim 16 / 32 / 64, 64-aligned width)")
+        if any(q is not None for q in (att._q4_qkv, att._q4_out, self._q4_up, self._q4_down)):
+            raise NotImplementedError("precision='exact' needs unquantised weights")
+        x32 = ctx.x32
+        T, E = x32.shape
+        H, d = att.num_heads, att.head_pad
+        alpha = 1.0 / self.residue_scaling
+        sc = ctx.scratch
+        if 'h' not in sc:
+            dev = x32.device
+            sc['h'] = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=dev)          # LayerNorm output pair / attention output pair
+            sc['qkv'] = torch.empty(T, 6 * E, dtype=torch.bfloat16, device=dev)        # [q k v hi | q k v lo]
+            sc['mid'] = torch.empty(T, 2 * self.final[1].out_features, dtype=torch.bfloat16, device=dev)
+            sc['x16'] = torch.empty(T, E, dtype=torch.bfloat16, device=dev)            # bf16 rounding of the stream (written by the residual epilogue, unused)
+        h, qkv, mid, x16 = sc['h'], sc['qkv'], sc['mid'], sc['x16']
+        # ---- attention branch
+        _hip.layernorm_split(x32, att.norm.weight, att.norm.bias, att.norm.eps, E, out=h)
+        w, b, _, _ = att._weights_qkv(False)
+        _hip.gemm_fused(h, w, b, out=qkv, split_a=True, pair_out=True)
+        if att.rot_emb is not None:       # fp32 tables (the reference's fp32 forward has them): a pass of its own, not the bf16-table epilogue
+            _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
+        _hip.attn_varlen_split(qkv, cu_lens, max_len, H, d, att.head_dim ** -0.5, out=h, order=ctx.order)
+        wo, bo = att._weights_out()
+        _hip.gemm_fused(h, wo, bo, _hip.EPI_RESIDUAL, None, alpha, x16, resid32=x32, split_a=True)
+        # ---- FFN branch
+        ln = self.final[0]
+        _hip.layernorm_split(x32, ln.weight, ln.bias, ln.eps, E, out=h)
+        wu, bu, _, _ = self._weights_up(False)
+        _hip.gemm_fused(h, wu, bu, _hip.EPI_GELU, out=mid, split_a=True, pair_out=True)
+        wd, bd = self._weights_down()
+        _hip.gemm_fused(mid, wd, bd, _hip.EPI_RESIDUAL, None, alpha, x16, resid32=x32, split_a=True)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
                 inplace: bool = False):

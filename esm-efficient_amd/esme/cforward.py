@@ -9,6 +9,7 @@ version changes.
 from __future__ import annotations
 
 import ctypes
+import operator
 from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_void_p
 
 import torch
@@ -25,6 +26,9 @@ def _bind():
 
 def _ptr(t):
     return t.data_ptr() if t is not None else None
+
+
+_VERSION = operator.attrgetter('_version')
 
 
 class ModelDescriptor:
@@ -58,11 +62,13 @@ class ModelDescriptor:
         d.n_layers, d.embed_dim, d.phys_dim = len(layers), model.embed_dim, model.phys_dim
         d.heads, d.head_dim, d.head_pad = att0.num_heads, att0.head_dim, att0.head_pad
         swiglu = first.final_activation == 'swiglu'
-        d.ffn_dim = first.final[1].out_features if swiglu else first.final[1].out_features
+        d.ffn_dim = first.final[1].out_features
         d.vocab = model.vocab_size
         d.swiglu, d.rotary, d.qk_norm = int(swiglu), int(att0.rot_emb is not None), int(att0.pre_layernorm)
         d.ln_eps, d.alpha = float(att0.norm.eps), 1.0 / float(first.residue_scaling)
         d.softmax_scale = att0.head_dim ** -0.5
+        from esme.attention import _ATTN_QP
+        d.attn_q_prescale = int(_ATTN_QP)                     # ONE flag drives both paths (esme.attention reads it the same way)
         d.layers = arr
         ln = model.emb_layer_norm_after
         d.final_ln_w, d.final_ln_b = _ptr(ln.weight), _ptr(ln.bias)
@@ -71,15 +77,18 @@ class ModelDescriptor:
 
     @staticmethod
     def signature(model):
-        """(storage, version) of every parameter: `load_state_dict`, `copy_`, optimiser steps and re-allocations all change
-        it, and the descriptor (which points at DERIVED copies: fused q/k/v, LayerNorm-folded weights) is rebuilt.  A write
-        through `p.data` (which bumps no version counter) is the one thing it cannot see: call `model.invalidate_graphs()`
-        after such a write -- it drops this descriptor together with the captured graphs.  The parameter list is cached on
-        the model (the module tree is fixed after construction), so the check is one tuple build, not a module walk."""
-        params = model.__dict__.get('_cparams')
-        if params is None:
-            params = model.__dict__['_cparams'] = list(model.parameters())
-        return tuple([(p.data_ptr(), p._version) for p in params])
+        """What the descriptor (raw pointers to DERIVED copies: fused q/k/v, LayerNorm-folded weights) depends on, cheap enough
+        to compare on every forward: the package-wide parameter epoch (esme.nn: bumped when a parameter OBJECT is assigned --
+        `lin.weight = nn.Parameter(...)`, `load_state_dict`, `.to()` / `_apply`, `set_precision`, `invalidate_graphs`) and the
+        version counters of the parameters (in-place `copy_` / optimiser steps), read with one C-level `map` over a list that
+        is rebuilt only when the epoch moves.  A write through `p.data` bumps neither: call `model.invalidate_graphs()` after
+        one (documented there)."""
+        from esme.nn import param_epoch
+        ep = param_epoch()
+        cache = model.__dict__.get('_cparams')
+        if cache is None or cache[0] != ep:
+            cache = model.__dict__['_cparams'] = (ep, list(model.parameters()))
+        return (ep, tuple(map(_VERSION, cache[1])))
 
     @staticmethod
     def supported(model) -> bool:
@@ -106,8 +115,13 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
     d.table_len = int(cos.shape[0]) if cos is not None else 0
     T = x.shape[0]
     nbytes = int(lib.esme_hip_forward_workspace_bytes(ctypes.byref(d), T))
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    # workspace: one buffer per (device, stream), kept on the model and grown on demand (two streams never share one)
+    key = (x.device.index, _hip._stream())
+    pool = model.__dict__.setdefault('_cws', {})
+    ws = pool.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = pool[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     _hip._check(lib.esme_hip_forward(ctypes.byref(d), _hip._dev(x, 'forward x', torch.bfloat16), x.stride(0),
                                      _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
-                                     _ptr(pos), ws.data_ptr(), nbytes, None, 0, _hip._stream()), 'esme_hip_forward')
+                                     _ptr(pos), ws.data_ptr(), ws.numel(), None, 0, _hip._stream()), 'esme_hip_forward')
     return x

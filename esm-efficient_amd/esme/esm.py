@@ -69,6 +69,8 @@ class ESM2(nn.Module):
     quant_type_4bit = 'fp4'        # codebook of quantization='4bit' (esme.quantization.CODEBOOKS)
     # 'fast': bf16 residual stream (storage at the reference's rounding points).  'high': fp32 residual stream + fp32
     # LayerNorm statistics + exact online softmax, bf16 only at MFMA operands; slower.
+    # 'exact': split-operand mode -- every activation feeding a matrix product is a (hi, lo) bf16 pair, fp32 everywhere else;
+    # reproduces the reference's fp32 forward (esme/esm.py:132-141 `dtype=`) to ~1e-5, returns fp32.
     precision = os.environ.get('ESME_PRECISION', 'fast')
     # all layers + final LayerNorm through ONE C call (esme_hip_forward) instead of ~5 Python-issued launches per layer
     c_forward = os.environ.get('ESME_NO_C_FORWARD', '0') != '1'
@@ -142,11 +144,23 @@ class ESM2(nn.Module):
         return ModelDescriptor.supported(self)
 
     def set_precision(self, mode: str):
-        """'fast' (default) or 'high' (fp32 residual stream; DESIGN.md section 4 has what each achieves)."""
-        assert mode in ('fast', 'high'), mode
+        """'fast' (default), 'high' (fp32 residual stream) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to
+        ~1e-5, fp32 outputs, ~2.3x the time); DESIGN.md section 4 has what each achieves."""
+        assert mode in ('fast', 'high', 'exact'), mode
         self.precision = mode
         self.invalidate_graphs()
         return self
+
+    def _apply(self, fn, *a, **kw):
+        """`.to()`, `.cuda()`, dtype casts: the parameters' storage moves -- drop everything derived from it."""
+        out = super()._apply(fn, *a, **kw)
+        self.invalidate_graphs()
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self.invalidate_graphs()
+        return out
 
     # -- helpers ---------------------------------------------------------------
     def _context(self, cu_lens, max_len, total, device) -> ForwardContext:
@@ -154,7 +168,7 @@ class ESM2(nn.Module):
         rot = self.layers[0].self_attn.rot_emb if len(self.layers) else None
         cos = sin = None
         if rot is not None:
-            cos, sin = rot.tables(int(max_len), device, torch.bfloat16)
+            cos, sin = rot.tables(int(max_len), device, torch.float32 if self.precision == 'exact' else torch.bfloat16)
         return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high')
 
     def _unpad(self, x, tokens):
@@ -169,7 +183,11 @@ class ESM2(nn.Module):
 
     @staticmethod
     def _pad(x, indices, batch, seqlen):
-        """`pad_input`: scatter packed rows into zeros (B*S, E) -> (B, S, E) (esm.py:255)."""
+        """`pad_input`: scatter packed rows into zeros (B*S, E) -> (B, S, E) (esm.py:255).  fp32 rows (precision 'exact') move as
+        twice as many 16-bit words: the kernel copies 16-byte chunks."""
+        if x.dtype == torch.float32:
+            y = _hip.scatter_rows(x.contiguous().view(torch.bfloat16), indices, batch * seqlen)
+            return y.view(torch.float32).view(batch, seqlen, x.shape[-1])
         return _hip.scatter_rows(x, indices, batch * seqlen).view(batch, seqlen, x.shape[-1])
 
     def _check_layers_arg(self, layers):
@@ -193,8 +211,9 @@ class ESM2(nn.Module):
                 x = torch.cat([x[..., i * Ep:i * Ep + E] for i in range(x.shape[-1] // Ep)], dim=-1)
             return x
 
-    def _forward_representation(self, tokens, pad_args, pad_output, pad_indices, layers):
-        """forward_representation at the PHYSICAL width (== the logical one unless the layout is padded)."""
+    def _forward_representation(self, tokens, pad_args, pad_output, pad_indices, layers, want_pair=False):
+        """forward_representation at the PHYSICAL width (== the logical one unless the layout is padded).  `want_pair`
+        (precision 'exact' only): return the (hi, lo) bf16 pair of the final-LayerNorm output, the LM head's operand."""
         x = self._embedding_phys(tokens, pad_args)
         if pad_args is not None:
             assert tokens.ndim == 1, 'tokens are expected to be unpadded with shape (batch * seq_len)'
@@ -213,7 +232,25 @@ class ESM2(nn.Module):
         ctx = self._context(cu_lens, max_len, x.shape[0], x.device)
         taps = []
         E = self.embed_dim
-        if self.precision == 'high' and len(self.layers):
+        if self.precision == 'exact':
+            # split-operand mode: fp32 residual stream, activation pairs, fp32 results (esme.attention.FlashTransformerLayer.forward_exact)
+            assert not self.padded, "precision='exact' needs a 64-aligned embedding width and a supported head dim"
+            T = x.shape[0]
+            ctx.x32 = torch.empty(T, E, dtype=torch.float32, device=x.device)
+            _hip.residual_f32_(ctx.x32, x, 1.0, x, None, init=True)           # the embedding rows, exactly, in fp32
+            ctx.order = _hip.seq_order(cu_lens)
+            for i, layer in enumerate(self.layers):
+                layer.forward_exact(cu_lens, max_len, ctx)
+                if i in layers:
+                    taps.append(ctx.x32.clone())
+            ln = self.emb_layer_norm_after
+            pair = ctx.scratch.get('h')
+            pair = pair if pair is not None else torch.empty(T, 2 * E, dtype=torch.bfloat16, device=x.device)
+            x = torch.empty(T, E, dtype=torch.float32, device=x.device)
+            _hip.layernorm_split(ctx.x32, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
+            if want_pair:
+                x, taps = pair, []
+        elif self.precision == 'high' and len(self.layers):
             # fp32 residual stream; x (bf16) is kept as the rounded copy the GEMMs read
             assert x.shape[1] % 64 == 0, 'high-precision mode needs a 64-aligned physical width'
             ctx.x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -243,9 +280,13 @@ class ESM2(nn.Module):
         return torch.concat((x, *taps), dim=-1) if taps else x
 
     def forward(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
-        """Logits (T, V) / (B, S, V), bf16, on the model's device (esm.py:268-282)."""
+        """Logits (T, V) / (B, S, V), bf16 (fp32 with precision 'exact'), on the model's device (esm.py:268-282)."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
         with _hip.stream_scope(self.embed_tokens.weight.device):
+            if self.precision == 'exact':                     # fp32 logits from the (hi, lo) pair of the final LayerNorm
+                pair = self._forward_representation(tokens, pad_args, pad_output, pad_indices, [], want_pair=True)
+                y = self.lm_head.forward_exact(pair.reshape(-1, pair.shape[-1]))
+                return y.view(*pair.shape[:-1], y.shape[-1])
             return self.lm_head(self._forward_representation(tokens, pad_args, pad_output, pad_indices, []))
 
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
@@ -275,6 +316,9 @@ class ESM2(nn.Module):
             self._graph_cache.clear()
         self.__dict__.pop('_cdesc', None)
         self.__dict__.pop('_cparams', None)
+        self.__dict__.pop('_cws', None)
+        from esme.nn import bump_epoch
+        bump_epoch()
 
     # -- loading -------------------------------------------------------------------
     @classmethod

@@ -33,6 +33,18 @@ class RobertaLMHead(nn.Module):
             self._pad_key = key
         return self._pad
 
+    def forward_exact(self, pair):
+        """Split-operand ('exact') mode: `pair` (T, 2E) = [hi | lo] of the final-LayerNorm output -> fp32 logits (T, V)."""
+        if self.phys_dim != self.embed_dim:
+            raise NotImplementedError("precision='exact' needs a 64-aligned embedding width")
+        T, E = pair.shape[0], self.embed_dim
+        h = _hip.gemm_fused(pair, self.dense.weight, self.dense.bias, _hip.EPI_GELU, split_a=True, pair_out=True)
+        ln = self.layer_norm
+        _hip.layernorm_split(h, ln.weight, ln.bias, ln.eps, E, out=h)
+        y = torch.empty(T, self.final.out_features, dtype=torch.float32, device=pair.device)
+        _hip.gemm_fused(h, self.final.weight, self.final.bias, split_a=True, out32=y)
+        return y
+
     def forward(self, features):
         shape = features.shape
         x = features.reshape(-1, shape[-1])

@@ -14,7 +14,28 @@ from torch import nn
 from esme import _hip
 
 
-class Linear(nn.Module):
+# Parameter epoch: bumped whenever a parameter OBJECT of one of these modules is (re)assigned -- `lin.weight = nn.Parameter(...)`,
+# `load_state_dict(assign=True)`, a module swap -- and by `ESM2._apply` / `load_state_dict` / `set_precision` / `invalidate_graphs`.
+# Consumers that cache derived weights (esme.cforward.ModelDescriptor) compare it in O(1) instead of walking the module tree.
+_EPOCH = [0]
+
+
+def bump_epoch() -> None:
+    _EPOCH[0] += 1
+
+
+def param_epoch() -> int:
+    return _EPOCH[0]
+
+
+class _TrackedModule(nn.Module):
+    def __setattr__(self, name, value):
+        if name in ('weight', 'bias'):
+            bump_epoch()
+        super().__setattr__(name, value)
+
+
+class Linear(_TrackedModule):
     """y = x W^T + b on the bf16 MFMA GEMM (replaces nn.Linear on the path)."""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True, dtype=torch.bfloat16, device=None):
@@ -44,7 +65,7 @@ class Linear(nn.Module):
         return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}'
 
 
-class LayerNorm(nn.Module):
+class LayerNorm(_TrackedModule):
     """Row LayerNorm over the last dim (fp32 statistics inside the kernel)."""
 
     def __init__(self, dim: int, eps: float = 1e-5, bias: bool = True, dtype=torch.bfloat16, device=None):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 5
+#define ESME_HIP_ABI_VERSION 6
 
 enum {
     ESME_OK = 0,
@@ -169,6 +169,42 @@ int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, 
                                    void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
                                    int H, int d, int max_len, float softmax_scale, void* stream);
 
+/* ---- split-operand ('exact') mode, model.set_precision('exact') -------------------------------------------------
+ * The reference can run this forward in fp32 (`dtype=torch.float32`, esme/esm.py:132-141); on bf16 matrix cores the same
+ * accuracy is reached by carrying every ACTIVATION that feeds a matrix product as a pair hi = bf16(x), lo = bf16(x - hi)
+ * (x = hi + lo to 2^-17 relative; weights are bf16 in the checkpoint, hence exact), stored side by side in one row:
+ * hi at column e, lo at column `off` + e.  The residual stream stays fp32 (esme_gemm_fusion_t.resid32), GEMMs run over
+ * [hi | lo] with K doubled (esme_gemm_fusion_t.w_k / pair_off / c32), and the three entry points below provide the
+ * LayerNorm, attention and softmax of that mode.  Measured: DESIGN.md section 4. */
+
+/* y = LayerNorm(x) (fp32 statistics and arithmetic) written as a (hi, lo) pair -- hi at y[t, e], lo at y[t, out_off + e] --
+ * and, when y32 != NULL, also in fp32.  x: fp32 (T, E) with row stride ldx (in_pair = 0), or a pair (in_pair = 1: bf16, hi at
+ * x[t, e], lo at x[t, in_off + e], read as hi + lo).  Replaces nn.LayerNorm (esme/attention.py:75,222,230; esme/esm.py:252;
+ * esme/head.py:22) of the fp32 forward. */
+int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b,
+                             void* y, int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E,
+                             float eps, void* stream);
+
+/* esme_hip_attn_varlen_fwd with every MFMA operand as a (hi, lo) pair: S = Qh Kh^T + Qh Kl^T + Ql Kh^T, P split in registers,
+ * O = Ph Vh + Ph Vl + Pl Vh, classic online softmax with exact row maxima, fp32 row sums; q / k / v: hi at the pointer, lo
+ * lo_qkv elements further right in the same row; o receives a pair likewise (lo at lo_o).  d in {16, 32, 64}.  seq_order as in
+ * esme_attn_opts_t (NULL = identity).  Replaces flash_attn_varlen_func (esme/attention.py:115-123) of the fp32 forward. */
+int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qkv,
+                                   void* o, int64_t ld_o, int64_t lo_o, const int32_t* cu_lens, int B, int64_t T,
+                                   int H, int d, int max_len, float softmax_scale, const int32_t* seq_order,
+                                   void* stream);
+
+/* esme_hip_rotary_varlen for that mode: in place on `nheads` consecutive heads of width d stored as a pair (hi at x[t, c], lo at
+ * x[t, lo_off + c]; e.g. the q and k blocks of a pair-output QKV projection: nheads = 2 H), x = hi + lo rotated in fp32 with FP32
+ * cos / sin tables (max_len, d) -- the reference casts its tables to the activation dtype (esme/rotary.py:144-149), so its fp32
+ * forward rotates with fp32 tables; the bf16 tables of the fused epilogue would cost 5e-4 on the logits. */
+int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const float* cos, const float* sin, const int32_t* pos,
+                          int64_t T, int nheads, int d, int max_len, void* stream);
+
+/* esme_hip_softmax_rows on fp32 logits (fp32 out): torch.log_softmax / torch.softmax at esme/esm.py:297-298,315-317. */
+int esme_hip_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t T, int V, int log_flag,
+                              void* stream);
+
 /* C (M, N') = epilogue(A (M, K) @ W (N, K)^T + bias (N)), bf16 in/out, fp32 accumulate on
  * MFMA.  bias may be NULL.  resid (M, N) is read only for ESME_EPI_RESIDUAL and may alias C.
  * N' = N/2 for ESME_EPI_SWIGLU, else N.  K must be a multiple of 64.
@@ -218,7 +254,14 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              (M, N) with row stride ld32, updated IN PLACE from the fp32 accumulators,
  *              resid32[m,n] += alpha * (acc[m,n] + bias[n]), and C receives its bf16 rounding (the next GEMM's operand);
  *              `resid` is ignored.  Replaces the same adds (esme/attention.py:253-255) with the stream kept in fp32:
- *              the branch output is never rounded to bf16 on its way into the stream. */
+ *              the branch output is never rounded to bf16 on its way into the stream.
+ *  - split-operand ('exact') mode, model.set_precision('exact'): an fp32 activation x is carried as the bf16 pair
+ *              hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|), stored side by side in one row: A = [hi | lo] with
+ *              K = 2 w_k, and x W^T = hi W^T + lo W^T is ONE GEMM over the doubled K whose W K-tile index wraps at w_k (one
+ *              copy of W in memory, its second pass served from L2).  pair_off makes the epilogue emit its fp32 result as
+ *              such a pair for the next GEMM (plain + fused rotary, GELU, SwiGLU epilogues); c32 returns it in fp32 (the
+ *              (T, V) logits).  Every product the reference's fp32 forward (`dtype=torch.float32`, esme/esm.py:132-141)
+ *              forms with an activation is then reproduced to ~2^-17 instead of bf16's 2^-9. */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;
@@ -237,6 +280,11 @@ typedef struct esme_gemm_fusion {
     int64_t ld32;
     float q_scale;               /* see above: fused rotary only; 0 = off */
     int q_cols;
+    /* split-operand ('exact') mode -- see below */
+    int w_k;                     /* K of W when A = [hi | lo | ...] repeats it: W is (N, w_k), K a multiple of w_k; 0 = K */
+    int64_t pair_off;            /* != 0: C receives the result as a (hi, lo) bf16 pair, lo at column pair_off + n of the same row */
+    float* c32;                  /* != NULL: the result is written in fp32 to c32 (M, N), row stride ldc32, instead of C */
+    int64_t ldc32;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
@@ -361,6 +409,10 @@ typedef struct esme_model_desc {
     int table_len;               /* rows of the cos / sin tables */
     float ln_eps, alpha;         /* alpha = 1 / residue_scaling */
     float softmax_scale;         /* head_dim^-1/2 of the LOGICAL head dim (esme/attention.py:115-123 leaves it to flash-attn) */
+    int attn_q_prescale;         /* 1 (what the Python package passes): where the kernels support it (head dim 64 with fused rotary or
+                                    the ESM-C q/k pass) softmax_scale * log2(e) is folded into q and attention runs without a reference
+                                    maximum (esme_attn_opts_t.q_prescaled); 0: the plain form.  Both callers of one model must agree:
+                                    the module-by-module path takes the same decision from the same Python flag. */
     const esme_layer_weights_t* layers;
     const void* final_ln_w; const void* final_ln_b;
     const void* head_dense_w; const void* head_dense_b; const void* head_ln_w; const void* head_ln_b;

@@ -1,0 +1,218 @@
+"""Split-operand ('exact') mode on the GPU (north_star's "logits within 1e-3 of the reference forward").
+
+`model.set_precision('exact')` carries every activation that feeds a matrix product as a (hi, lo) bf16 pair (x = hi + lo to
+2^-17), keeps everything else in fp32 and returns fp32 -- the MI355X counterpart of running the reference with
+`dtype=torch.float32` (esme/esm.py:132-141).  Checked here:
+  * each new kernel / epilogue against float64 torch arithmetic on the same inputs (tolerances written at the assert);
+  * the whole model against the REFERENCE's own fp32 outputs (tests/golden/*.npz `*_f32`, produced by the reference's code with
+    dtype=torch.float32) and against the fp32 oracle: rel-Frobenius <= 1e-4 (ten times inside north_star's 1e-3);
+  * alone-vs-packed bit identity in this mode as well.
+The full-size case (33 layers x 50 000 residues) is tests/test_fullsize_gpu.py::test_exact_mode_full_depth.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import load_golden, rel_fro
+from oracle import esm_oracle as O
+from esme import _hip
+from esme import synthetic as syn
+from test_model_gpu import build
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def split(x):
+    """fp32 -> (T, 2n) bf16 pair [hi | lo]."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.cat((hi, lo), dim=1).contiguous()
+
+
+def join(p):
+    n = p.shape[1] // 2
+    return p[:, :n].double() + p[:, n:].double()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (1000, 384, 320), (4099, 1280, 640), (45000, 512, 256)])
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_split_a_and_pair_out(M, N, K, tile):
+    """[hi | lo] x W over the doubled K == the fp32 product to ~2^-17; the pair epilogue returns it to ~2^-17 as well."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 3.0
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = x.double() @ w.double().t() + b.double()
+    a = split(x).to(DEV)
+    with _hip.gemm_options(tile=tile):
+        out = _hip.gemm_fused(a, w.to(DEV), b.to(DEV), split_a=True, pair_out=True)
+        got = join(out.cpu())
+        # what the operand split itself loses: (hi + lo) instead of x
+        floor = rel(join(a.cpu()) @ w.double().t() + b.double(), ref)
+        assert rel(got, ref) <= 2e-5 and floor <= 1e-5, (rel(got, ref), floor)
+        # hi is exactly the bf16 rounding of the fp32 result the plain epilogue would round (same accumulation order)
+        single = _hip.gemm_fused(a, w.to(DEV), b.to(DEV), split_a=True)
+        assert torch.equal(single, out[:, :N])
+        # GELU epilogue (degree-7 polynomial) in pair form
+        outg = _hip.gemm_fused(a, w.to(DEV), b.to(DEV), _hip.EPI_GELU, split_a=True, pair_out=True)
+        assert rel(join(outg.cpu()), F.gelu(ref)) <= 2e-5
+        # fp32 output through the scalar path
+        y32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        _hip.gemm_fused(a, w.to(DEV), b.to(DEV), split_a=True, out32=y32)
+        assert rel(y32.cpu(), ref) <= 1e-5
+
+
+def test_gemm_split_vocab_projection_fp32():
+    """N = 33 (not 16-byte addressable): the LM head's last GEMM in this mode."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(777, 320, generator=g)
+    w = (torch.randn(33, 320, generator=g) / 18).to(torch.bfloat16)
+    b = torch.randn(33, generator=g).to(torch.bfloat16)
+    y = torch.empty(777, 33, dtype=torch.float32, device=DEV)
+    _hip.gemm_fused(split(x).to(DEV), w.to(DEV), b.to(DEV), split_a=True, out32=y)
+    assert rel(y.cpu(), x.double() @ w.double().t() + b.double()) <= 1e-5
+
+
+@pytest.mark.parametrize('E', [320, 640, 1280, 2560])
+def test_layernorm_split(E):
+    g = torch.Generator().manual_seed(E)
+    x = torch.randn(1003, E, generator=g) * 2 + 0.3
+    w = (1 + 0.1 * torch.randn(E, generator=g)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(E, generator=g)).to(torch.bfloat16)
+    ref = F.layer_norm(x.double(), (E,), w.double(), b.double(), 1e-5)
+    y32 = torch.empty(1003, E, dtype=torch.float32, device=DEV)
+    pair = _hip.layernorm_split(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, E, out32=y32)
+    assert rel(y32.cpu(), ref) <= 1e-6
+    assert rel(join(pair.cpu()), ref) <= 1e-5
+    assert torch.equal(pair[:, :E], y32.to(torch.bfloat16))
+    # pair input (the LM head's LayerNorm), in place
+    pin = split(x).to(DEV)
+    refp = F.layer_norm(join(pin.cpu()), (E,), w.double(), b.double(), 1e-5)
+    _hip.layernorm_split(pin, w.to(DEV), b.to(DEV), 1e-5, E, out=pin)
+    assert rel(join(pin.cpu()), refp) <= 1e-5
+
+
+@pytest.mark.parametrize('d', [16, 32, 64])
+def test_rotary_split_fp32_tables(d):
+    """Pair rotary with fp32 tables == fp64 rotary of hi + lo to the pair's own resolution (the reference's fp32 forward uses fp32
+    tables: esme/rotary.py:144-149)."""
+    H, T, max_len = 6, 333, 97
+    E = H * d
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(T, 3 * E, generator=g)
+    pair = torch.cat((x.to(torch.bfloat16), (x - x.to(torch.bfloat16).float()).to(torch.bfloat16)), dim=1).contiguous()
+    pos = torch.randint(0, max_len, (T,), generator=g, dtype=torch.int32)
+    cos, sin = O.rotary_tables(max_len, d, torch.float32)
+    xs = (pair[:, :3 * E].double() + pair[:, 3 * E:].double())
+    qk = xs[:, :2 * E].view(T, 2 * H, d)
+    c, s_ = cos[pos.long()].double().unsqueeze(1), sin[pos.long()].double().unsqueeze(1)
+    rot = torch.cat((-qk[..., d // 2:], qk[..., :d // 2]), dim=-1)
+    ref = torch.cat(((qk * c + rot * s_).reshape(T, 2 * E), xs[:, 2 * E:]), dim=1)
+    dev = pair.to(DEV)
+    _hip.rotary_split_(dev, 3 * E, cos.to(DEV), sin.to(DEV), pos.to(DEV), 2 * H, d)
+    got = dev.cpu()[:, :3 * E].double() + dev.cpu()[:, 3 * E:].double()
+    assert rel(got, ref) <= 1e-5
+    assert torch.equal(dev.cpu()[:, 2 * E:3 * E], pair[:, 2 * E:3 * E])          # v untouched
+
+
+@pytest.mark.parametrize('d,H', [(16, 20), (32, 20), (64, 8)])
+def test_attention_split(d, H):
+    lengths = [1, 7, 64, 65, 130, 300, 517]
+    cu = syn.cu_lens_of(lengths)
+    T, E = sum(lengths), H * d
+    g = torch.Generator().manual_seed(d)
+    qkv = torch.randn(T, 3 * E, generator=g) * 1.5
+    pair = torch.cat((qkv.to(torch.bfloat16), (qkv - qkv.to(torch.bfloat16).float()).to(torch.bfloat16)), dim=1).contiguous()
+    x = pair[:, :3 * E].double() + pair[:, 3 * E:].double()        # what the kernel is handed
+    ref = torch.empty(T, E, dtype=torch.float64)
+    cul = cu.tolist()
+    for s0, s1 in zip(cul[:-1], cul[1:]):
+        q, k, v = (x[s0:s1, i * E:(i + 1) * E].view(-1, H, d).transpose(0, 1) for i in range(3))
+        p = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(d), dim=-1)
+        ref[s0:s1] = (p @ v).transpose(0, 1).reshape(-1, E)
+    order = _hip.seq_order(cu.to(DEV))
+    out = _hip.attn_varlen_split(pair.to(DEV), cu.to(DEV), max(lengths), H, d, d ** -0.5, order=order)
+    torch.cuda.synchronize()
+    e = rel(join(out.cpu()), ref)
+    print(f'\n[attn split d={d}] rel {e:.2e}')
+    assert e <= 2e-5, e
+    out2 = _hip.attn_varlen_split(pair.to(DEV), cu.to(DEV), max(lengths), H, d, d ** -0.5)
+    assert torch.equal(out, out2)                                   # dispatch order changes no bit
+
+
+def test_attention_split_dominant_key():
+    """A key that beats every other score by ~3000 log2 units, late in the sequence: the online rescale in pair form."""
+    d, H = 64, 4
+    lengths = [200]
+    E = H * d
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(200, 3 * E, generator=g)
+    qkv[150, E:E + d] = qkv[10, 0:d] * 40.0                           # key 150 of head 0 aligned with query 10
+    pair = torch.cat((qkv.to(torch.bfloat16), (qkv - qkv.to(torch.bfloat16).float()).to(torch.bfloat16)), dim=1).contiguous()
+    x = pair[:, :3 * E].double() + pair[:, 3 * E:].double()
+    q, k, v = (x[:, i * E:(i + 1) * E].view(-1, H, d).transpose(0, 1) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(1, 2) / 8.0, dim=-1) @ v).transpose(0, 1).reshape(-1, E)
+    out = _hip.attn_varlen_split(pair.to(DEV), syn.cu_lens_of(lengths).to(DEV), 200, H, d, d ** -0.5)
+    assert rel(join(out.cpu()), ref) <= 2e-5
+
+
+@pytest.mark.parametrize('fname', ['g1_esm2_tiny.npz', 'g3_esm2_650m_layer.npz', 'g3b_esm2_150m_layer.npz'])
+def test_exact_mode_vs_reference_fp32_golden(fname):
+    """The reference's OWN fp32 forward (golden `*_f32`, generated by tests/golden/make_golden.py from /root/reference with
+    dtype=torch.float32) vs precision='exact': <= 1e-4 on logits, log-probs and representations."""
+    g = load_golden(fname)
+    model = build(g['kind'], g['L'], g['E'], g['H'], g['seed']).set_precision('exact')
+    tokens, cu, max_len = g['tokens'].to(DEV), g['cu_lens'].to(DEV), g['max_len']
+    logits = model(tokens, (cu, max_len))
+    assert logits.dtype == torch.float32 and logits.shape == g['logits_f32'].shape
+    e = rel_fro(logits.cpu(), g['logits_f32'])
+    lp = model.predict_log_prob(tokens, (cu, max_len))
+    e_lp = rel_fro(lp.cpu(), g['logprob_f32'])
+    rep = model.forward_representation(tokens, (cu, max_len))
+    assert rep.dtype == torch.float32
+    e_rep = rel_fro(rep.cpu()[g['tap_rows']], g['rep_f32'])
+    fast = model.set_precision('fast')(tokens, (cu, max_len))
+    print(f'\n[exact] {fname}: logits {e:.2e}, log-prob {e_lp:.2e}, representation {e_rep:.2e} vs the reference fp32 forward '
+          f'(fast mode: {rel_fro(fast.float().cpu(), g["logits_f32"]):.2e})')
+    assert e <= 1e-4 and e_lp <= 1e-4 and e_rep <= 1e-4, (e, e_lp, e_rep)
+
+
+def test_exact_mode_alone_vs_packed_and_2d_input():
+    model = build('esm2', 4, 320, 20, seed=3).set_precision('exact')
+    w = syn.synthetic_state_dict('esm2', 4, 320, seed=3)
+    lengths = [37, 250, 5, 128]
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    out = model(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    ref = O.forward_logits(w, 20, tokens, cu, max(lengths), dtype=torch.float32)
+    assert rel_fro(out.cpu(), ref) <= 1e-4
+    cul = cu.tolist()
+    for i, n in enumerate(lengths):                                   # a sequence's logits do not depend on what it is packed with
+        alone = model(tokens[cul[i]:cul[i + 1]].to(DEV), (syn.cu_lens_of([n]).to(DEV), n))
+        assert torch.equal(alone, out[cul[i]:cul[i + 1]]), f'sequence {i}'
+    # 2-D padded input: (B, S, V) fp32, pad rows like the fast path's
+    pad = model.alphabet.padding_idx
+    S = max(lengths)
+    t2 = torch.full((len(lengths), S), pad, dtype=torch.int64)
+    for i, n in enumerate(lengths):
+        t2[i, :n] = tokens[cul[i]:cul[i + 1]]
+    out2 = model(t2.to(DEV))
+    assert out2.shape == (len(lengths), S, model.vocab_size) and out2.dtype == torch.float32
+    for i, n in enumerate(lengths):
+        assert torch.equal(out2[i, :n], out[cul[i]:cul[i + 1]])
+    taps = model.forward_representation(tokens.to(DEV), (cu.to(DEV), max(lengths)), layers=[1, 3])
+    assert taps.shape == (sum(lengths), 3 * 320) and taps.dtype == torch.float32
+
+
+def test_exact_mode_rejects_what_it_does_not_cover():
+    """ESM-C (q/k LayerNorm, SwiGLU) has no split-operand layer yet: a loud NotImplementedError, never a silent bf16 result."""
+    m = build('esmc', 2, 960, 15, seed=0).set_precision('exact')
+    tokens, cu = syn.random_tokens([40], seed=0), syn.cu_lens_of([40])
+    with pytest.raises(NotImplementedError):
+        m(tokens.to(DEV), (cu.to(DEV), 40))

@@ -296,9 +296,9 @@ def test_gelu_polynomial_all_bf16_inputs():
     Replaces the reference's nn.GELU() (esme/attention.py:233, esme/head.py:26)."""
     from scipy.special import ndtr
     src = open(os.path.join(os.path.dirname(__file__), '..', 'esm-efficient_amd', 'csrc', 'common.h')).read()
-    body = src[src.index('float gelu_erf(float x)'):]
-    body = body[:body.index('return fmaf(-z')]
-    deg7, deg5 = body.split('#else')
+    body = src[src.index('float gelu_poly(const float z)'):]
+    body = body[:body.index('template <int DEG = ESME_GELU_DEG>')]
+    deg7, deg5 = body.split('} else {')
     default = int(re.search(r'#define ESME_GELU_DEG (\d)', src).group(1))
     assert default in (5, 7)
     bits = (np.arange(65536, dtype=np.uint32) << 16)
@@ -312,7 +312,7 @@ def test_gelu_polynomial_all_bf16_inputs():
     for name, text, deg in (('7', deg7, 7), ('5', deg5, 5)):
         co = [float(v) for v in re.findall(r'(-?\d\.\d+(?:e-?\d+)?)f', text)]
         assert len(co) == deg + 1, (name, co)
-        z = np.abs(x)
+        z = np.minimum(np.abs(x), np.float32(64.0))                 # the kernel clamps z: gelu(+inf) = +inf, not NaN
         f32 = lambda v: v.astype(np.float32)
         with np.errstate(over='ignore', invalid='ignore'):
             p = f32(z.astype(np.float64) * np.float64(np.float32(co[0])) + np.float64(np.float32(co[1])))   # fmaf: exact product, one rounding
@@ -323,6 +323,12 @@ def test_gelu_polynomial_all_bf16_inputs():
         err = np.abs(y.astype(np.float64) - ref) / tol
         worst[name] = float(err.max())
         assert np.isfinite(y).all()
+        # beyond the fitted range the polynomial must stay far below 0 up to the clamp, so that 2^p underflows to the limit
+        zz = np.linspace(6.0, 64.0, 5801)
+        pp = np.polyval(co, zz)
+        assert pp.max() <= -29.0, (name, pp.max())
+        # x = +-inf: z = 64, 2^p(64) = 0 exactly -> gelu(+inf) = +inf, gelu(-inf) = -64 * 0 + 0 = -0
+        assert np.exp2(np.float32(np.polyval(co, 64.0))) == 0.0
     assert worst['7'] <= 0.01 and worst['5'] <= 0.25, worst          # fractions of (1/2 ulp | floor); the shipped degree is
     assert worst[str(default)] <= 0.25                                # far inside the 1/2-ulp bar
 
@@ -344,3 +350,29 @@ def test_rotary_tables_bit_equal_reference(d):
     c1, _ = rot.tables(60, 'cpu', torch.bfloat16)
     c2, _ = rot.tables(180, 'cpu', torch.bfloat16)
     assert torch.equal(c2[:60], c1) and torch.equal(c2.float(), g[f'cos_d{d}_bf16'].float())
+
+
+def test_descriptor_signature_sees_replaced_and_rewritten_parameters():
+    """esme.cforward.ModelDescriptor.signature (what decides whether the C entry's cached descriptor -- raw pointers to derived
+    weight copies -- is still valid) is O(1) in Python work per forward, yet must move when (a) a parameter OBJECT is replaced
+    (the old cached parameter list kept the dead object alive and never noticed), (b) a parameter is rewritten in
+    place, (c) load_state_dict / invalidate_graphs run; and must NOT move otherwise."""
+    from esme.cforward import ModelDescriptor
+    from esme.esm import ESM2
+    m = ESM2(num_layers=2, embed_dim=64, attention_heads=4)
+    s0 = ModelDescriptor.signature(m)
+    assert ModelDescriptor.signature(m) == s0
+    lin = m.layers[1].self_attn.out
+    lin.weight = torch.nn.Parameter(torch.zeros_like(lin.weight), requires_grad=False)          # (a)
+    s1 = ModelDescriptor.signature(m)
+    assert s1 != s0
+    assert any(p is lin.weight for p in m.__dict__['_cparams'][1])                                 # the cached list follows the new object
+    with torch.no_grad():
+        m.layers[0].final[1].weight.copy_(torch.ones_like(m.layers[0].final[1].weight))          # (b)
+    s2 = ModelDescriptor.signature(m)
+    assert s2 != s1 and ModelDescriptor.signature(m) == s2
+    m.load_state_dict(m.state_dict())                                                              # (c)
+    s3 = ModelDescriptor.signature(m)
+    assert s3 != s2
+    m.invalidate_graphs()
+    assert ModelDescriptor.signature(m) != s3
