@@ -26,7 +26,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // No hazard padding is needed inside: operands come from ds_read (waited for by the compiler's lgkmcnt), consecutive MFMAs use
 // different accumulators, and an accumulate chain on the same registers needs no wait state.
 #define MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(WF), "v"(AF))
-// FLAGS: 1 = skip the C stores (K loop only); ablations (wrong results, timing only): 2 = no LDS-DMA inside the loop, 4 = no fragment reads inside the loop
+// FLAGS: 1 = skip the C stores (K loop only); ablations (wrong results, timing only): 2 = no LDS-DMA inside the loop, 4 = no fragment reads inside the loop, 8 = no vmcnt wait (DMAs
+// issued but never waited for: separates the ISSUE cost from the LATENCY wait); 16 = the 16 DMA pieces as one burst behind the first MFMA of phase Y (correct)
 template <int FLAGS>
 __global__ __launch_bounds__(256) void gemm_1w(const Args a) {
     constexpr int STAGE = 65536, WOFF = 32768;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_1w(const Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- mid: tile kt+1 has landed (this wave's pieces), Q reads retired, every wave done reading tile kt
-        if constexpr (m1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (m1 && !(FLAGS & 8)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -132,7 +133,10 @@ __global__ __launch_bounds__(256) void gemm_1w(const Args a) {
         for (int m = 0; m < 64; ++m) {
             const int i = m >> 3, j = m & 7;
             MFMA(acc[i][j], Q.w[i], Q.a[j]);
-            if constexpr (m2 && !(FLAGS & 2)) { if (m % 3 == 1 && m / 3 < 16) piece(kt + 2, buf, m / 3); }
+            if constexpr (m2 && !(FLAGS & 2) && !(FLAGS & 16)) { if (m % 3 == 1 && m / 3 < 16) piece(kt + 2, buf, m / 3); }
+            if constexpr (m2 && (FLAGS & 16) != 0) { if (m == 0) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) piece(kt + 2, buf, p); } }
             if constexpr (m1 && !(FLAGS & 4)) { if (m % 3 == 0 && m / 3 < 16) rd(P, nbase, 0, m / 3); }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -209,6 +213,9 @@ extern "C" int lab1w_run(int flags, const void* A, const void* W, void* C, int64
         case 3: return launch<3>(a, s);
         case 5: return launch<5>(a, s);
         case 7: return launch<7>(a, s);
+        case 9: return launch<9>(a, s);
+        case 16: return launch<16>(a, s);
+        case 17: return launch<17>(a, s);
         default: return -4;
     }
 }
