@@ -1045,6 +1045,354 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     }
 }
 
+
+#ifdef ESME_ATTN_W4          // lab build only (tools/lab/build_alt.sh attn.hip ... with -DESME_ATTN_W4): measured slower, see the note below
+// =============================================================================================
+// Head dim 64, ONE wave per SIMD (round 4): 4 waves per workgroup, each wave owns FOUR 32-row query blocks (128 rows; 512 per
+// workgroup) and the whole 512-entry register file of its SIMD (O^T accumulators and the Q fragments in the accumulator half).
+// Same math, LDS images and data path as attn_pp64_kernel (K / V tiles by counted LDS-DMA into a ring of four slots, V^T fragments by
+// ds_read_b64_tr_b16, speculative softmax on pre-scaled q); what changes is the amount of work per fragment and per barrier:
+//   * every K / V^T fragment is read ONCE per key tile into registers and feeds FOUR MFMAs (one per query block): 24 LDS
+//     instructions per 64 MFMAs instead of ~1.5 per MFMA, one barrier per 64 MFMAs instead of per 32;
+//   * the software pipeline rotates over the four blocks: phase (b, t) runs softmax(b, t) on the VALU while the matrix pipe does
+//     O^T(b-1) += V^T P(b-1)^T and S^T(b+1) = K Q_{b+1}^T -- 16 x { 1 MFMA, 1 score pair: 2 v_exp + 2 v_add + 1 v_cvt_pk };
+//     the K fragment set is replaced in place (tile t+1) behind the MFMAs of phase (2, t), the V^T set behind those of (0, t+1).
+// MEASURED (profiles/r04_attn_w4_lab.txt; bit-identical to attn_pp64_kernel<4, true> on every batch): 237 vs 183 us at S = 500, 246 vs
+// 194 at S = 1 002, 663 vs 546 at S = 2 000, 504 vs 355 on the proteome-like batch -- 20-40 % SLOWER.  Ablations at S = 2 000: without
+// the in-loop LDS-DMA 607 us, without the fragment reloads 615: the core {1 MFMA, 2 v_exp, 2 v_add, 1 v_cvt_pk} stream of ONE wave runs
+// ~64 cycles per MFMA, which is what tools/lab/mfma_issue_probe.hip predicts (profiles/r02_mfma_issue_probe.txt: this mix at F = 5 costs
+// 49.7 cycles per MFMA with one wave per SIMD and 38.9 with two -- a second wave hides the VALU issue of the first behind its own MFMA;
+// at head dim 128, where the CDNA4 guide's one-wave kernel reaches 50-56 %, every MFMA carries half the softmax work).  Kept out of the
+// shipped library; not a candidate.
+// q must arrive pre-multiplied by softmax_scale * log2(e) (esme_attn_opts_t.q_prescaled; the QKV epilogue / the ESM-C q/k pass do
+// it): P = exp2(score) with no reference maximum; a row sum that overflows or vanishes sends the work item through the classic
+// online softmax (the same code with need_max), exactly as in attn_pp64_kernel<NW, true>.
+// The MFMAs are inline asm with the accumulator classes pinned -- O^T and Q in the AGPR half ("a"), scores in arch VGPRs ("v":
+// the softmax reads them; a VALU instruction cannot read an AGPR) -- hipcc's own placement of the builtin copies accumulators
+// between the halves.  Hazards: an MFMA result is read by the VALU at the earliest two MFMAs (>= 64 cycles) after the MFMA that
+// wrote it (kbk-minor order of the S^T steps; the need_max path pads with s_nop); an accumulate chain needs no wait state.
+#ifndef ESME_W4_ABL
+#define ESME_W4_ABL 0           // timing ablations (wrong results): 1 = no softmax VALU, 2 = no LDS-DMA inside the loop, 4 = no fragment reloads
+#endif
+#define ESME_MFMA32_VA(ACC, AF, BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(AF), "a"(BF))
+#define ESME_MFMA32_VA0(ACC, AF, BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(ACC) : "v"(AF), "a"(BF))
+#define ESME_MFMA32_AV(ACC, AF, BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(AF), "v"(BF))
+__global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnArgs a) {
+    constexpr int D = 64, DS = 4, NW = 4, NT = 256, QB = 4;
+    constexpr int K_BYTES = KT * D * 2;          // 8 KB
+    constexpr int SLOT = K_BYTES + D * 128;
+    constexpr int ROWS = NW * QB * 32;           // 512
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned int xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3;
+    const int qt = (int)(bi % (unsigned int)a.nqt);
+    const unsigned int hb = (bi / (unsigned int)a.nqt) * 8u + xcd;
+    if (hb >= (unsigned int)a.nhb) return;
+    const int h = (int)(hb % (unsigned int)a.H), bi_seq = (int)(hb / (unsigned int)a.H);
+    const int b = a.order ? a.order[bi_seq] : bi_seq;
+    const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
+    const int q0 = qt * ROWS;
+    if (q0 >= S) return;
+
+    const unsigned int ld = (unsigned int)a.ld;
+    const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
+    const unsigned int kv_bytes = ((unsigned int)(S - 1) * ld + D) * 2u;
+    auto make_rsrc = [&](const u16* p) -> u32x4 {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        return u32x4{(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v),
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)(v >> 32) & 0xffffu)),
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)kv_bytes), 0x00020000u};
+    };
+    const u32x4 krs = make_rsrc(a.k + (int64_t)s0 * a.ld + h * D);
+    const u32x4 vrs = make_rsrc(a.v + (int64_t)s0 * a.ld + h * D);
+    auto dma16 = [&](const u32x4 rs, const unsigned int voff, const char* dst) {
+        const unsigned int d = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)dst);
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(d), "s"(rs) : "memory");
+    };
+
+    // ---- Q fragments of the wave's four q-blocks (B operand of S^T), kept in the accumulator half
+    bf16x8 qf[QB][DS];
+    const int wrow0 = q0 + wave * (QB * 32);
+    const bool wave_active = wrow0 < S;
+#pragma unroll
+    for (int bb = 0; bb < QB; ++bb) {
+        const int qr = wrow0 + bb * 32 + l31;
+        const unsigned int qc = qr < S ? qr : S - 1;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds)
+            qf[bb][ds] = *reinterpret_cast<const bf16x8*>(qb + (qc * ld + ds * 16 + hi * 8));
+    }
+
+    constexpr int KI = 8 / NW;                                   // 2 DMA instructions per wave per K (or V) tile
+    const unsigned int tile_bytes = (unsigned int)KT * ld * 2u;
+    unsigned int kg0, vg0;
+    {
+        const int r = wave * 8 + (lane >> 3), pch = lane & 7;
+        kg0 = ((unsigned int)r * ld + ((pch ^ kswz<D>(r)) * 8)) * 2u;
+        vg0 = ((unsigned int)r * ld + ((pch ^ (((r >> 1) & 1) << 2)) * 8)) * 2u;
+    }
+    const unsigned int kg_step = (unsigned int)(NW * 8) * ld * 2u;
+    auto dma_piece = [&](const unsigned int rs_sel, const int tile, char* slot, const int i) {
+        if (rs_sel == 0) dma16(krs, (unsigned int)tile * tile_bytes + kg0 + i * kg_step, slot + (i * NW + wave) * 1024);
+        else dma16(vrs, (unsigned int)tile * tile_bytes + vg0 + i * kg_step, slot + K_BYTES + (i * NW + wave) * 1024);
+    };
+    auto dma_k = [&](int tile, char* slot) {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) dma_piece(0, tile, slot, i);
+    };
+    auto dma_v = [&](int tile, char* slot) {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) dma_piece(1, tile, slot, i);
+    };
+
+    const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
+    int kfo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kfo[i] = krow_perm * 128 + (((i * 2 + hi) ^ ((krow_perm >> 1) & 7)) << 4);
+    int vb[2];
+    {
+        const int j = (lane & 15) >> 2, p = lane & 3, gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) vb[db] = K_BYTES + (hi * 8 + j) * 128 + ((db ^ (j >> 1)) * 64) + gsel * 32 + p * 8;
+    }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto vfrag = [&](const char* Vs, const int db, const int ks) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4* ltr_t;
+        const char* p = Vs + vb[db] + ks * 2048;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p));
+        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p + 512));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto kfrag = [&](const char* Ks, const int kbk, const int ds) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(Ks + kbk * 4096 + kfo[ds]);
+    };
+
+    f32x16 oacc[QB][2];                // O^T of the four blocks: accumulator half
+    f32x16 sacc[2][2];                 // scores: set b & 1 of block b, [32-key block]
+    u32x4 pw[2][2][2];                 // P as packed bf16: set b & 1, [32-key block][16-key step]
+    bf16x8 kfr[2][4], vfr[2][4];       // the K fragment set [kbk][ds] and the V^T set [db][ks] of the tiles in use
+    float mc[QB], lrun[QB];
+    const float thr = a.thr;
+    int ovf = 0;
+
+    using std::integral_constant;
+    // One phase: softmax of block B on its finished scores, interleaved with the 16 MFMAs O^T(B-1) += V^T P(B-1)^T (m < 8) and
+    // S^T(B+1) = K Q^T (m >= 8).  RK / RV: this is the last phase that uses the K / V^T fragment set -- each fragment is
+    // replaced in place (from Kn / Vn, the next tile's slots) right behind the MFMA that used it last.
+    auto phase = [&](auto B_, const bool need_max, const bool tail, const int kv0, auto RK_, const char* Kn, auto RV_, const char* Vn, auto&& hook) __attribute__((always_inline)) {
+        constexpr int B = decltype(B_)::value, bs = B, bp = (B + 3) & 3, bq = (B + 1) & 3;
+        constexpr bool RK = decltype(RK_)::value, RV = decltype(RV_)::value;
+        constexpr int ss = bs & 1, sq = bq & 1, sp = bp & 1;          // register sets
+        auto mfma_step = [&](const int m) {
+            if (m < 8) {
+                const int db = m & 1, ks = m >> 1;
+                ESME_MFMA32_AV(oacc[bp][db], vfr[db][ks], pw[sp][ks >> 1][ks & 1]);
+                if constexpr (RV && !(ESME_W4_ABL & 4)) vfr[db][ks] = vfrag(Vn, db, ks);
+            } else {
+                const int j = m - 8, kbk = j & 1, ds = j >> 1;
+                if (ds == 0) ESME_MFMA32_VA0(sacc[sq][kbk], kfr[kbk][ds], qf[bq][ds]);
+                else ESME_MFMA32_VA(sacc[sq][kbk], kfr[kbk][ds], qf[bq][ds]);
+                if constexpr (RK && !(ESME_W4_ABL & 4)) kfr[kbk][ds] = kfrag(Kn, kbk, ds);
+            }
+        };
+        float ps0, ps1, ps2, ps3;
+        float pa0 = 0.f, pa1 = 0.f;
+        auto pair_sum_pack = [&](const int p, const float q0_, const float q1_) {
+            const int kbk = p >> 3, r = (2 * p) & 15;
+            pw[ss][kbk][r >> 3][(r & 7) >> 1] = pack_bf16(q0_, q1_);
+            if (p & 1) { ps2 += q0_; ps3 += q1_; } else { ps0 += q0_; ps1 += q1_; }
+        };
+        auto softmax_slot = [&](const int m) {
+            const float q0_ = pa0, q1_ = pa1;
+            const int kb2 = m >> 3, r2 = (2 * m) & 15;
+            pa0 = __builtin_amdgcn_exp2f(sacc[ss][kb2][r2]);
+            pa1 = __builtin_amdgcn_exp2f(sacc[ss][kb2][r2 + 1]);
+            if (m >= 1) pair_sum_pack(m - 1, q0_, q1_);
+            const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
+            asm volatile("" : "+v"(pw[ss][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(pa0), "+v"(pa1));
+        };
+        if (tail) {
+            int lim = S - kv0 - 8 * hi;
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbk * 32 + 16 * (r >> 3) + (r & 7) >= lim) sacc[ss][kbk][r] = -1e30f;
+        }
+        if (need_max) {                      // classic online softmax (the redo pass): exact row maximum, subtracted before the pipelined region
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last S^T MFMA of the previous phase must have written its scores
+            float tmax = sacc[ss][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[ss][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[ss][1][r]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            const float tmc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            if (__any(tmc > mc[bs] + thr)) {
+                const float mn = fmaxf(mc[bs], tmc);
+                const float alpha = __builtin_amdgcn_exp2f(mc[bs] - mn);
+                mc[bs] = mn;
+                lrun[bs] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[bs][i][r] *= alpha;
+            }
+            const float mref = mc[bs];
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[ss][kbk][r] -= mref;
+        }
+        ps0 = ps1 = ps2 = ps3 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            mfma_step(m);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ESME_W4_ABL & 1)) softmax_slot(m);
+            if constexpr (!(ESME_W4_ABL & 2)) hook(m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pair_sum_pack(15, pa0, pa1);
+        const float psum = (ps0 + ps1) + (ps2 + ps3);
+        if (__any(!(psum < 1e30f))) ovf = 1;
+        lrun[bs] += psum;
+    };
+    using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>; using I2 = integral_constant<int, 2>; using I3 = integral_constant<int, 3>;
+    using YES = integral_constant<bool, true>; using NO = integral_constant<bool, false>;
+
+    const int nt = (S + KT - 1) / KT;
+    bool exact = !a.spec;
+    for (;;) {
+#pragma unroll
+        for (int bb = 0; bb < QB; ++bb) {
+            mc[bb] = -1e30f; lrun[bb] = wave_active ? 0.f : 1.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[bb][i][r] = 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[st][i][r] = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) pw[st][i][s_] = u32x4{0u, 0u, 0u, 0u};
+            }
+        dma_k(0, smem);
+        dma_v(0, smem);
+        if (nt > 1) { dma_k(1, smem + SLOT); dma_v(1, smem + SLOT); }
+        if (nt > 2) dma_k(2, smem + 2 * SLOT);
+        {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            char* v3 = smem + 3 * SLOT + K_BYTES;
+#pragma unroll
+            for (int i = 0; i < (D * 128) / (NT * 16); ++i) *reinterpret_cast<u32x4*>(v3 + (i * NT + tid) * 16) = z;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the Q fragments re-defined while no load is in flight: hipcc's wait-count pass otherwise guards their first uses in
+        // the loop with vmcnt(3..0), which drains the tile prefetch issued a few instructions earlier -- see attn_pp64_kernel)
+#pragma unroll
+        for (int bb = 0; bb < QB; ++bb)
+            asm volatile("" : "+a"(qf[bb][0]), "+a"(qf[bb][1]), "+a"(qf[bb][2]), "+a"(qf[bb][3]) : : "memory");
+        __syncthreads();
+        if (wave_active) {
+            // fragment sets: K(0); V^T of slot 3 (zeros: phase (0, 0) multiplies it by P = 0); S^T(b0, tile 0)
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) kfr[kbk][ds] = kfrag(smem, kbk, ds);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) vfr[db][ks] = vfrag(smem + 3 * SLOT, db, ks);
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds)
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk) {
+                    if (ds == 0) ESME_MFMA32_VA0(sacc[0][kbk], kfr[kbk][ds], qf[0][ds]);
+                    else ESME_MFMA32_VA(sacc[0][kbk], kfr[kbk][ds], qf[0][ds]);
+                }
+        }
+        const bool ragged = (S & (KT - 1)) != 0;
+        for (int t = 0; t < nt; ++t) {
+            const bool pf_k = t + 3 < nt, pf_v = t + 2 < nt;
+            char* kslot = smem + ((t + 3) & 3) * SLOT;
+            char* vslot = smem + ((t + 2) & 3) * SLOT;
+            if (wave_active) {
+                const char* cur = smem + (t & 3) * SLOT;
+                const char* nxt = smem + ((t + 1) & 3) * SLOT;
+                const bool tail = t == nt - 1 && ragged;
+                const bool need_max = exact;
+                // phase (0, t): V^T set V(t-1) -> V(t) in place
+                phase(I0{}, need_max, tail, t * KT, NO{}, nxt, YES{}, cur, [&](const int m) { if (m == 5 && pf_k) dma_piece(0, t + 3, kslot, 0); });
+                phase(I1{}, need_max, tail, t * KT, NO{}, nxt, NO{}, cur, [&](const int m) { if (m == 5 && pf_k) dma_piece(0, t + 3, kslot, 1); });
+                // phase (2, t): K set K(t) -> K(t+1) in place
+                phase(I2{}, need_max, tail, t * KT, YES{}, nxt, NO{}, cur, [&](const int m) { if (m == 5 && pf_v) dma_piece(1, t + 2, vslot, 0); });
+                phase(I3{}, need_max, tail, t * KT, NO{}, nxt, NO{}, cur, [&](const int m) { if (m == 5 && pf_v) dma_piece(1, t + 2, vslot, 1); });
+            } else {
+                if (pf_k) dma_k(t + 3, kslot);
+                if (pf_v) dma_v(t + 2, vslot);
+            }
+            if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * KI) : "memory");
+            else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wave_active) {                          // drain: O^T(b3) += V(nt-1) P(b3, nt-1)  (the V^T set still holds V(nt-1))
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) ESME_MFMA32_AV(oacc[3][db], vfr[db][ks], pw[1][ks >> 1][ks & 1]);
+        }
+        if (!exact) {
+#pragma unroll
+            for (int bb = 0; bb < QB; ++bb)
+                if (__any(!(lrun[bb] > 1e-30f))) ovf = 1;
+        }
+        if (exact || !__syncthreads_or(ovf)) break;
+        exact = true;
+        ovf = 0;
+    }
+    if (!wave_active) return;
+
+    // ---- epilogue: normalise, transpose through a wave-private LDS slab (4 KB per wave in a slot no wave reads any more), whole rows out
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the drain MFMAs have written O^T
+    char* slab = smem + ((nt + 1) & 3) * SLOT + wave * 4096;
+#pragma unroll
+    for (int bb = 0; bb < QB; ++bb) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
+        const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+        if (bb) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk = {pack_bf16(oacc[bb][db][4 * g] * inv, oacc[bb][db][4 * g + 1] * inv),
+                            pack_bf16(oacc[bb][db][4 * g + 2] * inv, oacc[bb][db][4 * g + 3] * inv)};
+                *reinterpret_cast<u32x2*>(slab + l31 * 128 + (((db * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int rbase = wrow0 + bb * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * 128 + ((ch ^ (r & 7)) << 4));
+            if (rbase + r < S) *reinterpret_cast<u32x4*>(a.o + (int64_t)(s0 + rbase + r) * a.ldo + h * D + ch * 8) = v;
+        }
+    }
+}
+
+#endif  // ESME_ATTN_W4
+
 }  // namespace esme
 
 using namespace esme;
@@ -1068,6 +1416,28 @@ static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(NW * 64), smem, s, a);
     return check_launch("attn_varlen_fwd");
 }
+
+#ifdef ESME_ATTN_W4
+static int launch_w4(AttnArgs& a, int B, int max_len, hipStream_t s) {
+    constexpr int smem = 4 * (KT * 64 * 2 + 64 * 128);
+    auto kern = attn_w4_kernel;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return fail(ESME_ERR_LAUNCH, "attn: cannot raise the dynamic LDS limit");
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    a.nqt = (max_len + 511) / 512;
+    const int64_t blocks = (int64_t)a.nqt * (((int64_t)a.H * B + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "attn: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(256), smem, s, a);
+    return check_launch("attn_varlen_fwd");
+}
+
+#endif
 
 // (per-call options, esme_attn_opts_t: no process-global tuning state; NULL = the defaults below)
 static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o, int64_t ld_o, const int32_t* cu_lens,
@@ -1100,6 +1470,9 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
         // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
         const int nw = g_attn_variant == 8 ? 8 : 4;
+#ifdef ESME_ATTN_W4
+        if (qp && g_attn_variant == 16) return launch_w4(a, B, max_len, s);          // one wave per SIMD, four q-blocks per wave (lab build)
+#endif
         if (qp && nw == 4) return launch_pp64<4, true>(a, B, max_len, s);
         return nw == 8 ? launch_pp64<8>(a, B, max_len, s) : launch_pp64<4>(a, B, max_len, s);
     }

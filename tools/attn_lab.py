@@ -20,12 +20,13 @@ import torch
 from esme import _hip, synthetic as syn
 
 
-def reference(qkv, cu, H, d):
+def reference(qkv, cu, H, d, scale=None):
     T, E = qkv.shape[0], H * d
     out = torch.empty(T, E, dtype=torch.float32, device=qkv.device)
     q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    scale = d ** -0.5 if scale is None else scale
     for a, b in zip(cu[:-1].tolist(), cu[1:].tolist()):
-        s = torch.einsum('qhd,khd->hqk', q[a:b], k[a:b]) * d ** -0.5
+        s = torch.einsum('qhd,khd->hqk', q[a:b], k[a:b]) * scale
         out[a:b] = torch.einsum('hqk,khd->qhd', torch.softmax(s, -1), v[a:b]).reshape(b - a, E)
     return out
 
@@ -43,6 +44,7 @@ def main():
     ap.add_argument('--thr', default='8')
     ap.add_argument('--scale', type=float, default=1.0, help='std of q and k (scores ~ scale^2 * sqrt(d) * N(0,1) / sqrt(d))')
     ap.add_argument('--order', action='store_true', help='also time every variant with the longest-first dispatch order')
+    ap.add_argument('--qp', action='store_true', help='q pre-multiplied by softmax_scale * log2(e) (esme_attn_opts_t.q_prescaled): what the model runs at head dim 64')
     args = ap.parse_args()
     lib = _hip.load()
     dev = torch.device('cuda', 0)
@@ -57,8 +59,10 @@ def main():
     qkv[:, :2 * E] *= args.scale
     qkv = qkv.to(torch.bfloat16).to(dev)
     cu = cu.to(dev)
+    if args.qp:                      # q' = bf16(q * d^-1/2 * log2 e); the scores are then exponents of 2: softmax(s ln 2)
+        qkv[:, :E] = (qkv[:, :E].float() * (d ** -0.5 * 1.4426950408889634)).to(torch.bfloat16)
     q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
-    ref = reference(qkv, cu.cpu(), H, d)
+    ref = reference(qkv, cu.cpu(), H, d, scale=0.6931471805599453 if args.qp else None)
     flops = 4.0 * E * sum(s * s for s in lengths)
     variants = [int(x) for x in args.variants.split(',')]
     thrs = [float(x) for x in args.thr.split(',')]
@@ -68,7 +72,7 @@ def main():
         for thr in thrs:
             _hip.set_attn_options(variant=var)
             _hip.set_attn_options(thr=thr)
-            o = _hip.attn_varlen(q, k, v, cu, max_len, H)
+            o = _hip.attn_varlen(q, k, v, cu, max_len, H, q_prescaled=args.qp)
             torch.cuda.synchronize()
             err = (o.float() - ref).abs()
             rel = float((o.float() - ref).norm() / ref.norm())
@@ -81,11 +85,11 @@ def main():
     for r in range(args.rounds):
         for var in variants:
             _hip.set_attn_options(variant=var)
-            _hip.attn_varlen(q, k, v, cu, max_len, H, out=out)
+            _hip.attn_varlen(q, k, v, cu, max_len, H, out=out, q_prescaled=args.qp)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(args.iters):
-                _hip.attn_varlen(q, k, v, cu, max_len, H, out=out)
+                _hip.attn_varlen(q, k, v, cu, max_len, H, out=out, q_prescaled=args.qp)
             e.record()
             torch.cuda.synchronize()
             times[var].append(s.elapsed_time(e) / args.iters * 1e3)
