@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void embed_pos_kernel(const int64_t* __restric
                                                         const u32x4* __restrict__ table,
                                                         const u32x4* __restrict__ pos_table,
                                                         const int32_t* __restrict__ pos_idx, int pos_offset,
-                                                        u32x4* __restrict__ out, int64_t T, int chunks, int V, int P,
-                                                        int mask_idx) {
+                                                        u32x4* __restrict__ out, float* __restrict__ out32, int64_t T, int chunks, int V,
+                                                        int P, int mask_idx) {
     const int64_t total = T * chunks;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t t = i / chunks;
@@ -42,7 +42,13 @@ __global__ __launch_bounds__(256) void embed_pos_kernel(const int64_t* __restric
         unpack8(pos_table[(int64_t)p * chunks + c], b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += b[j];
-        out[i] = pack8(a);
+        if (out32) {                          // split-operand ('exact') mode: the sum of two bf16 values, exactly, in fp32
+            float* o = out32 + i * 8;
+            *reinterpret_cast<f32x4*>(o) = f32x4{a[0], a[1], a[2], a[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{a[4], a[5], a[6], a[7]};
+        } else {
+            out[i] = pack8(a);
+        }
     }
 }
 
@@ -917,7 +923,19 @@ extern "C" int esme_hip_embed_positions(const int64_t* tokens, const void* table
                    "embed_positions: E %% 8 != 0 or misaligned");
     const int chunks = E / 8;
     hipLaunchKernelGGL(embed_pos_kernel, dim3(grid_for(T * chunks, 256)), dim3(256), 0, (hipStream_t)stream, tokens,
-                       (const u32x4*)table, (const u32x4*)pos_table, pos_idx, pos_offset, (u32x4*)out, T, chunks, V, P,
+                       (const u32x4*)table, (const u32x4*)pos_table, pos_idx, pos_offset, (u32x4*)out, (float*)nullptr, T, chunks, V, P,
                        mask_idx);
     return check_launch("embed_positions");
+}
+
+extern "C" int esme_hip_embed_positions_f32(const int64_t* tokens, const void* table, const void* pos_table, const int32_t* pos_idx,
+                                            int pos_offset, float* out, int64_t T, int E, int V, int P, int mask_idx, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0 && V > 0 && P > 0, "embed_positions_f32: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(tokens && table && pos_table && pos_idx && out, "embed_positions_f32: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && aligned16(table) && aligned16(pos_table) && aligned16(out), "embed_positions_f32: E %% 8 != 0 or misaligned");
+    const int chunks = E / 8;
+    hipLaunchKernelGGL(embed_pos_kernel, dim3(grid_for(T * chunks, 256)), dim3(256), 0, (hipStream_t)stream, tokens,
+                       (const u32x4*)table, (const u32x4*)pos_table, pos_idx, pos_offset, (u32x4*)nullptr, out, T, chunks, V, P, mask_idx);
+    return check_launch("embed_positions_f32");
 }

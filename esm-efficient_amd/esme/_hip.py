@@ -89,6 +89,7 @@ SIGNATURES = {
     'esme_hip_attn_varlen_fwd_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                                c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_rotary_split': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_embed_positions_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     'esme_hip_softmax_rows_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gemm_bf16': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                    c_int64, c_int, c_int, c_int, c_float, c_void_p]),
@@ -329,10 +330,19 @@ def embed(tokens: torch.Tensor, table: torch.Tensor, mask_idx: int = -1, pad_idx
 
 
 def embed_positions(tokens: torch.Tensor, table: torch.Tensor, pos_table: torch.Tensor, pos_idx: torch.Tensor,
-                    pos_offset: int, mask_idx: int = -1) -> torch.Tensor:
-    """Token rows (`<mask>` zeroed) + learned-position rows pos_table[pos_idx + pos_offset] (ESM-1b / 1v)."""
+                    pos_offset: int, mask_idx: int = -1, f32: bool = False) -> torch.Tensor:
+    """Token rows (`<mask>` zeroed) + learned-position rows pos_table[pos_idx + pos_offset] (ESM-1b / 1v); `f32`: the exact sum in
+    float32 (split-operand mode) instead of its bf16 rounding."""
     tok = tokens.reshape(-1).contiguous()
     V, E = table.shape
+    if f32:
+        out = torch.empty(tok.numel(), E, dtype=torch.float32, device=table.device)
+        _check(load().esme_hip_embed_positions_f32(
+            _dev(tok, 'embed tokens', torch.int64), _dev(table.contiguous(), 'embed table', torch.bfloat16),
+            _dev(pos_table.contiguous(), 'position table', torch.bfloat16),
+            _dev(pos_idx.reshape(-1).contiguous(), 'position index', torch.int32), int(pos_offset), out.data_ptr(),
+            tok.numel(), E, V, pos_table.shape[0], mask_idx, _stream()), 'esme_hip_embed_positions_f32')
+        return out.view(*tokens.shape, E)
     out = torch.empty(tok.numel(), E, dtype=torch.bfloat16, device=table.device)
     _check(load().esme_hip_embed_positions(
         _dev(tok, 'embed tokens', torch.int64), _dev(table.contiguous(), 'embed table', torch.bfloat16),
@@ -486,14 +496,17 @@ def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 
 def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, dim: int,
-                    out: Optional[torch.Tensor] = None, out32: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, out32: Optional[torch.Tensor] = None, in_off: Optional[int] = None,
+                    out_off: Optional[int] = None) -> torch.Tensor:
     """Split-operand ('exact') mode: LayerNorm over `dim` features in fp32 -> (T, 2*dim) bf16 pair [hi | lo] (+ fp32 copy in
-    `out32`).  x: fp32 (T, dim), or a bf16 pair (T, 2*dim) read as hi + lo."""
+    `out32`).  x: fp32 (T, dim), or a bf16 pair (T, 2*dim) read as hi + lo.  `in_off` / `out_off` (elements; default `dim`): where
+    the lo half sits relative to the hi half when x / out are the hi views of a wider pair buffer (the q block of a (T, 6E)
+    projection: in_off = out_off = 3E)."""
     T = x.shape[0]
     pair_in = x.dtype == torch.bfloat16
     if pair_in:
         xp, ldx = _rows2d(x, 'layernorm_split x')
-        if x.shape[1] != 2 * dim:
+        if in_off is None and x.shape[1] != 2 * dim:
             raise ValueError('layernorm_split: a pair input is (T, 2 * dim)')
     else:
         xp, ldx = _rows2d(x, 'layernorm_split x', torch.float32)
@@ -506,9 +519,11 @@ def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     if out32 is not None:
         zp, ldz = _rows2d(out32, 'layernorm_split out32', torch.float32)
     with _Traced('layernorm_split', (T, dim)):
-        _check(load().esme_hip_layernorm_split(xp, ldx, 1 if pair_in else 0, dim, _dev(weight, 'layernorm weight', torch.bfloat16),
+        _check(load().esme_hip_layernorm_split(xp, ldx, 1 if pair_in else 0, dim if in_off is None else int(in_off),
+                                               _dev(weight, 'layernorm weight', torch.bfloat16),
                                                _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
-                                               yp, ldy, dim, zp, ldz, T, dim, float(eps), _stream()), 'esme_hip_layernorm_split')
+                                               yp, ldy, dim if out_off is None else int(out_off), zp, ldz, T, dim, float(eps), _stream()),
+               'esme_hip_layernorm_split')
     return out
 
 

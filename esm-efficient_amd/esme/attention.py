@@ -452,7 +452,8 @@ class FlashTransformerLayer(nn.Module):
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):
-        """One ESM-2 / ESM-1 layer of the split-operand ('exact') mode on the fp32 residual stream `ctx.x32` (updated in place).
+        """One layer (ESM-2 / ESM-1: GELU FFN with biases; ESM-C: q/k LayerNorm, SwiGLU) of the split-operand ('exact') mode on the
+        fp32 residual stream `ctx.x32` (updated in place).
         Every activation that feeds a matrix product travels as a (hi, lo) bf16 pair [hi | lo] (x = hi + lo to 2^-17), every
         GEMM runs over the doubled K against ONE copy of the bf16 weight, the LayerNorms are NOT folded (their gain would have
         to be rounded into the weight) and run in fp32 on the stream, attention multiplies pairs (3 MFMA passes) with exact
@@ -460,26 +461,32 @@ class FlashTransformerLayer(nn.Module):
         fp32 forward (`dtype=torch.float32`, esme/esm.py:132-141) to ~1e-5 relative instead of bf16's ~1e-2; ~2.3x the time
         of the fast mode."""
         att = self.self_attn
-        if self.padded or att.pre_layernorm or self.final_activation != 'gelu' or att.head_pad not in (16, 32, 64):
-            raise NotImplementedError("precision='exact' covers the ESM-2 / ESM-1 block (GELU FFN, head dim 16 / 32 / 64, 64-aligned width)")
+        if self.padded or att.head_pad not in (16, 32, 64):
+            raise NotImplementedError("precision='exact' needs a 64-aligned embedding width and head dim 16 / 32 / 64 "
+                                      "(ESM2-35M's padded layout and ESM2-15B's head dim 128 are not covered)")
         if any(q is not None for q in (att._q4_qkv, att._q4_out, self._q4_up, self._q4_down)):
             raise NotImplementedError("precision='exact' needs unquantised weights")
         x32 = ctx.x32
         T, E = x32.shape
         H, d = att.num_heads, att.head_pad
         alpha = 1.0 / self.residue_scaling
+        gelu = self.final_activation == 'gelu'
+        F = self.final[1].out_features                                                    # FFN width (GELU: 4E; SwiGLU: the rounded 8/3 E)
         sc = ctx.scratch
         if 'h' not in sc:
             dev = x32.device
             sc['h'] = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=dev)          # LayerNorm output pair / attention output pair
             sc['qkv'] = torch.empty(T, 6 * E, dtype=torch.bfloat16, device=dev)        # [q k v hi | q k v lo]
-            sc['mid'] = torch.empty(T, 2 * self.final[1].out_features, dtype=torch.bfloat16, device=dev)
+            sc['mid'] = torch.empty(T, 2 * F, dtype=torch.bfloat16, device=dev)
             sc['x16'] = torch.empty(T, E, dtype=torch.bfloat16, device=dev)            # bf16 rounding of the stream (written by the residual epilogue, unused)
         h, qkv, mid, x16 = sc['h'], sc['qkv'], sc['mid'], sc['x16']
         # ---- attention branch
         _hip.layernorm_split(x32, att.norm.weight, att.norm.bias, att.norm.eps, E, out=h)
         w, b, _, _ = att._weights_qkv(False)
         _hip.gemm_fused(h, w, b, out=qkv, split_a=True, pair_out=True)
+        if att.pre_layernorm:             # ESM-C: q / k LayerNorm over the full width, pair in -> pair out, in place (attention.py:104-105)
+            for blk, ln in ((qkv[:, :E], att.layernorm_q), (qkv[:, E:2 * E], att.layernorm_k)):
+                _hip.layernorm_split(blk, ln.weight, ln.bias, ln.eps, E, out=blk, in_off=3 * E, out_off=3 * E)
         if att.rot_emb is not None:       # fp32 tables (the reference's fp32 forward has them): a pass of its own, not the bf16-table epilogue
             _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
         _hip.attn_varlen_split(qkv, cu_lens, max_len, H, d, att.head_dim ** -0.5, out=h, order=ctx.order)
@@ -489,7 +496,7 @@ class FlashTransformerLayer(nn.Module):
         ln = self.final[0]
         _hip.layernorm_split(x32, ln.weight, ln.bias, ln.eps, E, out=h)
         wu, bu, _, _ = self._weights_up(False)
-        _hip.gemm_fused(h, wu, bu, _hip.EPI_GELU, out=mid, split_a=True, pair_out=True)
+        _hip.gemm_fused(h, wu, bu, _hip.EPI_GELU if gelu else _hip.EPI_SWIGLU, out=mid, split_a=True, pair_out=True)
         wd, bd = self._weights_down()
         _hip.gemm_fused(mid, wd, bd, _hip.EPI_RESIDUAL, None, alpha, x16, resid32=x32, split_a=True)
 

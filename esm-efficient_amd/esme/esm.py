@@ -139,6 +139,12 @@ class ESM2(nn.Module):
                           mask_idx=self.alphabet.mask_idx if self.zero_mask_rows else -1,
                           pad_idx=self.alphabet.padding_idx if (tokens.ndim == 2 and self.zero_mask_rows) else -1)
 
+    def _embedding_exact(self, x, tokens, pad_args, pad_indices):
+        """fp32 residual stream at the start of the split-operand mode: the (bf16, hence exactly representable) embedding rows."""
+        x32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        _hip.residual_f32_(x32, x, 1.0, x, None, init=True)
+        return x32
+
     def _c_forward_ok(self) -> bool:
         from esme.cforward import ModelDescriptor
         return ModelDescriptor.supported(self)
@@ -236,8 +242,7 @@ class ESM2(nn.Module):
             # split-operand mode: fp32 residual stream, activation pairs, fp32 results (esme.attention.FlashTransformerLayer.forward_exact)
             assert not self.padded, "precision='exact' needs a 64-aligned embedding width and a supported head dim"
             T = x.shape[0]
-            ctx.x32 = torch.empty(T, E, dtype=torch.float32, device=x.device)
-            _hip.residual_f32_(ctx.x32, x, 1.0, x, None, init=True)           # the embedding rows, exactly, in fp32
+            ctx.x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
             ctx.order = _hip.seq_order(cu_lens)
             for i, layer in enumerate(self.layers):
                 layer.forward_exact(cu_lens, max_len, ctx)
@@ -416,6 +421,25 @@ class _LearnedPositionESM(ESM2):
         if tokens.ndim == 2:
             x.masked_fill_(tokens.eq(self.alphabet.padding_idx).unsqueeze(-1), 0.0)   # row selection, no arithmetic
         return x
+
+    def _embedding_exact(self, x, tokens, pad_args, pad_indices):
+        """token row + learned-position row summed in fp32 [-> emb_layer_norm_before in fp32 (ESM-1b)] -> `<pad>` rows zeroed: what
+        the reference's fp32 forward starts from (the bf16 path rounds the sum, and ESM-1b's LayerNorm output, to bf16)."""
+        pe = self.embed_positions
+        if tokens.ndim == 2:
+            idx, offset = pe.positions(tokens).to(torch.int32), 0
+        else:
+            idx, offset = _hip.seq_positions(pad_args[0], tokens.numel())[0], pe.padding_idx + 1
+        x32 = _hip.embed_positions(tokens, self.embed_tokens.weight, pe.weight, idx, offset, mask_idx=self.alphabet.mask_idx, f32=True)
+        x32 = x32.view(-1, x32.shape[-1])
+        if self.norm_before:
+            ln = self.emb_layer_norm_before
+            scratch = torch.empty(x32.shape[0], 2 * x32.shape[1], dtype=torch.bfloat16, device=x32.device)
+            _hip.layernorm_split(x32, ln.weight, ln.bias, ln.eps, x32.shape[1], out=scratch, out32=x32)      # fp32 result in place
+        if tokens.ndim == 2:               # (B, S) grid: zero the `<pad>` rows, then keep the rows unpad_input keeps (16-byte chunk copies)
+            x32.masked_fill_(tokens.reshape(-1, 1).eq(self.alphabet.padding_idx), 0.0)
+            x32 = _hip.gather_rows(x32.view(torch.bfloat16), pad_indices).view(torch.float32)
+        return x32
 
     @classmethod
     def create_model(cls, path, checkpointing=False):

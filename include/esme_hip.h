@@ -201,6 +201,11 @@ int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, const void* v, 
 int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const float* cos, const float* sin, const int32_t* pos,
                           int64_t T, int nheads, int d, int max_len, void* stream);
 
+/* esme_hip_embed_positions with an fp32 result (contiguous (T, E)): token row + learned-position row summed exactly -- the embedding of
+ * ESM-1b / ESM-1v in the reference's fp32 forward (esme/esm.py:634-652,694-711). */
+int esme_hip_embed_positions_f32(const int64_t* tokens, const void* table, const void* pos_table, const int32_t* pos_idx,
+                                 int pos_offset, float* out, int64_t T, int E, int V, int P, int mask_idx, void* stream);
+
 /* esme_hip_softmax_rows on fp32 logits (fp32 out): torch.log_softmax / torch.softmax at esme/esm.py:297-298,315-317. */
 int esme_hip_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t T, int V, int log_flag,
                               void* stream);

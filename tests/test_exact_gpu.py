@@ -210,9 +210,45 @@ def test_exact_mode_alone_vs_packed_and_2d_input():
     assert taps.shape == (sum(lengths), 3 * 320) and taps.dtype == torch.float32
 
 
+@pytest.mark.parametrize('fname', ['g4_esmc_tiny.npz', 'g4b_esmc_300m_layer.npz'])
+def test_exact_mode_esmc_vs_reference_fp32_golden(fname):
+    """ESM-C (q/k LayerNorm over the full width, SwiGLU, no biases, residue scaling) in the split-operand mode vs the reference's own
+    fp32 forward."""
+    g = load_golden(fname)
+    model = build(g['kind'], g['L'], g['E'], g['H'], g['seed']).set_precision('exact')
+    tokens, cu, max_len = g['tokens'].to(DEV), g['cu_lens'].to(DEV), g['max_len']
+    logits = model(tokens, (cu, max_len))
+    assert logits.dtype == torch.float32 and logits.shape == g['logits_f32'].shape
+    e = rel_fro(logits.cpu(), g['logits_f32'])
+    rep = model.forward_representation(tokens, (cu, max_len))
+    e_rep = rel_fro(rep.cpu()[g['tap_rows']], g['rep_f32'])
+    print(f'\n[exact] {fname}: logits {e:.2e}, representation {e_rep:.2e} vs the reference fp32 forward')
+    assert e <= 1e-4 and e_rep <= 1e-4, (e, e_rep)
+
+
+@pytest.mark.parametrize('kind', ['esm1b', 'esm1v'])
+def test_exact_mode_esm1_vs_reference_fp32_golden(kind):
+    """ESM-1b / ESM-1v (learned positions summed in fp32, ESM-1b's emb_layer_norm_before in fp32), packed and 2-D padded input."""
+    import os, tempfile
+    from esme import ESM
+    g = load_golden('g10_esm1.npz')
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), kind, g['L'], g['E'], g['H'], seed=g['seed'])
+        model = ESM.from_pretrained(path, device=DEV).set_precision('exact')
+    tokens, cu, ml = g['tokens'].to(DEV), g['cu_lens'].to(DEV), g['max_len']
+    e = rel_fro(model(tokens, (cu, ml)).cpu(), g[f'{kind}_logits_f32'])
+    out2d = model(g['tokens2d'].to(DEV))
+    ref2d = g[f'{kind}_logits2d_f32']
+    keep = g['tokens2d'].ne(model.alphabet.padding_idx)
+    e2 = rel_fro(out2d.cpu()[keep], ref2d[keep])                    # (the reference's pad rows are its head applied to zeros: compared in the bf16 tests)
+    print(f'\n[exact] {kind}: packed logits {e:.2e}, padded logits (real rows) {e2:.2e} vs the reference fp32 forward')
+    assert e <= 1e-4 and e2 <= 1e-4, (e, e2)
+
+
 def test_exact_mode_rejects_what_it_does_not_cover():
-    """ESM-C (q/k LayerNorm, SwiGLU) has no split-operand layer yet: a loud NotImplementedError, never a silent bf16 result."""
-    m = build('esmc', 2, 960, 15, seed=0).set_precision('exact')
+    """Padded layouts (ESM2-35M: E = 480, head dim 24) have no split-operand form: a loud NotImplementedError / AssertionError, never
+    a silent bf16 answer."""
+    m = build('esm2', 2, 480, 20, seed=0).set_precision('exact')
     tokens, cu = syn.random_tokens([40], seed=0), syn.cu_lens_of([40])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises((NotImplementedError, AssertionError)):
         m(tokens.to(DEV), (cu.to(DEV), 40))
