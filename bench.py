@@ -87,7 +87,7 @@ def pmc_traffic():
     profiles/rNN_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  Counters cannot be read
     from inside the process, so this is the last PROFILED value -- a static file, not an observation of this run -- valid
     for the default workload only; (None, None) otherwise."""
-    for name in ('r03_traffic.json', 'r02_traffic.json'):
+    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:
@@ -350,6 +350,8 @@ def main():
         result['multi_gpu'] = multi
         if 'gather_ms' in multi:
             result['multi_gpu']['ms_per_step_incl_gather'] = round(ms_per_step + multi['gather_ms'], 3)
+            # (rounds 1-2 timed the gather inside the step: the comparable whole-job rate under that definition)
+            result['multi_gpu']['value_incl_gather'] = round(world * T / ((ms_per_step + multi['gather_ms']) * 1e-3), 1)
     if rank == 0:
         # ---- instrumented pass: HIP events around every launch on the launch stream
         with torch.no_grad():

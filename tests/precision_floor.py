@@ -12,6 +12,11 @@ shows WHY no mode with bf16 MFMA operands can reach 1e-3, by emulating on the CP
             (the cheap form of an exact mode: the GEMMs run on [hi | lo] x [W | W] with K doubled, attention unchanged).
   split     activations fed as (hi, lo) bf16 pairs -- x ~ bf16(x) + bf16(x - bf16(x)), 3 MFMA passes per GEMM with bf16
             weights (hi*W + lo*W; P and q/k/v likewise) -- i.e. what an 'exact' mode would cost 2-3x the GEMM time for.
+  split-attn:<qk><p><v>  split-gemm plus a choice of WHICH attention operands are pairs ('d') or single bf16 ('s'), e.g.
+            split-attn:ssd = only V.  Round 4 used this table to design attn_split_kernel: V matters most
+            (9.2e-4 -> 4.7e-4), q/k + V reach 2.7e-4, only all three (= 'split') leave two orders of margin under 1e-3.
+  --tables bf16  additionally rounds the rotary tables to bf16 (what the fused QKV epilogue uses): 4.8e-4 on its own, which is why
+            the split-operand mode has its own rotary kernel with fp32 tables.
 
 It lives under tests/ because it is built from oracle/ pieces (only tests, smoke() and bench's CPU leg may import the oracle).
     python tests/precision_floor.py [--layers 33] [--embed 1280] [--heads 20] [--tokens 300]
@@ -39,6 +44,25 @@ def r16(x):
 
 def make_ops(mode):
     """(operand transform, matmul) for one emulation mode.  `operand(x)` returns what the matrix unit is fed."""
+    if mode.startswith('split-attn:'):
+        qk, pp, vv = mode.split(':')[1]
+        lin, _ = make_ops('split')
+        sp = lambda a, m: (r16(a),) if m == 's' else (r16(a), r16(a - r16(a)))
+
+        def mm_qk(a, b_):                            # scores: a = q, b_ = k^T
+            A, B = sp(a, qk), sp(b_, qk)
+            y = A[0] @ B[0]
+            return y + A[0] @ B[1] + A[1] @ B[0] if qk == 'd' else y
+
+        def mm_pv(a, b_):                            # a = P, b_ = v
+            A, B = sp(a, pp), sp(b_, vv)
+            y = A[0] @ B[0]
+            if pp == 'd':
+                y = y + A[1] @ B[0]
+            if vv == 'd':
+                y = y + A[0] @ B[1]
+            return y
+        return lin, (mm_qk, mm_pv)
     if mode in ('split', 'split-gemm'):
         def lin(x, w, b=None):                      # 2 passes for a bf16 weight: (hi + lo) @ W^T
             hi = r16(x)
@@ -62,14 +86,18 @@ def make_ops(mode):
     return lin, mm
 
 
-def forward(weights, heads, tokens, cu_lens, max_len, mode):
-    """ESM-2 packed forward -> logits, fp32 with the operand rounding of `mode` ('ideal', 'stream', 'split-gemm', 'split')."""
+def forward(weights, heads, tokens, cu_lens, max_len, mode, tables='fp32'):
+    """ESM-2 packed forward -> logits, fp32 with the operand rounding of `mode` ('ideal', 'stream', 'split-gemm', 'split',
+    'split-attn:<qk><p><v>')."""
     lin, mm = make_ops(mode)
+    mm_qk, mm_pv = mm if isinstance(mm, tuple) else (mm, mm)
     kind, L, E = O._cfg_of(weights)
     assert kind == 'esm2'
     w = {k: v.float() for k, v in weights.items()}
     d = E // heads
     cos, sin = O.rotary_tables(max_len, d, torch.float32)
+    if tables == 'bf16':
+        cos, sin = r16(cos), r16(sin)
     pos = O.culen_positions(cu_lens)
     x = O.embedding(w, tokens, kind, torch.float32, cu_lens)
     store = r16 if mode == 'stream' else (lambda t: t)
@@ -83,8 +111,8 @@ def forward(weights, heads, tokens, cu_lens, max_len, mode):
         a = torch.empty_like(q)
         for s0, s1 in zip(cu[:-1], cu[1:]):
             qs, ks, vs = (t[s0:s1].transpose(0, 1) for t in (q, k, v))
-            pr = torch.softmax(mm(qs, ks.transpose(1, 2)) / math.sqrt(d), dim=-1)
-            a[s0:s1] = mm(pr, vs).transpose(0, 1)
+            pr = torch.softmax(mm_qk(qs, ks.transpose(1, 2)) / math.sqrt(d), dim=-1)
+            a[s0:s1] = mm_pv(pr, vs).transpose(0, 1)
         x = store(x + lin(a.reshape(-1, E), w[p + 'out.weight'], w[p + 'out.bias']))
         p = f'layers.{i}.final.'
         h = O._ln(x, w[p + '0.weight'], w[p + '0.bias'])
@@ -96,15 +124,17 @@ def forward(weights, heads, tokens, cu_lens, max_len, mode):
     return lin(h, w['lm_head.final.weight'], w['lm_head.final.bias'])
 
 
-def floors(L, E, H, lengths, seed=0):
+def floors(L, E, H, lengths, seed=0, extra=(), tables='fp32'):
     from esme import synthetic as syn
     weights = syn.synthetic_state_dict('esm2', L, E, seed=seed)
     tokens, cu = syn.random_tokens(lengths, seed=seed), syn.cu_lens_of(lengths)
     ref32 = O.forward_logits(weights, H, tokens, cu, max(lengths), torch.float32).float()
     rel = lambda a: float((a - ref32).norm() / ref32.norm())
     out = {'reference-equivalent bf16 forward': rel(O.forward_logits(weights, H, tokens, cu, max(lengths), torch.bfloat16).float())}
-    for mode in ('stream', 'ideal', 'split-gemm', 'split'):
+    for mode in ('stream', 'ideal', 'split-gemm', 'split') + tuple(extra):
         out[mode] = rel(forward(weights, H, tokens, cu, max(lengths), mode))
+    if tables == 'bf16':
+        out['split, bf16 rotary tables'] = rel(forward(weights, H, tokens, cu, max(lengths), 'split', tables='bf16'))
     return out
 
 
@@ -114,10 +144,13 @@ if __name__ == '__main__':
     ap.add_argument('--embed', type=int, default=1280)
     ap.add_argument('--heads', type=int, default=20)
     ap.add_argument('--tokens', type=int, default=300)
+    ap.add_argument('--attn', action='store_true', help='also the split-attn:<qk><p><v> table (which attention operands must be pairs)')
+    ap.add_argument('--tables', choices=['fp32', 'bf16'], default='fp32')
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
     lengths = [a.tokens - a.tokens // 3, a.tokens // 3]
-    res = floors(a.layers, a.embed, a.heads, lengths)
+    extra = tuple(f'split-attn:{q}{p}{v}' for q in 'sd' for p in 'sd' for v in 'sd') if a.attn else ()
+    res = floors(a.layers, a.embed, a.heads, lengths, extra=extra, tables=a.tables)
     print(f'ESM-2 geometry L={a.layers} E={a.embed} H={a.heads}, {a.tokens} residues; rel-Frobenius of the logits vs the fp32-math forward')
     for k, v in res.items():
         print(f'  {k:36s} {v:.3e}')
