@@ -536,15 +536,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             const f32x4 c1q = c1s[q4], c2q = c2s[q4];
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                // two columns per instruction on the packed fp32 pipe (the same IEEE fma per element: every bit as before).  hipcc packs
-                // this by itself next to the rotary epilogue but left it scalar (2 VALU per element) next to the GELU one.
-                const f32x2_t rs = {st[j][0], st[j][0]}, nrm = {-st[j][1], -st[j][1]};
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const f32x2_t t = __builtin_elementwise_fma(nrm, f32x2_t{c1q[e], c1q[e + 1]}, f32x2_t{c2q[e], c2q[e + 1]});
-                    const f32x2_t y = __builtin_elementwise_fma(rs, f32x2_t{acc[i][j][e], acc[i][j][e + 1]}, t);
-                    acc[i][j][e] = y[0]; acc[i][j][e + 1] = y[1];
-                }
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][e] = fmaf(st[j][0], acc[i][j][e], fmaf(-st[j][1], c1q[e], c2q[e]));
             }
         }
     }
@@ -745,10 +739,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         if (m < a.M && n < a.N) *reinterpret_cast<f32x4*>(a.resid32 + m * a.ld32 + n) = f32x4{o[0], o[1], o[2], o[3]};
                     } else if constexpr (EPI == ESME_EPI_RESIDUAL) {
                         const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));
-                        const f32x2_t al = {a.alpha, a.alpha};                    // resid + alpha * o as fma(alpha, o, resid), two columns per instruction
-                        const f32x2_t y0 = __builtin_elementwise_fma(al, f32x2_t{o[0], o[1]}, f32x2_t{bf_lo(rw[0]), bf_hi(rw[0])});
-                        const f32x2_t y1 = __builtin_elementwise_fma(al, f32x2_t{o[2], o[3]}, f32x2_t{bf_lo(rw[1]), bf_hi(rw[1])});
-                        o[0] = y0[0]; o[1] = y0[1]; o[2] = y1[0]; o[3] = y1[1];
+                        o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
+                        o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
                     }
                 }
                 u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
