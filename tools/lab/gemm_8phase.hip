@@ -98,7 +98,10 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
     const int KT = a.K / 64;
     // prologue: tile 0 (4 half-tiles) + the first three half-tiles of tile 1, then wait for tile 0
     stageW(0, 0); stageA(0, 0); stageW(0, 1); stageA(0, 1);
-    if (KT > 1) {
+    if (KT > 1 && (FLAGS & 1024)) {                 // balanced variant: W-h1 of tile 1 goes out in phase A of tile 0
+        stageW(1, 0); stageA(1, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (KT > 1) {
         stageW(1, 0); stageA(1, 0); stageW(1, 1);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
@@ -173,19 +176,28 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     // (prologue above issued tile 0 + W-h0, A-h0, W-h1 of tile 1 and waited for tile 0: matches this schedule's order)
+    // round-4 ablations (timing only, wrong results): FLAGS & 256 = no LDS-DMA inside the loop, & 512 = no fragment reads inside the loop
+    constexpr bool NODMA = (FLAGS & 256) != 0, NORD = (FLAGS & 512) != 0;
+    if (NORD) { rdW2(smem); rdA(smem, 0); }
     for (int kt = 0; kt < KT; ++kt) {
         const char* base = smem + (kt & 1) * BUF;
         const bool m1 = kt + 1 < KT, m2 = kt + 2 < KT;
+        // FLAGS & 1024 (round 4): the 8 LDS-DMA pieces of a K-tile split 4 + 4 over the two read sections instead of 2 + 6 (an
+        // LDS-DMA costs its issuing wave ~60-100 cycles: six of them make phase B's read section longer than the partner's
+        // 512-cycle MFMA burst): phase A stages A-h1 AND W-h1 of tile t+1, phase B stages W-h0, A-h0 of tile t+2, vmcnt(4).
+        // FLAGS & 2048: no vmcnt wait at all (timing only: separates DMA issue cost from latency exposure)
+        constexpr bool BAL = (FLAGS & 1024) != 0, NOWAIT = (FLAGS & 2048) != 0;
         // ---- phase A
-        rdW2(base);
-        rdA(base, 0);
-        if (m1) stageA(kt + 1, 1);
+        if (!NORD) { rdW2(base); rdA(base, 0); }
+        if (m1 && !NODMA) { stageA(kt + 1, 1); if (BAL) stageW(kt + 1, 1); }
         mma2(0);
         // ---- phase B
-        rdA(base, 1);
-        if (m2) { stageW(kt + 2, 0); stageA(kt + 2, 0); stageW(kt + 2, 1); }
-        if (m2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!NORD) rdA(base, 1);
+        if (m2 && !NODMA) { stageW(kt + 2, 0); stageA(kt + 2, 0); if (!BAL) stageW(kt + 2, 1); }
+        if (!NODMA && !NOWAIT) {
+            if (m2) { if (BAL) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         mma2(1);
     }
     } else {
@@ -319,6 +331,12 @@ extern "C" int lab8_run(int flags, const void* A, const void* W, void* C, int64_
         case 49: return launch<33, 16>(a, s);
         case 50: return launch<34, 16>(a, s);
         case 112: return launch<96, 16>(a, s);      // 2 phases per K-tile, direct (no-LDS) epilogue
+        case 1056: return launch<32 + 1024, 16>(a, s);        // 2-phase, balanced DMA (4 + 4), with stores
+        case 1057: return launch<33 + 1024, 16>(a, s);        // ... loop only
+        case 2081: return launch<33 + 2048, 16>(a, s);        // 2-phase loop only, no vmcnt wait (ablation)
+        case 305: return launch<33 + 256, 16>(a, s);          // 2-phase loop only, no LDS-DMA in the loop (ablation)
+        case 561: return launch<33 + 512, 16>(a, s);          // 2-phase loop only, no fragment reads in the loop (ablation)
+        case 817: return launch<33 + 768, 16>(a, s);          // 2-phase loop only, neither (MFMAs + barriers only)
         default: return -4;
     }
 }

@@ -25,12 +25,21 @@ for fill, M, N, K in shapes:
     Cp = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
     fns = {'production': lambda: _hip.gemm(A, W, None, out=Cp)}
+    _hip.gemm(A, W, None, out=Cp); torch.cuda.synchronize()
     if lab8 is not None:
         fns['r3 lab 2-phase 16x16x32'] = lambda: lab8.lab8_run(48, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s)
         fns['r3 lab 2-phase, loop only'] = lambda: lab8.lab8_run(49, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s)
+    for v8 in [int(x) for x in os.environ.get('LAB8_CHECK', '').split(',') if x]:        # full-store lab variants: must equal production bit for bit
+        C.zero_(); lab8.lab8_run(v8, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s); torch.cuda.synchronize()
+        first = C.clone(); bad = 0
+        for _ in range(5):
+            C.zero_(); lab8.lab8_run(v8, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s); torch.cuda.synchronize(); bad += int(not torch.equal(C, first))
+        print(f'  check lab8 v{v8}: bit-identical to production: {torch.equal(first, Cp)}; race screen: {bad} of 5 reruns differ', flush=True)
+        fns[f'r3 2-phase variant {v8}'] = (lambda v8=v8: lab8.lab8_run(v8, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s))
+    for v8 in [int(x) for x in os.environ.get('LAB8_ABL', '').split(',') if x]:
+        fns[f'r3 2-phase loop only, ablation {v8}'] = (lambda v8=v8: lab8.lab8_run(v8, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s))
     for v in variants:
         fns[f'1w v{v}' + (' (loop only)' if v & 1 else '')] = (lambda v=v: lab.lab1w_run(v, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, 0, 0, s))
-    _hip.gemm(A, W, None, out=Cp)
     for v in variants:
         if v & 1: continue
         C.zero_()
