@@ -252,3 +252,25 @@ def test_exact_mode_rejects_what_it_does_not_cover():
     tokens, cu = syn.random_tokens([40], seed=0), syn.cu_lens_of([40])
     with pytest.raises((NotImplementedError, AssertionError)):
         m(tokens.to(DEV), (cu.to(DEV), 40))
+
+
+def test_exact_mode_mask_margin_scores():
+    """predict_mask_margin in the split-operand mode: fp32 scores that match the fp32 oracle to ~1e-5 (absolute, log-prob units)."""
+    from esme.variant import predict_mask_margin
+    model = build('esm2', 2, 320, 20, seed=11).set_precision('exact')
+    w = syn.synthetic_state_dict('esm2', 2, 320, seed=11)
+    seq = 'MKTAYIAKQRQISFVKSHFSRQ'
+    df = predict_mask_margin(model, seq, batch_size=8)
+    assert len(df) == len(seq) * 20
+    alphabet = model.alphabet
+    tok = torch.tensor(alphabet.encode(list(seq)) if hasattr(alphabet, 'encode') else [], dtype=torch.int64)
+    if tok.numel() == 0:
+        pytest.skip('alphabet has no encode()')
+    cu = torch.tensor([0, tok.numel()], dtype=torch.int32)
+    pos = 5                                                     # 1-based residue index == token index after <cls>
+    t = tok.clone(); t[pos] = alphabet.mask_idx
+    lp = torch.log_softmax(O.forward_logits(w, 20, t, cu, tok.numel(), dtype=torch.float32)[pos].float(), -1)
+    aa_idx = [alphabet.token_to_idx[a] for a in alphabet.amino_acids]
+    ref = (lp[aa_idx] - lp[int(tok[pos])]).numpy()
+    got = df['score'].to_numpy().reshape(len(seq), 20)[pos - 1]
+    assert abs(got - ref).max() <= 2e-4, abs(got - ref).max()
