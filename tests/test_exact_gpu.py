@@ -274,3 +274,37 @@ def test_exact_mode_mask_margin_scores():
     ref = (lp[aa_idx] - lp[int(tok[pos])]).numpy()
     got = df['score'].to_numpy().reshape(len(seq), 20)[pos - 1]
     assert abs(got - ref).max() <= 2e-4, abs(got - ref).max()
+
+
+def test_split_entry_points_reject_bad_arguments():
+    """The new C entry points check their arguments before launching anything: wrong pair offsets, unsupported head dims, pair output on
+    the residual epilogue, w_k that does not divide K -- ESME_ERR_ARG / ESME_ERR_UNSUPPORTED with a message, never a launch."""
+    import ctypes
+    lib = _hip.load()
+    x = torch.zeros(16, 6 * 128, dtype=torch.bfloat16, device=DEV)
+    cu = torch.tensor([0, 16], dtype=torch.int32, device=DEV)
+    o = torch.zeros(16, 2 * 128, dtype=torch.bfloat16, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    # head dim 128 is not a split-attention head dim
+    rc = lib.esme_hip_attn_varlen_fwd_split(x.data_ptr(), x.data_ptr() + 256, x.data_ptr() + 512, 768, 384, o.data_ptr(), 256, 128, cu.data_ptr(),
+                                            1, 16, 1, 128, 16, 0.1, None, s)
+    assert rc == -2 and b'head dim' in lib.esme_hip_last_error()
+    # lo offset of the output overlapping the hi block
+    rc = lib.esme_hip_attn_varlen_fwd_split(x.data_ptr(), x.data_ptr() + 256, x.data_ptr() + 512, 768, 384, o.data_ptr(), 256, 64, cu.data_ptr(),
+                                            1, 16, 2, 64, 16, 0.1, None, s)
+    assert rc == -1
+    w = torch.zeros(128, dtype=torch.bfloat16, device=DEV)
+    f32 = torch.zeros(16, 128, dtype=torch.float32, device=DEV)
+    rc = lib.esme_hip_layernorm_split(f32.data_ptr(), 128, 0, 128, w.data_ptr(), None, o.data_ptr(), 256, 64, None, 0, 16, 128, 1e-5, s)
+    assert rc == -1 and b'output layout' in lib.esme_hip_last_error()          # out_off < E
+    rc = lib.esme_hip_rotary_split(x.data_ptr(), 768, 384, f32.data_ptr(), f32.data_ptr(), cu.data_ptr(), 16, 4, 24, 16, s)
+    assert rc == -2                                                              # head dim not a multiple of 16
+    a = torch.zeros(32, 256, dtype=torch.bfloat16, device=DEV)
+    wt = torch.zeros(64, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match='pair output'):
+        _hip.gemm_fused(a, wt, None, _hip.EPI_RESIDUAL, resid=torch.zeros(32, 64, dtype=torch.bfloat16, device=DEV), out=torch.zeros(32, 128, dtype=torch.bfloat16, device=DEV),
+                        split_a=True, pair_out=True)
+    fu = _hip.GemmFusion()
+    fu.w_k = 192                                                                 # does not divide K = 256
+    rc = lib.esme_hip_gemm_bf16_fused(a.data_ptr(), 256, wt.data_ptr(), None, None, 0, o.data_ptr(), 256, 16, 64, 256, 0, 1.0, ctypes.byref(fu), s)
+    assert rc == -1 and b'w_k' in lib.esme_hip_last_error()

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
         const int ng = lb / grp, rg = lb - ng * grp;
         n0 = (ng * a.gn + rg / rows) * 256;
         m0 = ((int64_t)band * a.gm + rg % rows) * 256;
+        if (FLAGS & 4096) { n0 = 0; m0 = 0; }
     }
     // staging sources: half-tile h, instruction i (two per thread per half-tile); chunk swizzle folded into the address
     const u16* srcA[2][2];
@@ -61,17 +62,20 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
             gn = gn < a.N ? gn : a.N - 1;
             srcW[h][i] = a.W + (int64_t)gn * a.K + c * 8;
         }
+    // FLAGS & 4096 (round-4 ablation, timing only): every workgroup stages the SAME 64 KB (tile (0, 0), K-tile 0) over and over: the
+    // LDS-DMA instructions, their TA / L1 / L2 requests and LDS writes remain, the fabric / MALL / HBM traffic is gone
+    constexpr bool HOT = (FLAGS & 4096) != 0;
     auto stageA = [&](int kt, int h) {
         char* base = smem + (kt & 1) * BUF + h * HALF;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[h][i] + kt * 64), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[h][i] + (HOT ? 0 : kt * 64)), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
     };
     auto stageW = [&](int kt, int h) {
         char* base = smem + (kt & 1) * BUF + (2 + h) * HALF;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[h][i] + kt * 64), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[h][i] + (HOT ? 0 : kt * 64)), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
     };
     constexpr int FNW = MF == 32 ? 2 : 4, FMW = MF == 32 ? 4 : 8;          // accumulator fragments of the wave tile: [n][m]
     constexpr int KS = MF == 32 ? 4 : 2;                                     // k-steps per K-tile
@@ -333,7 +337,8 @@ extern "C" int lab8_run(int flags, const void* A, const void* W, void* C, int64_
         case 112: return launch<96, 16>(a, s);      // 2 phases per K-tile, direct (no-LDS) epilogue
         case 1056: return launch<32 + 1024, 16>(a, s);        // 2-phase, balanced DMA (4 + 4), with stores
         case 1057: return launch<33 + 1024, 16>(a, s);        // ... loop only
-        case 2081: return launch<33 + 2048, 16>(a, s);        // 2-phase loop only, no vmcnt wait (ablation)
+        case 2081: return launch<33 + 2048, 16>(a, s);
+        case 4129: return launch<33 + 4096, 16>(a, s);        // 2-phase loop only, every DMA from the same L2-hot 64 KB (ablation)        // 2-phase loop only, no vmcnt wait (ablation)
         case 305: return launch<33 + 256, 16>(a, s);          // 2-phase loop only, no LDS-DMA in the loop (ablation)
         case 561: return launch<33 + 512, 16>(a, s);          // 2-phase loop only, no fragment reads in the loop (ablation)
         case 817: return launch<33 + 768, 16>(a, s);          // 2-phase loop only, neither (MFMAs + barriers only)
