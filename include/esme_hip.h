@@ -142,7 +142,8 @@ int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_
  *   defer_max_thr: online-softmax rescale threshold in log2 units (default 8; 0 = every row maximum exact)
  *   speculative:   head-dim-64 kernel: 1 = speculative softmax (default), 0 = classic online softmax
  *   seq_order:     NULL, or int32 (B): the order in which the sequences' work items are dispatched (esme_hip_seq_order:
- *                  longest first).  Speed only -- results do not depend on it, bit for bit; on ragged batches the long
+ *                  longest first).  MUST be a permutation of 0 .. B-1 (the kernels index cu_lens with it unchecked: a shorter
+ *                  array is read out of bounds, a repeated index leaves another sequence's output rows unwritten).  Speed only -- results do not depend on it, bit for bit; on ragged batches the long
  *                  proteins' workgroups no longer start last (-6 % on a proteome-like 50 000-residue batch).
  *   q_prescaled:   1 = q already carries softmax_scale * log2(e) (the QKV projection folded it in before its bf16 rounding:
  *                  esme_gemm_fusion_t.q_scale; `softmax_scale` is then ignored).  The 4-wave head-dim-64 kernel computes
