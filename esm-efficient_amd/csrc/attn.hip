@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
         for (int i = 0; i < KI; ++i) {
             if (KCH >= 256 * KI || krow[i] < KT) {
                 const int row = krow[i], ch = (int)(koff[i] >> 3);
+                ESME_LDS_CHECK(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4), 16, smem, 2 * BUF);
                 *reinterpret_cast<u32x4*>(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4)) = kreg[i];
             }
         }
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                     const int drow = dq * 4 + dd;
                     const int ch = kq >> 1;                         // 16-B chunk (8 keys) of the V^T row
                     u32x2 out = {e0, e1};
+                    ESME_LDS_CHECK(Vt + drow * 128 + ((ch ^ ((drow >> 1) & 7)) << 4) + (kq & 1) * 8, 8, smem, 2 * BUF);
                     *reinterpret_cast<u32x2*>(Vt + drow * 128 + ((ch ^ ((drow >> 1) & 7)) << 4) + (kq & 1) * 8) = out;
                 }
             }
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                 const int sw = kswz<D>(row);
 #pragma unroll
                 for (int ds = 0; ds < DS; ++ds) {
+                    ESME_LDS_CHECK(rp + (((ds * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
 #pragma unroll
                     for (int b = 0; b < QB; ++b)
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                 for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
+                        ESME_LDS_CHECK(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
                         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
 #pragma unroll
                         for (int b = 0; b < QB; ++b)
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
             for (int i = 0; i < KI; ++i) {
                 if (KCH >= 256 * KI || krow[i] < KT) {
                     const int row = krow[i], ch = (int)(koff[i] >> 3);
+                    ESME_LDS_CHECK(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4), 16, smem, 2 * BUF);
                     *reinterpret_cast<u32x4*>(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4)) = kreg[pt][i];
                 }
             }
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
                         const int drow = dq * 4 + dd;
                         const int ch = kq >> 1;
                         u32x2 out = {e0, e1};
+                        ESME_LDS_CHECK(Vt + drow * 128 + ((ch ^ ((drow >> 1) & 7)) << 4) + (kq & 1) * 8, 8, smem, 2 * BUF);
                         *reinterpret_cast<u32x2*>(Vt + drow * 128 + ((ch ^ ((drow >> 1) & 7)) << 4) + (kq & 1) * 8) = out;
                     }
                 }
@@ -494,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 #pragma unroll
                 for (int ds = 0; ds < DS; ++ds) {
                     const bf16x8 kh = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
+                    ESME_LDS_CHECK(rp + K_BYTES + (((ds * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
                     const bf16x8 kl = *reinterpret_cast<const bf16x8*>(rp + K_BYTES + (((ds * 2 + hi) ^ sw) << 4));
                     sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ds], sacc[kbk], 0, 0, 0);      // small terms first
                     sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][ds], sacc[kbk], 0, 0, 0);
@@ -557,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const bf16x8 vh = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
+                        ESME_LDS_CHECK(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
                         const bf16x8 vl = *reinterpret_cast<const bf16x8*>(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
                         oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pf[0][kbk][s], oacc[i], 0, 0, 0);
                         oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[1][kbk][s], oacc[i], 0, 0, 0);
@@ -691,6 +699,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // the prefetch of a tile that is needed two iterations later.  The kernel does its own accounting instead: counted
     // vmcnt + s_barrier at the end of every key tile.  M0 (the LDS destination) is saved and restored: hipcc owns it.
     auto dma16 = [&](const u32x4 rs, const unsigned int voff, const char* dst) {
+        ESME_LDS_CHECK(dst, 1024, smem, 4 * SLOT);
         const unsigned int d = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)dst);
         unsigned int keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -758,6 +767,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     auto vfrag = [&](const char* Vs, const int db, const int ks) -> bf16x8 {
         typedef __attribute__((address_space(3))) s16x4* ltr_t;
         const char* p = Vs + vb[db] + ks * 2048;
+        ESME_LDS_CHECK(p, 8, smem, 4 * SLOT); ESME_LDS_CHECK(p + 512, 8, smem, 4 * SLOT);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p));
         const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p + 512));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -776,6 +786,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // S^T): an MFMA never follows one on the same accumulator with VALU instructions in between (a 43-cycle cliff).
     auto frag = [&](int m, const char* Ks, const char* Vs) -> bf16x8 {
         if (m < 8) return vfrag(Vs, m & 1, m >> 1);
+        ESME_LDS_CHECK(Ks + (m & 1) * 4096 + kfo[(m - 8) >> 1], 16, smem, 4 * SLOT);
         return *reinterpret_cast<const bf16x8*>(Ks + (m & 1) * 4096 + kfo[(m - 8) >> 1]);
     };
 
@@ -1032,6 +1043,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk = {pack_bf16(oacc[bb][db][4 * g] * inv, oacc[bb][db][4 * g + 1] * inv),
                             pack_bf16(oacc[bb][db][4 * g + 2] * inv, oacc[bb][db][4 * g + 3] * inv)};
+                ESME_LDS_CHECK(slab + l31 * 128 + (((db * 4 + g) ^ (l31 & 7)) << 4) + hi * 8, 8, smem, 4 * SLOT);
                 *reinterpret_cast<u32x2*>(slab + l31 * 128 + (((db * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = pk;
             }
         __builtin_amdgcn_wave_barrier();
@@ -1039,6 +1051,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int r = it * 8 + (lane >> 3), ch = lane & 7;
+            ESME_LDS_CHECK(slab + r * 128 + ((ch ^ (r & 7)) << 4), 16, smem, 4 * SLOT);
             const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * 128 + ((ch ^ (r & 7)) << 4));
             if (rbase + r < S) *reinterpret_cast<u32x4*>(a.o + (int64_t)(s0 + rbase + r) * a.ldo + h * D + ch * 8) = v;
         }

@@ -17,6 +17,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 static constexpr int kWave = 64;
 
+// Debug build only (`make DEBUG=1` -> libesme_hip_debug.so, never shipped; SURVEY.md section 5: there is no compute-sanitizer for
+// ROCm): every LDS access of the tiled kernels -- LDS-DMA destinations, fragment reads, result slabs, statistics / table strips --
+// checks its byte range against the workgroup's allocation and traps when it falls outside (the launch then fails with a queue
+// error, i.e. the test that drove it fails).  tools/debug_lds_check.sh runs the kernel tests against that build.
+#ifdef ESME_DEBUG_LDS
+#ifndef ESME_DEBUG_LDS_SHRINK
+#define ESME_DEBUG_LDS_SHRINK 0     // negative control: pretend the allocation is this many bytes smaller -- the asserts must then fire
+#endif
+#define ESME_LDS_CHECK(ptr, bytes, base, limit) \
+    do { const long o_ = (const char*)(ptr) - (const char*)(base); if (o_ < 0 || o_ + (long)(bytes) > (long)(limit) - ESME_DEBUG_LDS_SHRINK) __builtin_trap(); } while (0)
+#else
+#define ESME_LDS_CHECK(ptr, bytes, base, limit) do {} while (0)
+#endif
+
 __device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((unsigned int)h) << 16); }

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     static_assert(EPI != ESME_EPI_SWIGLU || WTN == 64, "swiglu needs 64-wide wave tiles");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDS_BYTES = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);      // = launch_one's request
+    (void)LDS_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     auto stage_piece = [&](int kt, int buf, int p) {
         char* base = smem + buf * STAGE;
         const int k0 = kt * BK;
+        ESME_LDS_CHECK(p < IA ? base + (p * NW + wave) * 1024 : base + A_ROWS_BYTES + ((p - IA) * NW + wave) * 1024, 1024, smem, 2 * STAGE);
         if (p < IA) __builtin_amdgcn_global_load_lds((gptr_t)(srcA[p] + k0), (lptr_t)(base + (p * NW + wave) * 1024), 16, 0, 0);
         else __builtin_amdgcn_global_load_lds((gptr_t)(srcW[p - IA] + w_k0(kt)),
                                               (lptr_t)(base + A_ROWS_BYTES + ((p - IA) * NW + wave) * 1024), 16, 0, 0);
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int p = lpos[wm * WTM + r];
                 const u16* src = (c < CPRW / 2) ? a.cosT + (int64_t)p * ROTD + c * 8
                                                 : a.sinT + (int64_t)p * ROTD + (c - CPRW / 2) * 8;
+                ESME_LDS_CHECK(tab + g * 1024, 1024, smem, 2 * STAGE);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tab + g * 1024), 16, 0, 0);
             }
         }
@@ -302,11 +306,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const float inv = 1.0f / (float)a.ln_dim;
                 const float mean = s1 * inv;
                 const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
+                ESME_LDS_CHECK(&lnst[tid], 8, smem, LDS_BYTES);
                 lnst[tid] = f32x2{rstd, rstd * mean};
             }
             if (tid < BN / 4) {                                     // this tile's c1 / c2 columns -> LDS strip
                 int n = n0 + tid * 4;
                 n = n < a.N - 4 ? n : a.N - 4;
+                ESME_LDS_CHECK(&c2s[tid], 16, smem, LDS_BYTES);
                 c1s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c1 + n);
                 c2s[tid] = *reinterpret_cast<const f32x4*>(a.ln_c2 + n);
             }
@@ -358,13 +364,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
         for (int i = 0; i < FN; ++i)                                   // fragment i = half-tile i / 2, 16-row block i % 2
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fw[i][ks] = *reinterpret_cast<const bf16x8*>(base + rowW + (i >> 1) * HALFB + (i & 1) * 16 * 128 + coff[ks]);
+            for (int ks = 0; ks < 2; ++ks) {
+                ESME_LDS_CHECK(base + rowW + (i >> 1) * HALFB + (i & 1) * 16 * 128 + coff[ks], 16, smem, 2 * STAGE);
+                fw[i][ks] = *reinterpret_cast<const bf16x8*>(base + rowW + (i >> 1) * HALFB + (i & 1) * 16 * 128 + coff[ks]);
+            }
     };
     auto rdAh = [&](const char* base, const int h) {
 #pragma unroll
         for (int f = 0; f < FMH; ++f)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *reinterpret_cast<const bf16x8*>(base + rowA + h * HALFB + f * 16 * 128 + coff[ks]);
+            for (int ks = 0; ks < 2; ++ks) {
+                ESME_LDS_CHECK(base + rowA + h * HALFB + f * 16 * 128 + coff[ks], 16, smem, 2 * STAGE);
+                fa[f][ks] = *reinterpret_cast<const bf16x8*>(base + rowA + h * HALFB + f * 16 * 128 + coff[ks]);
+            }
     };
     auto mma = [&](const int j0) {                                    // all W fragments x A half-tile (accumulator rows j0 .. j0 + 3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -440,9 +452,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             const int i = m / FMH, j = m % FMH;            // weight fragment held for FMH MFMAs
             acc[i][h * FMH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[i], ca.v[j], acc[i][h * FMH + j], 0, 0, 0);
             if (neww && j == FMH - 1) {
-                if (rd_on) w.v[i] = *reinterpret_cast<const bf16x8*>(nbase + rowW + i * 16 * 128 + coff[nks]);
+                if (rd_on) { ESME_LDS_CHECK(nbase + rowW + i * 16 * 128 + coff[nks], 16, smem, 2 * STAGE); w.v[i] = *reinterpret_cast<const bf16x8*>(nbase + rowW + i * 16 * 128 + coff[nks]); }
             } else if (na_next < FMH) {
-                if (rd_on) na.v[na_next] = *reinterpret_cast<const bf16x8*>(nbase + rowA + (nh * FMH + na_next) * 16 * 128 + coff[nks]);
+                if (rd_on) { ESME_LDS_CHECK(nbase + rowA + (nh * FMH + na_next) * 16 * 128 + coff[nks], 16, smem, 2 * STAGE); na.v[na_next] = *reinterpret_cast<const bf16x8*>(nbase + rowA + (nh * FMH + na_next) * 16 * 128 + coff[nks]); }
                 ++na_next;
             }
 #pragma unroll
@@ -689,6 +701,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 m = m < a.M ? m : a.M - 1;
                 int n = nw0 + c * 8;
                 n = n < a.N - 8 ? n : a.N - 8;
+                ESME_LDS_CHECK(slab + it * 1024, 1024, smem, 2 * STAGE);
                 __builtin_amdgcn_global_load_lds((gptr_t)(a.resid + m * a.ldr + n), (lptr_t)(slab + it * 1024), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -748,6 +761,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     acc[i][j][0] = o[0] - bf_lo(pk[0]); acc[i][j][1] = o[1] - bf_hi(pk[0]);
                     acc[i][j][2] = o[2] - bf_lo(pk[1]); acc[i][j][3] = o[3] - bf_hi(pk[1]);
                 }
+                ESME_LDS_CHECK(slab + slab_off(r, cl), 8, smem, 2 * STAGE);
                 *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = pk;
             }
             if constexpr (EPI == ESME_EPI_RESIDUAL && !R32) __builtin_amdgcn_sched_barrier(0);   // keep the slab reads of later fragments from being hoisted (VGPRs)
@@ -795,6 +809,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             for (int it = 0; it < RPP / RPI; ++it) {
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + pass * RPP + r;
+                ESME_LDS_CHECK(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4), 16, smem, 2 * STAGE);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (col_ok && m < a.M && ESME_TUNE_STORE_OK) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n + (PAIR ? half * a.pair_off : 0)) = v;
                 if constexpr (STATS) {
@@ -809,6 +824,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);      // lane ^ 1
                     t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);      // lane ^ 2
                     t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);    // lane -> 7 - lane (other quad)
+                    ESME_LDS_CHECK(&blkst[wn * BM + wm * WTM + pass * RPP + r], 8, smem, LDS_BYTES);
                     if (ch == 0) blkst[wn * BM + wm * WTM + pass * RPP + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
                 }
             }

@@ -65,17 +65,34 @@ __global__ __launch_bounds__(512) void gemm_8phase(const Args a) {
     // FLAGS & 4096 (round-4 ablation, timing only): every workgroup stages the SAME 64 KB (tile (0, 0), K-tile 0) over and over: the
     // LDS-DMA instructions, their TA / L1 / L2 requests and LDS writes remain, the fabric / MALL / HBM traffic is gone
     constexpr bool HOT = (FLAGS & 4096) != 0;
+    // FLAGS & 8192 (round 4): the LDS-DMA through buffer descriptors (one SRD per operand, a per-lane 32-bit byte offset that is
+    // constant over the K loop, the K-tile offset in an SGPR) instead of 64-bit per-lane global addresses
+    constexpr bool BUFD = (FLAGS & 8192) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(a.W), 0, 0x7fffffff, 0x00020000);
+    unsigned int offA[2][2], offW[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            offA[h][i] = (unsigned int)((const char*)srcA[h][i] - (const char*)a.A);
+            offW[h][i] = (unsigned int)((const char*)srcW[h][i] - (const char*)a.W);
+        }
     auto stageA = [&](int kt, int h) {
         char* base = smem + (kt & 1) * BUF + h * HALF;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[h][i] + (HOT ? 0 : kt * 64)), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (BUFD) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(base + (i * 8 + wave) * 1024), 16, offA[h][i], kt * 128, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)(srcA[h][i] + (HOT ? 0 : kt * 64)), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
     };
     auto stageW = [&](int kt, int h) {
         char* base = smem + (kt & 1) * BUF + (2 + h) * HALF;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcW[h][i] + (HOT ? 0 : kt * 64)), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (BUFD) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(base + (i * 8 + wave) * 1024), 16, offW[h][i], kt * 128, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)(srcW[h][i] + (HOT ? 0 : kt * 64)), (lptr_t)(base + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
     };
     constexpr int FNW = MF == 32 ? 2 : 4, FMW = MF == 32 ? 4 : 8;          // accumulator fragments of the wave tile: [n][m]
     constexpr int KS = MF == 32 ? 4 : 2;                                     // k-steps per K-tile
@@ -338,7 +355,9 @@ extern "C" int lab8_run(int flags, const void* A, const void* W, void* C, int64_
         case 1056: return launch<32 + 1024, 16>(a, s);        // 2-phase, balanced DMA (4 + 4), with stores
         case 1057: return launch<33 + 1024, 16>(a, s);        // ... loop only
         case 2081: return launch<33 + 2048, 16>(a, s);
-        case 4129: return launch<33 + 4096, 16>(a, s);        // 2-phase loop only, every DMA from the same L2-hot 64 KB (ablation)        // 2-phase loop only, no vmcnt wait (ablation)
+        case 4129: return launch<33 + 4096, 16>(a, s);
+        case 8224: return launch<32 + 8192, 16>(a, s);        // 2-phase, LDS-DMA through buffer descriptors, with stores
+        case 8225: return launch<33 + 8192, 16>(a, s);        // ... loop only        // 2-phase loop only, every DMA from the same L2-hot 64 KB (ablation)        // 2-phase loop only, no vmcnt wait (ablation)
         case 305: return launch<33 + 256, 16>(a, s);          // 2-phase loop only, no LDS-DMA in the loop (ablation)
         case 561: return launch<33 + 512, 16>(a, s);          // 2-phase loop only, no fragment reads in the loop (ablation)
         case 817: return launch<33 + 768, 16>(a, s);          // 2-phase loop only, neither (MFMAs + barriers only)
