@@ -654,13 +654,21 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 // score pair in a loop that is bound by the VALU port (-5 % at S = 500, -8 % at S = 1 002).  fp32 / bf16 hold P from 2^-126 to
 // 2^127; a row sum that overflows (>= 1e30) or vanishes (<= 1e-30) flags the work item, which is redone with the classic online
 // softmax (the row maximum subtracted before the pipelined region), exactly as for the speculative pass of the plain form.
-template <int NW, bool QP = false>
+// Head dim 32 (round 4: ESM2-150M, BASELINE config 2; ESM2-35M through its padded layout): the same kernel with D = 32 -- K / V rows of
+// 64 B (tiles of 4 KB, one LDS-DMA piece per wave and tile), two k-steps per S^T block and ONE 32-row block of O^T, i.e. 8 MFMAs per
+// phase against the same 16 score pairs: two pairs per MFMA slot.  The VALU port bounds it harder than head dim 64 (the softmax work
+// per score is the same, the MFMA work half), but the ping-pong schedule, the LDS-DMA data path and the speculative softmax carry over.
+template <int NW, bool QP = false, int D = 64>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
-    constexpr int D = 64, DS = 4, NT = NW * 64;
-    constexpr int K_BYTES = KT * D * 2;          // 8 KB
-    constexpr int SLOT = K_BYTES + D * 128;      // K tile [64 keys][64] + V^T tile [64][64 keys]
+    constexpr int DS = D / 16, DB = D / 32, NT = NW * 64;
+    constexpr int ROWB = D * 2;                  // bytes per K / V row
+    constexpr int K_BYTES = KT * D * 2;          // 8 KB (head dim 64) / 4 KB (32)
+    constexpr int SLOT = K_BYTES + D * 128;      // K tile [64 keys][D] + V tile [64 keys][D]
     constexpr int ROWS = NW * 64;
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int NPV = 4 * DB, NQK = 2 * DS, NM = NPV + NQK;      // MFMAs of a phase: O^T += V^T P^T, then S^T = K Q^T (16 / 8)
+    constexpr int PPS = 16 / NM;                 // score pairs per MFMA slot (1 / 2)
+    static_assert(D == 64 || D == 32, "head dims 64 and 32");
+    static_assert(NW == 4 || (NW == 8 && D == 64), "4 waves (8: head dim 64 only)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -723,15 +731,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // wave instruction, no VGPR round trip, no ds_write): the LDS image is lane-linear, so the chunk swizzle is applied
     // to the per-lane SOURCE address; rows past the sequence end read as zeros (descriptor bounds).  V stays row-major
     // ([key][d], as in HBM): the V^T fragments of the second MFMA are gathered by ds_read_b64_tr_b16 (below).
-    constexpr int KI = 8 / NW;                                   // DMA instructions per wave per K (or V) tile (2 or 1)
+    constexpr int KI = K_BYTES / (NW * 1024);                    // DMA instructions per wave per K (or V) tile (2 or 1)
+    constexpr int CPR = D / 8;                                   // 16-B chunks per row; a 1 KB piece = 64 / CPR rows
     const unsigned int tile_bytes = (unsigned int)KT * ld * 2u;
     unsigned int kg0, vg0;                                       // byte offset of this lane's chunk inside a tile (piece 0)
     {
-        const int r = wave * 8 + (lane >> 3), pch = lane & 7;    // LDS row / chunk position this lane fills
+        const int r = wave * (64 / CPR) + lane / CPR, pch = lane % CPR;    // LDS row / chunk position this lane fills
         kg0 = ((unsigned int)r * ld + ((pch ^ kswz<D>(r)) * 8)) * 2u;
-        vg0 = ((unsigned int)r * ld + ((pch ^ (((r >> 1) & 1) << 2)) * 8)) * 2u;   // V: 64-B halves swapped on rows 2, 3 (mod 4)
+        // V, head dim 64: 64-B halves swapped on rows 2, 3 (mod 4); head dim 32: rows of 64 B as they are (the 32 lanes of a transposing
+        // read cover 4 rows x 64 B = one whole 256-B bank row)
+        vg0 = ((unsigned int)r * ld + ((D == 64 ? (pch ^ (((r >> 1) & 1) << 2)) : pch) * 8)) * 2u;
     }
-    const unsigned int kg_step = (unsigned int)(NW * 8) * ld * 2u;   // piece i: rows + NW*8 (same swizzles: NW*8 is a multiple of 16)
+    const unsigned int kg_step = (unsigned int)(NW * (64 / CPR)) * ld * 2u;   // piece i: rows + NW * 64 / CPR (same swizzles: a multiple of 16 rows)
     auto dma_k = [&](int tile, char* slot) {
         const unsigned int base = (unsigned int)tile * tile_bytes + kg0;
 #pragma unroll
@@ -748,32 +759,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // ---- per-lane LDS fragment offsets.  K row fed to MFMA row i: bits 2 and 3 of i swapped (P lands in the
     // B-operand layout of the second MFMA); the chunk swizzles do not depend on the 32-row block.
     const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
-    int kfo[4];
+    int kfo[DS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kfo[i] = krow_perm * 128 + (((i * 2 + hi) ^ ((krow_perm >> 1) & 7)) << 4);
+    for (int i = 0; i < DS; ++i) kfo[i] = krow_perm * ROWB + (((i * 2 + hi) ^ kswz<D>(krow_perm)) << 4);
     // V^T fragment (A operand of O^T += V^T P^T: row = d, k = key) of 32-d block db, 16-key step ks: two transposing
     // reads of 4 keys each.  ds_read_b64_tr_b16 works on 16-lane groups: lane 4j + p of a group SUPPLIES the 8 bytes
     // V[key j][4p .. 4p+3] of a [4 keys][16 d] block, lane c RECEIVES column c (V[key 0..3][c]).  Lane (l31, hi) of the
     // MFMA wants d = l31, keys hi*8 + 0..7: group (lane >> 4) & 1 covers d 0..15 / 16..31, so this lane supplies row
     // hi*8 + j (+4 for the second read), bytes gsel*32 + p*8 of the 64-B half that holds block db (halves swapped on rows
     // with bit 1 set: the four 64-B row pieces of a 32-lane group fall into four different 16-bank quarters).
-    int vb[2];
+    int vb[DB];
     {
         const int j = (lane & 15) >> 2, p = lane & 3, gsel = (lane >> 4) & 1;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) vb[db] = K_BYTES + (hi * 8 + j) * 128 + ((db ^ (j >> 1)) * 64) + gsel * 32 + p * 8;
+        for (int db = 0; db < DB; ++db) vb[db] = K_BYTES + (hi * 8 + j) * ROWB + (D == 64 ? ((db ^ (j >> 1)) * 64) : 0) + gsel * 32 + p * 8;
     }
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     auto vfrag = [&](const char* Vs, const int db, const int ks) -> bf16x8 {
         typedef __attribute__((address_space(3))) s16x4* ltr_t;
-        const char* p = Vs + vb[db] + ks * 2048;
-        ESME_LDS_CHECK(p, 8, smem, 4 * SLOT); ESME_LDS_CHECK(p + 512, 8, smem, 4 * SLOT);
+        const char* p = Vs + vb[db] + ks * (16 * ROWB);
+        ESME_LDS_CHECK(p, 8, smem, 4 * SLOT); ESME_LDS_CHECK(p + 4 * ROWB, 8, smem, 4 * SLOT);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p));
-        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p + 512));
+        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p + 4 * ROWB));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
-    f32x16 oacc[2][2], sacc[2][2];
+    f32x16 oacc[2][DB], sacc[2][2];
     u32x4 pw[2][2][2];                 // P of block bb as packed bf16: [bb][32-key block][16-key step]
     float mc[2], lrun[2];
     const float c = a.scale_log2, thr = a.thr;
@@ -785,9 +796,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // Consecutive MFMAs alternate between the two accumulators of a contraction (32-row blocks of O^T, 32-key blocks of
     // S^T): an MFMA never follows one on the same accumulator with VALU instructions in between (a 43-cycle cliff).
     auto frag = [&](int m, const char* Ks, const char* Vs) -> bf16x8 {
-        if (m < 8) return vfrag(Vs, m & 1, m >> 1);
-        ESME_LDS_CHECK(Ks + (m & 1) * 4096 + kfo[(m - 8) >> 1], 16, smem, 4 * SLOT);
-        return *reinterpret_cast<const bf16x8*>(Ks + (m & 1) * 4096 + kfo[(m - 8) >> 1]);
+        if (m < NPV) return vfrag(Vs, m % DB, m / DB);
+        ESME_LDS_CHECK(Ks + ((m - NPV) & 1) * (32 * ROWB) + kfo[(m - NPV) >> 1], 16, smem, 4 * SLOT);
+        return *reinterpret_cast<const bf16x8*>(Ks + ((m - NPV) & 1) * (32 * ROWB) + kfo[(m - NPV) >> 1]);
     };
 
     // One phase: softmax of block BS on its finished scores, interleaved with the 16 MFMAs of block BM.
@@ -798,9 +809,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         fr[0] = frag(0, Ks, Vs);
         fr[1] = frag(1, Ks, Vs);
         auto mfma_step = [&](int m) {
-            if (m + 2 < 16) fr[(m + 2) % 3] = frag(m + 2, Ks, Vs);
-            if (m >= 8) {
-                const int j = m - 8, kbk = j & 1, ds = j >> 1;
+            if (m + 2 < NM) fr[(m + 2) % 3] = frag(m + 2, Ks, Vs);
+            if (m >= NPV) {
+                const int j = m - NPV, kbk = j & 1, ds = j >> 1;
                 if (ds == 0) {
                     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     sacc[bm][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % 3], qf[bm][ds], z, 0, 0, 0);
@@ -808,7 +819,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                     sacc[bm][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % 3], qf[bm][ds], sacc[bm][kbk], 0, 0, 0);
                 }
             } else {
-                const int db = m & 1, ks = m >> 1;
+                const int db = m % DB, ks = m / DB;
                 oacc[bm][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     fr[m % 3], __builtin_bit_cast(bf16x8, pw[bm][ks >> 1][ks & 1]), oacc[bm][db], 0, 0, 0);
             }
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack_bf16(q0, q1);
             if (p & 1) { ps2 += q0; ps3 += q1; } else { ps0 += q0; ps1 += q1; }
         };
-        auto softmax_slot = [&](const int m, const float nm) {      // m = 0..15
+        auto softmax_slot = [&](const int m, const float nm) {      // pair step m = 0..15 (one per MFMA slot at head dim 64, two at 32)
             const float q0 = pa0, q1 = pa1;                  // P of pair m - 1
             if constexpr (QP) {                              // the scores are the exponents (the exact pass has subtracted the maximum already)
                 const int kb2 = m >> 3, r2 = (2 * m) & 15;
@@ -867,7 +878,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             mc[bs] = mn;
             lrun[bs] *= alpha;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < DB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[bs][i][r] *= alpha;
         };
@@ -902,10 +913,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         const float nm = -mc[bs];
         if constexpr (!QP) pair_fma(0, nm);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
+        for (int m = 0; m < NM; ++m) {
             mfma_step(m);
             __builtin_amdgcn_sched_barrier(0);
-            softmax_slot(m, nm);
+#pragma unroll
+            for (int u = 0; u < PPS; ++u) softmax_slot(m * PPS + u, nm);
             hook(m);                                         // this wave's share of the prefetch DMAs (issued under an MFMA)
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -931,7 +943,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     #pragma unroll
             for (int i = 0; i < 2; ++i) {
     #pragma unroll
-                for (int r = 0; r < 16; ++r) { oacc[bb][i][r] = 0.f; sacc[bb][i][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { if (i < DB) oacc[bb][i < DB ? i : 0][r] = 0.f; sacc[bb][i][r] = 0.f; }
     #pragma unroll
                 for (int s = 0; s < 2; ++s) pw[bb][i][s] = u32x4{0u, 0u, 0u, 0u};
             }
@@ -944,8 +956,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         // wait-count pass otherwise carries "the Q loads may still be pending" into the loop header and guards their
         // first uses with s_waitcnt vmcnt(3..0) -- which, in steady state, drains the staging loads issued at the top of
         // the same iteration (an HBM latency per key tile; the kernel ran 1.7x slower on long sequences).
-        asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]),
-                          "+v"(qf[1][0]), "+v"(qf[1][1]), "+v"(qf[1][2]), "+v"(qf[1][3]) : : "memory");
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int ds = 0; ds < DS; ds += 2) asm volatile("" : "+v"(qf[bb][ds]), "+v"(qf[bb][ds + 1]) : : "memory");
         {
             const u32x4 z = {0u, 0u, 0u, 0u};
             char* v3 = smem + 3 * SLOT + K_BYTES;
@@ -959,7 +973,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             for (int ds = 0; ds < DS; ++ds)
     #pragma unroll
                 for (int kbk = 0; kbk < 2; ++kbk) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kbk * 4096 + kfo[ds]);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kbk * (32 * ROWB) + kfo[ds]);
                     sacc[0][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ds], sacc[0][kbk], 0, 0, 0);
                 }
         }
@@ -988,11 +1002,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 const bool need_max = exact || (!QP && t == 0);
                 phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT, [&](const int m) {
                     if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_k) dma_piece(0, t + 3, kslot, 0); if (m == ESME_ATTN_DMA1 && pf_k) dma_piece(0, t + 3, kslot, KI - 1); }
-                    else if (m == 7 && pf_k) dma_piece(0, t + 3, kslot, 0);
+                    else if (m == NM / 2 - 1 && pf_k) dma_piece(0, t + 3, kslot, 0);
                 });
                 phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT, [&](const int m) {
                     if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_v) dma_piece(1, t + 2, vslot, 0); if (m == ESME_ATTN_DMA1 && pf_v) dma_piece(1, t + 2, vslot, KI - 1); }
-                    else if (m == 7 && pf_v) dma_piece(1, t + 2, vslot, 0);
+                    else if (m == NM / 2 - 1 && pf_v) dma_piece(1, t + 2, vslot, 0);
                 });
             } else {
                 if (pf_k) dma_k(t + 3, kslot);
@@ -1012,7 +1026,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
     #pragma unroll
-                for (int db = 0; db < 2; ++db) {
+                for (int db = 0; db < DB; ++db) {
                     const bf16x8 vf = vfrag(Vs, db, ks);
                     oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks >> 1][ks & 1]),
                                                                           oacc[1][db], 0, 0, 0);
@@ -1031,28 +1045,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 
     // ---- epilogue: normalise, transpose through a wave-private LDS slab (a slot no wave reads any more: every
     // wave passed the loop's last barrier, only V of tile nt-1 is still in use), store whole 128-B rows
-    char* slab = smem + ((nt + (wave >> 2)) & 3) * SLOT + (wave & 3) * 4096;
+    constexpr int OCH = D / 8;                              // 16-B chunks per output row
+    char* slab = smem + ((nt + (wave >> 2)) & 3) * SLOT + (wave & 3) * (32 * ROWB);
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
         const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
         if (bb) __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk = {pack_bf16(oacc[bb][db][4 * g] * inv, oacc[bb][db][4 * g + 1] * inv),
                             pack_bf16(oacc[bb][db][4 * g + 2] * inv, oacc[bb][db][4 * g + 3] * inv)};
-                ESME_LDS_CHECK(slab + l31 * 128 + (((db * 4 + g) ^ (l31 & 7)) << 4) + hi * 8, 8, smem, 4 * SLOT);
-                *reinterpret_cast<u32x2*>(slab + l31 * 128 + (((db * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = pk;
+                ESME_LDS_CHECK(slab + l31 * ROWB + (((db * 4 + g) ^ (l31 & (OCH - 1))) << 4) + hi * 8, 8, smem, 4 * SLOT);
+                *reinterpret_cast<u32x2*>(slab + l31 * ROWB + (((db * 4 + g) ^ (l31 & (OCH - 1))) << 4) + hi * 8) = pk;
             }
         __builtin_amdgcn_wave_barrier();
         const int rbase = wrow0 + bb * 32;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = it * 8 + (lane >> 3), ch = lane & 7;
-            ESME_LDS_CHECK(slab + r * 128 + ((ch ^ (r & 7)) << 4), 16, smem, 4 * SLOT);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * 128 + ((ch ^ (r & 7)) << 4));
+        for (int it = 0; it < 32 / (64 / OCH); ++it) {
+            const int r = it * (64 / OCH) + lane / OCH, ch = lane % OCH;
+            ESME_LDS_CHECK(slab + r * ROWB + ((ch ^ (r & (OCH - 1))) << 4), 16, smem, 4 * SLOT);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (OCH - 1))) << 4));
             if (rbase + r < S) *reinterpret_cast<u32x4*>(a.o + (int64_t)(s0 + rbase + r) * a.ldo + h * D + ch * 8) = v;
         }
     }
@@ -1410,10 +1425,10 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnArgs a) {
 
 using namespace esme;
 
-template <int NW, bool QP = false>
+template <int NW, bool QP = false, int D = 64>
 static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
-    constexpr int smem = 4 * (KT * 64 * 2 + 64 * 128);
-    auto kern = attn_pp64_kernel<NW, QP>;
+    constexpr int smem = 4 * (KT * D * 2 + D * 128);
+    auto kern = attn_pp64_kernel<NW, QP, D>;
     static std::atomic<unsigned long long> done{0ull};         // dynamic-LDS attribute: per (kernel, device)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1488,6 +1503,10 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
 #endif
         if (qp && nw == 4) return launch_pp64<4, true>(a, B, max_len, s);
         return nw == 8 ? launch_pp64<8>(a, B, max_len, s) : launch_pp64<4>(a, B, max_len, s);
+    }
+    if (d == 32 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o) && fits32) {
+        // head dim 32 (ESM2-150M; ESM2-35M's padded heads): the same software-pipelined kernel at D = 32 (round 4)
+        return qp ? launch_pp64<4, true, 32>(a, B, max_len, s) : launch_pp64<4, false, 32>(a, B, max_len, s);
     }
     // two 32-row q-blocks per wave when the longest sequence fills at least one 256-row tile
     // (head dim 128 keeps one: its accumulators alone take 128 VGPRs per q-block)

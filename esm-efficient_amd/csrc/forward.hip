@@ -64,10 +64,10 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
 #define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
     // longest sequences first in every attention launch (speed only; ragged batches), computed once per forward
     esme_attn_opts_t aopts{(int)sizeof(esme_attn_opts_t), 0, 0, 8.0f, 1, nullptr, 0};
-    // head dim 64 with fused rotary (ESM2-650M / 3B): softmax_scale * log2(e) rides in the QKV epilogue and the attention kernel
+    // head dim 64 / 32 with fused rotary (ESM2-650M / 3B / 150M): softmax_scale * log2(e) rides in the QKV epilogue and the attention kernel
     // runs without a reference maximum (esme_attn_opts_t.q_prescaled); the caller says so in the descriptor (no environment
     // switch in the library: the module-by-module path must take the same decision to stay bit-identical).
-    const bool qp = m->attn_q_prescale && m->rotary && dp == 64 && Ea % 64 == 0 && (rot_fused || m->qk_norm);      // (ESM-C: the q/k-norm pass folds the scale in)
+    const bool qp = m->attn_q_prescale && m->rotary && (dp == 64 || dp == 32) && Ea % 64 == 0 && (rot_fused || m->qk_norm);      // (ESM-C: the q/k-norm pass folds the scale in)
     aopts.q_prescaled = qp ? 1 : 0;
     if (B > 1 && B <= 1024 && m->n_layers > 0) {
         ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));

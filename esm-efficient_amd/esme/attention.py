@@ -34,7 +34,7 @@ from esme import _hip
 from esme.nn import GELU, LayerNorm, Linear
 from esme.rotary import RotaryEmbedding
 
-# head dim 64 with fused rotary: softmax_scale * log2(e) folded into q by the QKV epilogue, attention without a reference maximum
+# head dim 64 / 32 with fused rotary: softmax_scale * log2(e) folded into q by the QKV epilogue, attention without a reference maximum
 # (ESME_ATTN_QP=0: the plain form, an A/B switch read HERE only; the C entry gets the decision in esme_model_desc_t.attn_q_prescale)
 _ATTN_QP = os.environ.get('ESME_ATTN_QP', '1') != '0'
 
@@ -275,7 +275,7 @@ class FlashMultiheadAttention(nn.Module):
                        and d in (16, 32, 64) and E % 32 == 0)
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
         qk_pass = (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128) and E <= 5120)
-        qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d == 64 and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
+        qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,

@@ -727,3 +727,59 @@ def test_two_host_threads_two_streams_different_options():
     for i in range(2):
         for g_, w_ in zip(got[i], want[i]):
             assert torch.equal(g_, w_)
+
+
+# ------------------------------------------------------------------ head dim 32: the software-pipelined kernel at D = 32 (round 4)
+@pytest.mark.parametrize('lengths,H', [([37, 70, 193], 20), ([512] * 4, 20), ([1, 300, 63, 64, 65], 5), ([1253], 4),
+                                       ([256, 257, 255], 3), ([513, 2], 2), ([2049], 1)])
+@pytest.mark.parametrize('variant,spec', [(0, 1), (0, 0), (1, 0)])
+def test_attention_d32_variants(lengths, H, variant, spec):
+    """Head dim 32 (ESM2-150M): the ping-pong kernel at D = 32 (variant 0: speculative or classic online softmax) and the
+    first-generation kernel (variant 1) against the fp32 oracle, on ragged tiles, 1-row sequences and lengths around the 256-row tile."""
+    from esme import _hip
+    with _hip.attn_options(variant=variant, spec=spec):
+        got, ref = _attn_case(lengths, H, 32, seed=60)
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attention d32 variant {variant} spec {spec} {lengths}')
+
+
+def test_attention_d32_speculative_overflow_and_prescaled_q():
+    """The D = 32 instantiation keeps the head-dim-64 kernel's guarantees: a late key that overflows the speculative softmax sends the
+    work item through the classic pass (bit-identical to running it from the start); with pre-scaled q (no reference maximum)
+    overflowing and vanishing row sums do the same; results equal the fp32 oracle."""
+    from esme import _hip
+    H, d = 2, 32
+    E = H * d
+    lengths = [900, 130, 300]
+    T = sum(lengths)
+    cu = torch.tensor(np.cumsum([0] + lengths), dtype=torch.int32)
+    qkv = rnd((T, 3 * E), 61)
+    qkv[5, :E] = 4.0
+    qkv[700, E:2 * E] = 64.0                           # q.k = 4*64*32 = 8192 -> * 32^-1/2 * log2e ~ 2089 log2 units
+    q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    ref = O.varlen_attention(q, k, v, cu).view(T, E)
+    g = qkv.to(dev())
+    run = lambda **kw: _hip.attn_varlen(g[:, :E], g[:, E:2 * E], g[:, 2 * E:], cu.to(dev()), max(lengths), H, **kw)
+    with _hip.attn_options(spec=1):
+        spec = run()
+    with _hip.attn_options(spec=0):
+        classic = run()
+    check(spec, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='d32 overflow redo')
+    assert torch.equal(spec[:256], classic[:256])      # the workgroup that overflowed redid its rows with the classic pass
+    assert torch.equal(run(), spec)                    # the plain entry point takes the same path
+    check(run(exact=True), ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what='d32 exact entry')
+    # pre-scaled q: +1 row against +32 keys overflows, an all -32 key block makes a row vanish
+    c = d ** -0.5 * 1.4426950408889634
+    qs = rnd((T, 3 * E), 62)
+    qs[:, :E] = (qs[:, :E].float() * c).to(torch.bfloat16)
+    qs[5, :E] = 1.0
+    qs[700, E:2 * E] = 32.0                            # score 1*32*32 = 1024 > 127: overflow
+    qs[1000, :E] = 8.0
+    qs[900:1030, E:2 * E] = -8.0                       # sequence 1, row 100: every score -2048: the row sum vanishes
+    q2, k2, v2 = (qs[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
+    ref2 = O.varlen_attention(q2, k2, v2, cu, softmax_scale=math.log(2.0)).view(T, E)
+    g2 = qs.to(dev())
+    got2 = _hip.attn_varlen(g2[:, :E], g2[:, E:2 * E], g2[:, 2 * E:], cu.to(dev()), max(lengths), H, q_prescaled=True)
+    check(got2, ref2, rtol=2.0 ** -6, atol_scale=2.0 ** -5.5, what='d32 prescaled q with overflowing / vanishing rows')
+    with _hip.attn_options(variant=1):
+        first_gen = _hip.attn_varlen(g2[:, :E], g2[:, E:2 * E], g2[:, 2 * E:], cu.to(dev()), max(lengths), H, q_prescaled=True)
+    check(first_gen, ref2, rtol=2.0 ** -6, atol_scale=2.0 ** -5.5, what='d32 prescaled q, first-generation kernel')
