@@ -136,8 +136,9 @@ int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_
 
 /* Per-call kernel selection for tests and tuning (NULL = exactly esme_hip_attn_varlen_fwd).  There is no process-global
  * tuning state in the library: two host threads on two streams can use different options concurrently.
- *   variant:       0 = heuristic; 1 = the first-generation kernel (all head dims); 4 / 8 = the head-dim-64 software-pipelined
- *                  kernel with 4 / 8 waves per workgroup
+ *   variant:       0 = heuristic (head dims 64 and 32: the software-pipelined kernel with 4 waves per workgroup; 16 / 128: the
+ *                  first-generation kernel); 1 = the first-generation kernel (all head dims); 4 / 8 = the head-dim-64
+ *                  software-pipelined kernel with 4 / 8 waves per workgroup
  *   q_blocks:      first-generation kernel: 32-row query blocks per wave (0 = heuristic, 1, 2)
  *   defer_max_thr: online-softmax rescale threshold in log2 units (default 8; 0 = every row maximum exact)
  *   speculative:   head-dim-64 kernel: 1 = speculative softmax (default), 0 = classic online softmax
@@ -146,7 +147,7 @@ int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_
  *                  array is read out of bounds, a repeated index leaves another sequence's output rows unwritten).  Speed only -- results do not depend on it, bit for bit; on ragged batches the long
  *                  proteins' workgroups no longer start last (-6 % on a proteome-like 50 000-residue batch).
  *   q_prescaled:   1 = q already carries softmax_scale * log2(e) (the QKV projection folded it in before its bf16 rounding:
- *                  esme_gemm_fusion_t.q_scale; `softmax_scale` is then ignored).  The 4-wave head-dim-64 kernel computes
+ *                  esme_gemm_fusion_t.q_scale; `softmax_scale` is then ignored).  The 4-wave software-pipelined kernel (head dims 64 and 32) computes
  *                  P = exp2(score) with no reference maximum (5 instead of 7 VALU instructions per score pair; a row sum
  *                  that overflows or vanishes sends the work item through the classic online softmax); every other kernel
  *                  simply runs with a unit scale. */
