@@ -86,10 +86,11 @@ def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], 
         out_r = forward(tok_r.to(device), (cu_r.to(device), max_r))
     else:
         out_r = None
-    width = torch.tensor([0 if out_r is None else out_r.shape[1]], device=device)
-    dist.all_reduce(width, op=dist.ReduceOp.MAX, group=group)
+    # (width, 1 if the logits are fp32 -- precision 'exact' -- else 0): a rank without sequences learns both from the others
+    meta = torch.tensor([0, 0] if out_r is None else [out_r.shape[1], int(out_r.dtype == torch.float32)], device=device)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
     if out_r is None:
-        out_r = torch.zeros(0, int(width.item()), dtype=torch.bfloat16, device=device)
+        out_r = torch.zeros(0, int(meta[0].item()), dtype=torch.float32 if int(meta[1].item()) else torch.bfloat16, device=device)
     gathered = gather_rows_all_ranks(out_r, counts, group)
     # gathered holds rank 0's sequences, then rank 1's, ...: build the inverse permutation
     src = np.concatenate([np.arange(cu[i], cu[i + 1]) for p in plan for i in p]) if len(lengths) else np.zeros(0, int)

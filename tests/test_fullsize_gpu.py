@@ -201,3 +201,24 @@ def test_exact_mode_full_depth():
     assert e_exact <= 1.0e-3, e_exact                         # north_star's tolerance
     assert e_exact <= 1.0e-4, e_exact                         # what the split-operand design should deliver (emulation: 6e-6)
     assert e_lp <= 1.0e-4, e_lp
+
+
+def test_exact_mode_esmc_600m_full_depth():
+    """The split-operand mode on BASELINE config 5's model at its real depth: ESMC-600M (36 layers, E = 1152, q/k LayerNorm, SwiGLU) on
+    32 x 1 002 residues, one whole sequence vs the fp32-math oracle: <= 1e-3 (north_star), measured ~1e-5."""
+    model, w, H = load('esmc_600m')
+    tokens, cu, max_len, lengths = syn.uniform_batch(32 * 1002, 1002, seed=5)
+    cul = cu.tolist()
+    i = 17
+    sub_t, sub_cu = tokens[cul[i]:cul[i + 1]], syn.cu_lens_of([1002])
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    ref32 = O.forward_logits(w, H, sub_t, sub_cu, 1002, dtype=torch.float32).float()
+    model.set_precision('exact')
+    out = model(tokens.to(DEV), (cu.to(DEV), max_len))
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    got = out[cul[i]:cul[i + 1]].cpu()
+    alone = model(sub_t.to(DEV), (sub_cu.to(DEV), 1002))
+    assert torch.equal(alone.cpu(), got), 'exact mode (ESM-C): packed rows differ from the sequence run alone'
+    e = rel_fro(got, ref32)
+    print(f'\n[precision] ESMC-600M x 36 layers, 32 x 1 002 residues, exact mode: rel_fro vs fp32 oracle {e:.3e}')
+    assert e <= 1.0e-3 and e <= 1.0e-4, e
