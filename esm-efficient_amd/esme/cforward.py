@@ -120,6 +120,8 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
     pool = model.__dict__.setdefault('_cws', {})
     ws = pool.get(key)
     if ws is None or ws.numel() < nbytes:
+        if len(pool) >= 8:                 # short-lived streams must not pile buffers up: start over (the allocator recycles them)
+            pool.clear()
         ws = pool[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
     _hip._check(lib.esme_hip_forward(ctypes.byref(d), _hip._dev(x, 'forward x', torch.bfloat16), x.stride(0),
                                      _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
