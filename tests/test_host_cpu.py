@@ -175,7 +175,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, lengths, out_path):
+def _worker(rank, world, port, lengths, out_path, dtype=torch.bfloat16):
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, 'esm-efficient_amd'))
     from esme import shard, synthetic as syn
@@ -190,7 +190,7 @@ def _worker(rank, world, port, lengths, out_path):
         pos = torch.arange(tok.numel()) - torch.repeat_interleave(cu_r[:-1].long(), (cu_r[1:] - cu_r[:-1]).long())
         out = table[tok].clone()
         out[:, 0] = pos.to(torch.bfloat16)             # position inside its own sequence
-        return out
+        return out.to(dtype)
 
     full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu')
     if rank == 0:
@@ -214,6 +214,22 @@ def test_sharded_forward_gloo_world2(lengths):
     pos = torch.arange(tokens.numel()) - torch.repeat_interleave(cu[:-1].long(), (cu[1:] - cu[:-1]).long())
     ref[:, 0] = pos.to(torch.bfloat16)
     assert torch.equal(full, ref)
+
+
+def test_sharded_forward_gloo_world2_fp32_logits_and_an_empty_rank():
+    """precision='exact' returns fp32 logits: the gather keeps the dtype, and a rank that received no sequence (one sequence, two
+    ranks) learns width AND dtype from the others instead of contributing bf16 zeros to an fp32 all-gather."""
+    from esme import synthetic as syn
+    lengths = [11]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'full.pt')
+        mp.spawn(_worker, args=(2, _free_port(), lengths, out, torch.float32), nprocs=2, join=True)
+        full = torch.load(out)
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    table = torch.arange(33 * 8, dtype=torch.float32).view(33, 8).to(torch.bfloat16)
+    ref = table[tokens].clone()
+    ref[:, 0] = torch.arange(11).to(torch.bfloat16)
+    assert full.dtype == torch.float32 and torch.equal(full, ref.float())
 
 
 def test_feedforward_head_module():
