@@ -64,10 +64,11 @@ def parse():
                     help='replay from a hipGraph when the forward is launch-bound (T x L <= 400 000)')
     ap.add_argument('--high-precision', action='store_true',
                     help="model.set_precision('high'): fp32 residual stream (not the headline mode; see DESIGN.md section 4)")
-    ap.add_argument('--precision', choices=['fast', 'high', 'exact'], default=None,
+    ap.add_argument('--precision', choices=['fast', 'high', 'half', 'exact'], default=None,
                     help="model.set_precision(...): 'fast' = the headline mode (bf16 storage at the reference's rounding points); 'high' = fp32 "
-                         "residual stream; 'exact' = split (hi, lo) bf16 operand pairs, fp32 logits: the reference's fp32 forward to ~1e-5 "
-                         "at ~2.3x the time (DESIGN.md section 4).  Not the headline; the line says which mode ran.")
+                         "residual stream; 'half' = fp32 residual stream + IEEE fp16 MFMA operands, fp32 logits within ~5e-4 of the fp32 forward at "
+                         "~1.1x the time (the line then says dtype f16); 'exact' = split (hi, lo) bf16 operand pairs, fp32 logits: the "
+                         "reference's fp32 forward to ~1e-5 at ~2.5x the time (DESIGN.md section 4).  Not the headline; the line says which mode ran.")
     ap.add_argument('--spawn', action='store_true',
                     help='go through the torch.distributed.run self-launch even for --gpus 1 (exercises the RCCL '
                          'init + launcher path on a single-GPU box)')
@@ -324,7 +325,7 @@ def main():
         'metric': metric_label(args.model, T, args.batch),
         'value': round(value, 1), 'unit': 'residues/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if args.precision == 'half' else 'bf16', 'data': 'synthetic',
         'config': {'workload': f'{args.model} packed forward -> logits, {T} residues/GPU, '
                                f'{args.batch} batch ({len(lengths)} seqs, max_len {max_len})',
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
@@ -335,6 +336,8 @@ def main():
                    'launcher': 'torch.distributed.run (self-launched)' if os.environ.get('ESME_BENCH_SPAWNED') else
                                ('torch.distributed.run' if launched else 'plain python'),
                    'precision': {'fast': 'fast (bf16 residual stream)', 'high': 'high (fp32 residual stream)',
+                                 'half': 'half (fp32 residual stream, IEEE fp16 MFMA operands converted exactly from the bf16 weights, exact online '
+                                         'softmax, split-operand LM head, fp32 logits)',
                                  'exact': 'exact (split (hi, lo) bf16 operand pairs, fp32 residual stream, fp32 logits; 2 MFMA passes per '
                                           'projection, 3 per attention product)'}[args.precision],
                    'setup': '2 untimed forwards before the warm-up steps (weight packing / LN folding, module load)',
@@ -367,6 +370,8 @@ def main():
                         _hip.EPI_GELU if kind != 'esmc' else _hip.EPI_SWIGLU))
         if args.precision == 'exact':              # the same launch in pair form: K doubled ([hi | lo]); MFMA FLOPs are counted as executed
             key = ('gemm', (T, 4 * E, 2 * E, f'split:{_hip.EPI_GELU}'))
+        if args.precision == 'half':               # the same launch on fp16 operands
+            key = ('gemm', (key[1][0], key[1][1], key[1][2], f'f16:{key[1][3]}'))
         traffic, traffic_src = pmc_traffic() if (args.model == 'esm2_650m' and T == 50000 and args.precision == 'fast'
                                                  and args.quantization == 'none') else (None, None)
         if key in per_op:

@@ -61,7 +61,8 @@ __device__ __forceinline__ int kswz(int row) {
     return (row / RPB) & (CPR - 1);
 }
 
-template <int D, int QB>
+// F16 (precision 'half'): q, k, v, P and o are IEEE fp16; the host then runs the classic online softmax with exact maxima (P <= 1).
+template <int D, int QB, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
     constexpr int DS = D / 16;                   // k-steps of the QK^T contraction
     constexpr int DB = (D + 31) / 32;            // 32-row blocks of O^T
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
 #pragma unroll
                     for (int b = 0; b < QB; ++b)
-                        sacc[b][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ds], sacc[b][kbk], 0, 0, 0);
+                        sacc[b][kbk] = mfma_32x32x16<F16>(kf, qf[b][ds], sacc[b][kbk]);
                 }
             }
             bf16x8 pf[QB][2][2];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                             p[j] = __builtin_amdgcn_exp2f(fmaf(sacc[b][kbk][8 * s + j], c, -mc[b]));
                             psum += p[j];
                         }
-                        u32x4 pk = pack8(p);
+                        u32x4 pk = pack8t<F16>(p);
                         pf[b][kbk][s] = __builtin_bit_cast(bf16x8, pk);
                     }
                 l_run[b] += psum;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
 #pragma unroll
                         for (int b = 0; b < QB; ++b)
-                            oacc[b][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][kbk][s], oacc[b][i], 0, 0, 0);
+                            oacc[b][i] = mfma_32x32x16<F16>(vf, pf[b][kbk][s], oacc[b][i]);
                     }
             }
         }
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const AttnArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     const int d = i * 32 + 8 * g + 4 * hi;
                     if (d < D) {
-                        u32x2 pk = {pack_bf16(oacc[b][i][4 * g] * inv, oacc[b][i][4 * g + 1] * inv),
-                                    pack_bf16(oacc[b][i][4 * g + 2] * inv, oacc[b][i][4 * g + 3] * inv)};
+                        u32x2 pk = {pack16<F16>(oacc[b][i][4 * g] * inv, oacc[b][i][4 * g + 1] * inv),
+                                    pack16<F16>(oacc[b][i][4 * g + 2] * inv, oacc[b][i][4 * g + 3] * inv)};
                         *reinterpret_cast<u32x2*>(op + d) = pk;
                     }
                 }
@@ -658,8 +659,11 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 // 64 B (tiles of 4 KB, one LDS-DMA piece per wave and tile), two k-steps per S^T block and ONE 32-row block of O^T, i.e. 8 MFMAs per
 // phase against the same 16 score pairs: two pairs per MFMA slot.  The VALU port bounds it harder than head dim 64 (the softmax work
 // per score is the same, the MFMA work half), but the ping-pong schedule, the LDS-DMA data path and the speculative softmax carry over.
-template <int NW, bool QP = false, int D = 64>
+// F16 (precision 'half'): q, k, v, P and o are IEEE fp16 (11 significant bits).  P must stay <= 1 -- fp16 ends at 65 504 -- so the host runs this
+// form with the classic online softmax only (a.spec = 0, thr = 0: every row maximum exact), never with the speculative / QP passes.
+template <int NW, bool QP = false, int D = 64, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
+    static_assert(!F16 || !QP, "fp16 P needs a reference maximum");
     constexpr int DS = D / 16, DB = D / 32, NT = NW * 64;
     constexpr int ROWB = D * 2;                  // bytes per K / V row
     constexpr int K_BYTES = KT * D * 2;          // 8 KB (head dim 64) / 4 KB (32)
@@ -814,14 +818,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 const int j = m - NPV, kbk = j & 1, ds = j >> 1;
                 if (ds == 0) {
                     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    sacc[bm][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % 3], qf[bm][ds], z, 0, 0, 0);
+                    sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], z);
                 } else {
-                    sacc[bm][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % 3], qf[bm][ds], sacc[bm][kbk], 0, 0, 0);
+                    sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], sacc[bm][kbk]);
                 }
             } else {
                 const int db = m % DB, ks = m / DB;
-                oacc[bm][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    fr[m % 3], __builtin_bit_cast(bf16x8, pw[bm][ks >> 1][ks & 1]), oacc[bm][db], 0, 0, 0);
+                oacc[bm][db] = mfma_32x32x16<F16>(
+                    fr[m % 3], __builtin_bit_cast(bf16x8, pw[bm][ks >> 1][ks & 1]), oacc[bm][db]);
             }
         };
         // P, packed to bf16, and four partial row sums of block bs against the reference maximum -nm.  Pair p covers
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         };
         auto pair_sum_pack = [&](const int p, const float q0, const float q1) {
             const int kbk = p >> 3, r = (2 * p) & 15;
-            pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack_bf16(q0, q1);
+            pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack16<F16>(q0, q1);
             if (p & 1) { ps2 += q0; ps3 += q1; } else { ps0 += q0; ps1 += q1; }
         };
         auto softmax_slot = [&](const int m, const float nm) {      // pair step m = 0..15 (one per MFMA slot at head dim 64, two at 32)
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     #pragma unroll
                 for (int kbk = 0; kbk < 2; ++kbk) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + kbk * (32 * ROWB) + kfo[ds]);
-                    sacc[0][kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ds], sacc[0][kbk], 0, 0, 0);
+                    sacc[0][kbk] = mfma_32x32x16<F16>(kf, qf[0][ds], sacc[0][kbk]);
                 }
         }
         const bool ragged = (S & (KT - 1)) != 0;
@@ -1028,8 +1032,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const bf16x8 vf = vfrag(Vs, db, ks);
-                    oacc[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks >> 1][ks & 1]),
-                                                                          oacc[1][db], 0, 0, 0);
+                    oacc[1][db] = mfma_32x32x16<F16>(vf, __builtin_bit_cast(bf16x8, pw[1][ks >> 1][ks & 1]),
+                                                                          oacc[1][db]);
                 }
         }
         if constexpr (QP) {
@@ -1056,8 +1060,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                u32x2 pk = {pack_bf16(oacc[bb][db][4 * g] * inv, oacc[bb][db][4 * g + 1] * inv),
-                            pack_bf16(oacc[bb][db][4 * g + 2] * inv, oacc[bb][db][4 * g + 3] * inv)};
+                u32x2 pk = {pack16<F16>(oacc[bb][db][4 * g] * inv, oacc[bb][db][4 * g + 1] * inv),
+                            pack16<F16>(oacc[bb][db][4 * g + 2] * inv, oacc[bb][db][4 * g + 3] * inv)};
                 ESME_LDS_CHECK(slab + l31 * ROWB + (((db * 4 + g) ^ (l31 & (OCH - 1))) << 4) + hi * 8, 8, smem, 4 * SLOT);
                 *reinterpret_cast<u32x2*>(slab + l31 * ROWB + (((db * 4 + g) ^ (l31 & (OCH - 1))) << 4) + hi * 8) = pk;
             }
@@ -1425,10 +1429,10 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const AttnArgs a) {
 
 using namespace esme;
 
-template <int NW, bool QP = false, int D = 64>
+template <int NW, bool QP = false, int D = 64, bool F16 = false>
 static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     constexpr int smem = 4 * (KT * D * 2 + D * 128);
-    auto kern = attn_pp64_kernel<NW, QP, D>;
+    auto kern = attn_pp64_kernel<NW, QP, D, F16>;
     static std::atomic<unsigned long long> done{0ull};         // dynamic-LDS attribute: per (kernel, device)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1486,7 +1490,10 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
     // q_prescaled: q already carries softmax_scale * log2(e) (esme_gemm_fusion_t.q_scale): every kernel then runs with c = 1, and
     // the 4-wave head-dim-64 kernel in its no-reference-maximum form
+    const bool f16 = opts && opts->f16;                         // fp16 operands: P must stay <= 1, i.e. the classic online softmax with exact maxima
+    if (f16) exact = true;
     const bool qp = opts && opts->q_prescaled;
+    ESME_CHECK_ARG(!(f16 && qp), "attn: fp16 operands do not combine with q_prescaled (no reference maximum: P would leave fp16's range)");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
                qp ? 1.0f : softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec,
                opts ? opts->seq_order : nullptr};
@@ -1498,6 +1505,7 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
         // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
         const int nw = g_attn_variant == 8 ? 8 : 4;
+        if (f16) return launch_pp64<4, false, 64, true>(a, B, max_len, s);
 #ifdef ESME_ATTN_W4
         if (qp && g_attn_variant == 16) return launch_w4(a, B, max_len, s);          // one wave per SIMD, four q-blocks per wave (lab build)
 #endif
@@ -1506,6 +1514,7 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     }
     if (d == 32 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o) && fits32) {
         // head dim 32 (ESM2-150M; ESM2-35M's padded heads): the same software-pipelined kernel at D = 32 (round 4)
+        if (f16) return launch_pp64<4, false, 32, true>(a, B, max_len, s);
         return qp ? launch_pp64<4, true, 32>(a, B, max_len, s) : launch_pp64<4, false, 32>(a, B, max_len, s);
     }
     // two 32-row q-blocks per wave when the longest sequence fills at least one 256-row tile
@@ -1516,7 +1525,10 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     const dim3 grid((unsigned int)((max_len + rows - 1) / rows), (unsigned int)H, (unsigned int)B), block(256);
 #define ESME_ATTN(DD)                                                                         \
     case DD:                                                                                   \
-        if (two) hipLaunchKernelGGL((attn_varlen_kernel<DD, (DD <= 64 ? 2 : 1)>), grid, block, 0, s, a); \
+        if (f16) {                                                                             \
+            if (two) hipLaunchKernelGGL((attn_varlen_kernel<DD, (DD <= 64 ? 2 : 1), true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((attn_varlen_kernel<DD, 1, true>), grid, block, 0, s, a);  \
+        } else if (two) hipLaunchKernelGGL((attn_varlen_kernel<DD, (DD <= 64 ? 2 : 1)>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((attn_varlen_kernel<DD, 1>), grid, block, 0, s, a);            \
         break;
     switch (d) {

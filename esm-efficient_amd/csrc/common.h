@@ -54,6 +54,43 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     return c;
 }
 
+// ---- 16-bit operand type as a template switch (F16 = false: bf16, the checkpoint's type; true: IEEE fp16, the operand type of
+// precision 'half': 11 significant bits instead of 8 at the same MFMA rate).  Same storage (u16), same LDS / DMA paths.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ unsigned int pack_f16(float lo, float hi) {          // round-to-nearest-even; one v_cvt_pk_f16_f32
+    const f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+}
+template <bool F16> __device__ __forceinline__ unsigned int pack16(float lo, float hi) { if constexpr (F16) return pack_f16(lo, hi); else return pack_bf16(lo, hi); }
+template <bool F16> __device__ __forceinline__ float lo16(unsigned int w) {
+    if constexpr (F16) return (float)__builtin_bit_cast(f16x2, w)[0]; else return bf_lo(w);
+}
+template <bool F16> __device__ __forceinline__ float hi16(unsigned int w) {
+    if constexpr (F16) return (float)__builtin_bit_cast(f16x2, w)[1]; else return bf_hi(w);
+}
+template <bool F16> __device__ __forceinline__ float h2f(u16 h) { return lo16<F16>((unsigned int)h); }
+template <bool F16> __device__ __forceinline__ u16 f2h(float x) { return (u16)(pack16<F16>(x, 0.f) & 0xffffu); }
+template <bool F16> __device__ __forceinline__ void unpack8t(const u32x4 c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = lo16<F16>(c[i]); f[2 * i + 1] = hi16<F16>(c[i]); }
+}
+template <bool F16> __device__ __forceinline__ u32x4 pack8t(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = pack16<F16>(f[2 * i], f[2 * i + 1]);
+    return c;
+}
+// the two MFMA shapes of the library on either operand type (the fragments travel as bf16x8 = 16 bytes per lane either way)
+template <bool F16> __device__ __forceinline__ f32x4 mfma_16x16x32(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

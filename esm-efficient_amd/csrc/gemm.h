@@ -40,6 +40,7 @@ struct GemmArgs {
     // (kt_wrap = K-tiles of W, 0 = no wrap); PAIR kernels write the result as a (hi, lo) bf16 pair, lo at column offset pair_off of
     // the same C row; c32: fp32 result through the scalar store path (the (T, V) logits)
     int kt_wrap = 0; int64_t pair_off = 0; float* c32 = nullptr; int64_t ldc32 = 0;
+    int f16 = 0;                 // precision 'half': A, W, rotary tables and C are IEEE fp16 (esme_gemm_fusion_t.f16)
 };
 
 // The tuning hooks (start skew, "no C store", "loop only") exist only in the instrumented build (`make TRACE=1`);

@@ -41,8 +41,11 @@
 
 namespace esme {
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false, bool PAIR = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+    // F16 (precision 'half'): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (bias stays bf16, a checkpoint parameter); what
+    // changes is the MFMA opcode, the table unpack and the output rounding -- the LDS image, the DMA path and the schedule do not.
+    static_assert(!F16 || (!PAIR && (EPI != ESME_EPI_RESIDUAL || R32)), "fp16 operands: plain / GELU / SwiGLU epilogues and the fp32-stream residual epilogue");
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
     static_assert(!R32 || EPI == ESME_EPI_RESIDUAL, "the fp32 residual stream belongs to the residual epilogue");
     static_assert(!PAIR || (EPI != ESME_EPI_RESIDUAL && !LNF && !STATS && !PERSIST), "(hi, lo) pair output: plain / GELU / SwiGLU epilogues of the split-operand mode");
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int f = 0; f < FMH; ++f)
-                    acc[i][j0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][ks], fa[f][ks], acc[i][j0 + f], 0, 0, 0);
+                    acc[i][j0 + f] = mfma_16x16x32<F16>(fw[i][ks], fa[f][ks], acc[i][j0 + f]);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
         for (int m = 0; m < total; ++m) {
             const int i = m / FMH, j = m % FMH;            // weight fragment held for FMH MFMAs
-            acc[i][h * FMH + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[i], ca.v[j], acc[i][h * FMH + j], 0, 0, 0);
+            acc[i][h * FMH + j] = mfma_16x16x32<F16>(w.v[i], ca.v[j], acc[i][h * FMH + j]);
             if (neww && j == FMH - 1) {
                 if (rd_on) { ESME_LDS_CHECK(nbase + rowW + i * 16 * 128 + coff[nks], 16, smem, 2 * STAGE); w.v[i] = *reinterpret_cast<const bf16x8*>(nbase + rowW + i * 16 * 128 + coff[nks]); }
             } else if (na_next < FMH) {
@@ -583,8 +586,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     // one fragment = one head: column 4 lq + e pairs with 4 (lq ^ 2) + e, i.e. the same register of lane ^ 32
                     const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((0 ^ (r & 1)) << 4));
                     const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + ((1 ^ (r & 1)) << 4));
-                    const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
-                    const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
+                    const float cv[4] = {lo16<F16>(cw[0]), hi16<F16>(cw[0]), lo16<F16>(cw[1]), hi16<F16>(cw[1])};
+                    const float sv[4] = {lo16<F16>(sw[0]), hi16<F16>(sw[0]), lo16<F16>(sw[1]), hi16<F16>(sw[1])};
 #pragma unroll
                     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -605,8 +608,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     const int cc = (hc >> 3) + (lq >> 1);     // cos chunk of the lane's quad; the sin chunk sits CPRW/2 further
                     const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((cc ^ (r & (CPRW - 1))) << 4));
                     const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + (((cc + CPRW / 2) ^ (r & (CPRW - 1))) << 4));
-                    const float cv[4] = {bf_lo(cw[0]), bf_hi(cw[0]), bf_lo(cw[1]), bf_hi(cw[1])};
-                    const float sv[4] = {bf_lo(sw[0]), bf_hi(sw[0]), bf_lo(sw[1]), bf_hi(sw[1])};
+                    const float cv[4] = {lo16<F16>(cw[0]), hi16<F16>(cw[0]), lo16<F16>(cw[1]), hi16<F16>(cw[1])};
+                    const float sv[4] = {lo16<F16>(sw[0]), hi16<F16>(sw[0]), lo16<F16>(sw[1]), hi16<F16>(sw[1])};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = acc[i][j][e], up = acc[i2][j][e];
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         o[2] = bf_lo(rw[1]) + a.alpha * o[2]; o[3] = bf_hi(rw[1]) + a.alpha * o[3];
                     }
                 }
-                u32x2 pk = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
+                u32x2 pk = {pack16<F16>(o[0], o[1]), pack16<F16>(o[2], o[3])};
                 if (PAIR && half == 0) {
                     acc[i][j][0] = o[0] - bf_lo(pk[0]); acc[i][j][1] = o[1] - bf_hi(pk[0]);
                     acc[i][j][2] = o[2] - bf_lo(pk[1]); acc[i][j][3] = o[3] - bf_hi(pk[1]);
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
                     // (two quad_perm DPP steps + row_half_mirror).
                     float f[8];
-                    unpack8(v, f);
+                    unpack8t<F16>(v, f);
                     float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
                     float t2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) +
                                ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
@@ -870,7 +873,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                             if constexpr (R32) { float* xp = a.resid32 + m * a.ld32 + n + e; v = fmaf(a.alpha, v, *xp); *xp = v; }
                             else if constexpr (EPI == ESME_EPI_RESIDUAL) v = bf2f(a.resid[m * a.ldr + n + e]) + a.alpha * v;
                             if (a.c32) a.c32[m * a.ldc32 + n + e] = v;             // fp32 result (the split-operand mode's logits)
-                            else a.C[m * a.ldc + n + e] = f2bf(v);
+                            else a.C[m * a.ldc + n + e] = f2h<F16>(v);
                         }
                     }
                 }
@@ -928,7 +931,7 @@ static void set_raster(GemmArgs& a) {
     if (a.gn < 1) a.gn = 1;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false, bool PAIR = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false>
 static int launch_one(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
@@ -939,11 +942,11 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
         const bool want = a.opt_persist < 0 ? persist_default() != 0 : a.opt_persist != 0;
-        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32>(a, s);
+        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16>(a, s);
 
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32, PAIR>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32, PAIR, F16>;
     if (smem >= 64 * 1024) {
         // the attribute is per (kernel, device): one bit per device ordinal, set once, safe from any host thread
         static std::atomic<unsigned long long> done{0ull};
@@ -980,6 +983,24 @@ static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hip
             default: return fail(ESME_ERR_ARG, "gemm: pair output does not combine with the residual epilogue");
         }
 #undef ESME_LP
+    }
+    if (a.f16) {                                    // precision 'half': fp16 operands (checked by the caller: residual epilogue only on the fp32 stream)
+#define ESME_LH(E, R, L, S, R32) launch_one<BM, BN, WM, WN, E, R, L, S, false, R32, false, true>(a, s)
+        switch (epi) {
+            case ESME_EPI_NONE:
+                switch (rotd) {
+                    case 0: return lnf ? ESME_LH(ESME_EPI_NONE, 0, true, false, false) : ESME_LH(ESME_EPI_NONE, 0, false, false, false);
+                    case 16: return lnf ? ESME_LH(ESME_EPI_NONE, 16, true, false, false) : fail(ESME_ERR_UNSUPPORTED, "gemm: fp16 fused rotary runs LayerNorm-folded only");
+                    case 32: return lnf ? ESME_LH(ESME_EPI_NONE, 32, true, false, false) : fail(ESME_ERR_UNSUPPORTED, "gemm: fp16 fused rotary runs LayerNorm-folded only");
+                    case 64: return lnf ? ESME_LH(ESME_EPI_NONE, 64, true, false, false) : fail(ESME_ERR_UNSUPPORTED, "gemm: fp16 fused rotary runs LayerNorm-folded only");
+                    default: return fail(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs head dim 16, 32 or 64");
+                }
+            case ESME_EPI_GELU: return lnf ? ESME_LH(ESME_EPI_GELU, 0, true, false, false) : ESME_LH(ESME_EPI_GELU, 0, false, false, false);
+            case ESME_EPI_SWIGLU: return lnf ? ESME_LH(ESME_EPI_SWIGLU, 0, true, false, false) : fail(ESME_ERR_UNSUPPORTED, "gemm: fp16 SwiGLU runs LayerNorm-folded only");
+            case ESME_EPI_RESIDUAL: return stats ? ESME_LH(ESME_EPI_RESIDUAL, 0, false, true, true) : ESME_LH(ESME_EPI_RESIDUAL, 0, false, false, true);
+            default: return fail(ESME_ERR_ARG, "gemm: unknown epilogue");
+        }
+#undef ESME_LH
     }
     switch (epi) {
         case ESME_EPI_NONE:
@@ -1094,6 +1115,12 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
             a.c32 = fu->c32; a.ldc32 = fu->ldc32;
             a.vec_ok = 0;                                            // fp32 results leave through the scalar store path
         }
+    }
+    if (fu && fu->f16) {                                             // precision 'half': fp16 A, W, tables, C
+        ESME_CHECK_ARG(!fu->w_k && !fu->pair_off && !fu->c32, "gemm: fp16 operands do not combine with the split-operand fields");
+        ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL || r32, "gemm: fp16 operands run the residual epilogue on the fp32 stream only");
+        if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: fp16 operands need a 16-byte addressable C and N % 8 == 0");
+        a.f16 = 1;
     }
     if (fu) {
         if (fu->head_dim != 0) {                                     // fused rotary

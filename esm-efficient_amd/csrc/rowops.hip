@@ -428,6 +428,37 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
     }
 }
 
+// ------------------------------------------- MFMA operand of an fp32 stream
+// x16 = round(x32) (bf16, or IEEE fp16 for precision 'half') + per-row {sum, sum of squares} of the ROUNDED values: the operand the
+// LayerNorm-folded GEMMs read and the statistics they fold (the start of a forward on an fp32 residual stream whose rows are not
+// bf16 embedding rows, e.g. after the learned-position sum; afterwards the residual GEMMs' epilogues keep both current).
+template <int NCH, bool F16>
+__global__ __launch_bounds__(256) void stream_operand_kernel(const float* __restrict__ x32, int64_t ld32, u16* __restrict__ x16,
+                                                             int64_t ld16, f32x2* __restrict__ sums, int64_t T, int E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float* xr = x32 + row * ld32;
+    u16* yr = x16 + row * ld16;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e0 = (c * 64 + lane) * 8;
+        if (e0 < E) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + e0), a1 = *reinterpret_cast<const f32x4*>(xr + e0 + 4);
+            const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const u32x4 pk = pack8t<F16>(v);
+            *reinterpret_cast<u32x4*>(yr + e0) = pk;
+            float r[8];
+            unpack8t<F16>(pk, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1 += r[j]; s2 = fmaf(r[j], r[j], s2); }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0 && sums) sums[row] = f32x2{s1, s2};
+}
+
 // ------------------------------------------- q/k LayerNorm + rotary (ESM-C)
 // ESM-C normalises q and k over the FULL embedding width between the projection and the rotary
 // (attention.py:104-105), so that LayerNorm cannot ride in a GEMM epilogue (a row spans several
@@ -441,7 +472,8 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
 // cos, 3 sin, 3 stores) and ran at 4.2 TB/s.  Here the LayerNorm weights (biases) of the wave's type are loaded
 // once for its RPW rows, and the cos / sin chunk of a lane is the same for every 64-lane chunk of the row
 // (512 elements per chunk step is a multiple of the head dim), so it is ONE load each per row: 8 + 6 / RPW.
-template <int NCH, int RPW>
+// F16 (precision 'half'): q, k and the rotary tables are IEEE fp16 (the LayerNorm parameters stay bf16).
+template <int NCH, int RPW, bool F16 = false>
 __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q, u16* __restrict__ k, int64_t ld,
                                                              const u16* __restrict__ wq, const u16* __restrict__ wk,
                                                              const u16* __restrict__ bq, const u16* __restrict__ bk,
@@ -484,7 +516,7 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
         for (int c = 0; c < NCH; ++c) {
             const int e0 = (c * 64 + lane) * 8;
             if (e0 < E) {
-                unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
+                unpack8t<F16>(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[c][j];
             } else {
@@ -504,15 +536,16 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
         }
         const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
         float cs[8], sn[8];
-        unpack8(craw, cs);
-        unpack8(sraw, sn);
+        unpack8t<F16>(craw, cs);
+        unpack8t<F16>(sraw, sn);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e0 = (c * 64 + lane) * 8;
             const bool ok = e0 < E;
             u32x4 y = {0u, 0u, 0u, 0u};
+            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                float wf[8], o[8];
+                float wf[8];
                 unpack8(wraw[c], wf);
                 if (b) {
                     float bfv[8];
@@ -523,15 +556,22 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
                 }
-                y = pack8(o);                                 // bf16 rounding point of the LayerNorm output
+                if constexpr (!F16) y = pack8(o);             // bf16 rounding point of the LayerNorm output (the reference's; precision 'half'
+                                                              // answers to the fp32 forward instead and keeps the fp32 values: one rounding fewer on q, k)
             }
-            u32x4 other;
+            float a[8], o2[8];
+            if constexpr (F16) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
-            if (ok) {
-                float a[8], o2[8], r[8];
+                for (int j = 0; j < 8; ++j) { a[j] = o[j]; o2[j] = __shfl_xor(o[j], shift, 64); }
+            } else {
+                u32x4 other;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
                 unpack8(y, a);
                 unpack8(other, o2);
+            }
+            if (ok) {
+                float r[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float t = __fmul_rn(o2[j], sn[j]);
@@ -541,7 +581,7 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r[j] *= q_scale;
                 }
-                *reinterpret_cast<u32x4*>(xr + e0) = pack8(r);
+                *reinterpret_cast<u32x4*>(xr + e0) = pack8t<F16>(r);
             }
         }
     }
@@ -727,6 +767,27 @@ extern "C" int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, in
     return check_launch("residual_f32");
 }
 
+extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int f16, float* sums, int64_t T, int E,
+                                       void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "stream_operand: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x32 && x16, "stream_operand: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && ld32 % 4 == 0 && ld16 % 8 == 0 && ld32 >= E && ld16 >= E, "stream_operand: E / row strides not multiples of 8");
+    ESME_CHECK_ARG(aligned16(x32) && aligned16(x16) && (!sums || (reinterpret_cast<uintptr_t>(sums) & 7u) == 0), "stream_operand: misaligned");
+    const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, (f32x2*)sums, T, E); \
+                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, (f32x2*)sums, T, E); } while (0)
+    if (E <= 512) ESME_SO(1);
+    else if (E <= 1024) ESME_SO(2);
+    else if (E <= 1536) ESME_SO(3);
+    else if (E <= 2560) ESME_SO(5);
+    else if (E <= 5120) ESME_SO(10);
+    else ESME_FAIL(ESME_ERR_UNSUPPORTED, "stream_operand: E > 5120 unsupported");
+#undef ESME_SO
+    return check_launch("stream_operand");
+}
+
 extern "C" int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,
                                       int64_t T, int E, float eps, void* stream) {
     ESME_CHECK_ARG(T >= 0 && E > 0, "layernorm_f32: bad sizes");
@@ -874,10 +935,10 @@ extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* 
     return check_launch("segment_mean");
 }
 
-extern "C" int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
-                                              const void* bk, float eps, const void* cosT, const void* sinT,
-                                              const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, float q_scale,
-                                              void* stream) {
+static int qk_norm_rotary_impl(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                               const void* bk, float eps, const void* cosT, const void* sinT,
+                               const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, float q_scale,
+                               bool f16, void* stream) {
     ESME_CHECK_ARG(T >= 0 && heads > 0 && head_dim > 0 && max_len > 0, "qk_norm_rotary: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && wq && wk && cosT && sinT && pos, "qk_norm_rotary: null pointer");
@@ -896,8 +957,10 @@ extern "C" int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, cons
     const dim3 grid((unsigned int)((T + 2 * RPW - 1) / (2 * RPW))), block(256);
     const hipStream_t s = (hipStream_t)stream;
 #define ESME_QKN(N)                                                                                                 \
-    hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
-                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale)
+    do { if (f16) hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW, true>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
+                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale); \
+    else hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
+                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale); } while (0)
     if (E <= 512) ESME_QKN(1);
     else if (E <= 1024) ESME_QKN(2);
     else if (E <= 1536) ESME_QKN(3);
@@ -905,6 +968,19 @@ extern "C" int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, cons
     else ESME_QKN(10);
 #undef ESME_QKN
     return check_launch("qk_norm_rotary");
+}
+
+extern "C" int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                              const void* bk, float eps, const void* cosT, const void* sinT,
+                                              const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, float q_scale,
+                                              void* stream) {
+    return qk_norm_rotary_impl(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, q_scale, false, stream);
+}
+
+extern "C" int esme_hip_qk_norm_rotary_f16(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                           const void* bk, float eps, const void* cosT, const void* sinT,
+                                           const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, void* stream) {
+    return qk_norm_rotary_impl(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, 1.0f, true, stream);
 }
 
 extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,

@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -27,7 +27,7 @@ class GemmFusion(Structure):
     _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int),
-                ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64)]
+                ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64), ('f16', c_int)]
 
 
 class GemmOpts(Structure):
@@ -38,7 +38,7 @@ class GemmOpts(Structure):
 class AttnOpts(Structure):
     """esme_attn_opts_t (include/esme_hip.h)."""
     _fields_ = [('struct_bytes', c_int), ('variant', c_int), ('q_blocks', c_int), ('defer_max_thr', c_float), ('speculative', c_int),
-                ('seq_order', c_void_p), ('q_prescaled', c_int)]
+                ('seq_order', c_void_p), ('q_prescaled', c_int), ('f16', c_int)]
 
 
 class LayerWeights(Structure):
@@ -80,6 +80,9 @@ SIGNATURES = {
                                               c_int64, c_int, c_int, c_int, c_float, POINTER(AttnOpts), c_void_p]),
     'esme_hip_attn_varlen_fwd_exact': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                                c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    'esme_hip_qk_norm_rotary_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                            c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_void_p]),
     'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
@@ -410,12 +413,24 @@ def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torc
                     cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, heads: int, q_scale: float = 1.0) -> None:
     """In place on the (T, H*d) views q and k: LayerNorm over H*d (weights wq / wk, optional biases), bf16
     rounding, rotary -- one pass instead of three (ESM-C's q/k normalisation).  `q_scale` != 1: q leaves multiplied by it
-    (softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True))."""
-    qp, ld = _rows2d(q, 'qk_norm_rotary q')
-    kp, ldk = _rows2d(k, 'qk_norm_rotary k')
+    (softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True)).  float16 q / k / tables: precision 'half'."""
+    dt = q.dtype if q.dtype == torch.float16 else torch.bfloat16
+    qp, ld = _rows2d(q, 'qk_norm_rotary q', dt)
+    kp, ldk = _rows2d(k, 'qk_norm_rotary k', dt)
     if ld != ldk:
         raise ValueError('qk_norm_rotary: q and k must share a row stride')
     T, E = q.shape
+    if dt == torch.float16:
+        if q_scale != 1.0:
+            raise ValueError('qk_norm_rotary: q_scale is not available for float16 operands')
+        with _Traced('qk_norm_rotary', (T, E)):
+            _check(load().esme_hip_qk_norm_rotary_f16(
+                qp, kp, ld, _dev(wq, 'wq', torch.bfloat16), _dev(wk, 'wk', torch.bfloat16),
+                _dev(bq, 'bq', torch.bfloat16) if bq is not None else None,
+                _dev(bk, 'bk', torch.bfloat16) if bk is not None else None, float(eps),
+                _dev(cos, 'cos', torch.float16), _dev(sin, 'sin', torch.float16), _dev(pos, 'pos', torch.int32),
+                T, heads, E // heads, cos.shape[0], _stream()), 'esme_hip_qk_norm_rotary_f16')
+        return
     with _Traced('qk_norm_rotary', (T, E)):
         _check(load().esme_hip_qk_norm_rotary_scaled(
             qp, kp, ld, _dev(wq, 'wq', torch.bfloat16), _dev(wk, 'wk', torch.bfloat16),
@@ -432,17 +447,19 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     with every row maximum exact (esme_hip_attn_varlen_fwd_exact; the high-precision mode).  `order` (seq_order(cu_lens)):
     dispatch the longest sequences' work first -- speed only, the result is the same bit for bit.  `q_prescaled`: q already
     carries softmax_scale * log2(e) (gemm_fused(..., q_scale=)); `softmax_scale` is ignored and the head-dim-64 kernel runs its
-    no-reference-maximum form."""
-    qp, ld = _rows2d(q, 'attn q')
-    kp, ld2 = _rows2d(k, 'attn k')
-    vp, ld3 = _rows2d(v, 'attn v')
+    no-reference-maximum form.  float16 q, k, v (precision 'half'): float16 output, always the classic online softmax."""
+    f16 = q.dtype == torch.float16
+    dt = torch.float16 if f16 else torch.bfloat16
+    qp, ld = _rows2d(q, 'attn q', dt)
+    kp, ld2 = _rows2d(k, 'attn k', dt)
+    vp, ld3 = _rows2d(v, 'attn v', dt)
     if not (ld == ld2 == ld3):
         raise ValueError('attn: q, k, v must share a row stride')
     T, E = q.shape
     d = E // heads
     if out is None:
-        out = torch.empty(T, E, dtype=torch.bfloat16, device=q.device)
-    op, ldo = _rows2d(out, 'attn out')
+        out = torch.empty(T, E, dtype=dt, device=q.device)
+    op, ldo = _rows2d(out, 'attn out', dt)
     cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
     scale = softmax_scale if softmax_scale is not None else d ** -0.5
     ao = _TLS.attn_opts
@@ -450,11 +467,18 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
         raise ValueError('attn: `order` must be a permutation of the B sequence indices (seq_order(cu_lens))')
     if q_prescaled and exact:
         raise ValueError('attn: q_prescaled is not available through the exact entry (pass the unscaled q)')
-    if (order is not None or q_prescaled) and not exact:
+    if f16:
+        if q_prescaled:
+            raise ValueError('attn: q_prescaled is not available for float16 operands (P must stay <= 1)')
+        base = ao
+        ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0, 0.0, 0,
+                      _dev(order, 'seq order', torch.int32) if order is not None else None, 0, 1)
+        exact = False                                   # (the options entry: f16 implies the exact softmax)
+    elif (order is not None or q_prescaled) and not exact:
         base = ao
         ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0,
                       base.defer_max_thr if base else 8.0, base.speculative if base else 1,
-                      _dev(order, 'seq order', torch.int32) if order is not None else None, 1 if q_prescaled else 0)
+                      _dev(order, 'seq order', torch.int32) if order is not None else None, 1 if q_prescaled else 0, 0)
     with _Traced('attn', (T, heads, d)):
         if ao is not None and not exact:
             _check(load().esme_hip_attn_varlen_fwd_opts(qp, kp, vp, ld, op, ldo, _dev(cu, 'cu_lens', torch.int32), cu.numel() - 1, T,
@@ -482,6 +506,22 @@ def residual_f32_(x32: torch.Tensor, o: torch.Tensor, alpha: float, x16: torch.T
         _check(load().esme_hip_residual_f32(xp, ld32, opp, ldo, float(alpha), 1 if init else 0, yp, ld16,
                                             _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
                'esme_hip_residual_f32')
+
+
+def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor]) -> None:
+    """x16 <- round(x32) in x16's dtype (bfloat16, or float16 for precision 'half'); sums (1, T, 2) <- row {sum, sum sq} of the ROUNDED
+    values: the operand and the statistics the LayerNorm-folded GEMMs read at the start of a forward on an fp32 stream."""
+    if x16.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError('stream_operand: x16 must be bfloat16 or float16')
+    xp, ld32 = _rows2d(x32, 'stream_operand x32', torch.float32)
+    yp, ld16 = _rows2d(x16, 'stream_operand x16', x16.dtype)
+    T, E = x32.shape
+    if x16.shape != (T, E):
+        raise ValueError('stream_operand: shape mismatch')
+    with _Traced('stream_operand', (T, E)):
+        _check(load().esme_hip_stream_operand(xp, ld32, yp, ld16, 1 if x16.dtype == torch.float16 else 0,
+                                              _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
+               'esme_hip_stream_operand')
 
 
 def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, out: torch.Tensor) -> torch.Tensor:
@@ -633,8 +673,14 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     multiplied by it -- softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True).
     Split-operand ('exact') mode: `split_a`: a is (M, 2K) = [hi | lo] against w (N, K) (K doubled, W's K index wraps);
     `pair_out`: the result is written as a pair, out (M, 2 * n_out) = [hi | lo]; `out32` (M, N) fp32 receives the result instead
-    of `out` (scalar store path: the vocab projection)."""
-    ap, lda = _rows2d(a, 'gemm a')
+    of `out` (scalar store path: the vocab projection).
+    float16 `a` and `w` (precision 'half'): fp16 operands, float16 output, float16 rotary tables; `bias` stays bfloat16; the residual
+    epilogue needs `resid32`."""
+    f16 = a.dtype == torch.float16
+    dt = torch.float16 if f16 else torch.bfloat16
+    if f16 and (split_a or pair_out or out32 is not None):
+        raise ValueError('gemm: float16 operands do not combine with the split-operand arguments')
+    ap, lda = _rows2d(a, 'gemm a', dt)
     if not w.is_contiguous():
         raise ValueError('gemm: weight must be contiguous (N, K)')
     M, K = a.shape
@@ -643,13 +689,14 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         raise ValueError(f'gemm: K mismatch {a.shape} x {w.shape}')
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out is None:
-        out = torch.empty(M, 2 * n_out if pair_out else n_out, dtype=torch.bfloat16, device=a.device) if out32 is None else out32
+        out = torch.empty(M, 2 * n_out if pair_out else n_out, dtype=dt, device=a.device) if out32 is None else out32
     fu = GemmFusion()
+    fu.f16 = 1 if f16 else 0
     if out32 is not None:
         fu.c32, fu.ldc32 = _dev(out32, 'gemm out32', torch.float32), out32.stride(0)
         cp, ldc = fu.c32, out32.stride(0)               # (C itself is not written)
     else:
-        cp, ldc = _rows2d(out, 'gemm out')
+        cp, ldc = _rows2d(out, 'gemm out', dt)
     if split_a:
         fu.w_k = K // 2
     if pair_out:
@@ -676,7 +723,7 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         fu.stats_out = _dev(stats_out, 'stats_out', torch.float32)
     if rot is not None:
         cos, sin, pos, head_dim, rot_cols = rot
-        fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16), _dev(pos, 'pos', torch.int32)
+        fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', dt), _dev(sin, 'sin', dt), _dev(pos, 'pos', torch.int32)
         fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
         if q_scale:
             fu.q_scale, fu.q_cols = float(q_scale), int(rot_cols) // 2
@@ -686,14 +733,16 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         tag = 'residual_f32'
     if split_a or pair_out or out32 is not None:
         tag = f'split:{tag}'
+    if f16:
+        tag = f'f16:{tag}'
     with _Traced('gemm', (M, N, K, tag)):
         if go is not None:
-            _check(load().esme_hip_gemm_bf16_opts(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+            _check(load().esme_hip_gemm_bf16_opts(ap, lda, _dev(w, 'gemm w', dt),
                                                   _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
                                                   rp, ldr, cp, ldc, M, N, K, epilogue, alpha, ctypes.byref(fu), ctypes.byref(go),
                                                   _stream()), 'esme_hip_gemm_bf16_opts')
         else:
-            _check(load().esme_hip_gemm_bf16_fused(ap, lda, _dev(w, 'gemm w', torch.bfloat16),
+            _check(load().esme_hip_gemm_bf16_fused(ap, lda, _dev(w, 'gemm w', dt),
                                                    _dev(bias, 'gemm bias', torch.bfloat16) if bias is not None else None,
                                                    rp, ldr, cp, ldc, M, N, K, epilogue, alpha, ctypes.byref(fu), _stream()),
                    'esme_hip_gemm_bf16_fused')

@@ -48,10 +48,11 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16')
 
-    def __init__(self, pos, cos, sin, fold=False, exact_attn=False):
+    def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False):
         self.pos, self.cos, self.sin = pos, cos, sin
+        self.f16 = f16              # precision 'half': IEEE fp16 MFMA operands (weights converted once, activations rounded to fp16)
         self.fold = fold            # run the LN-folded fast path
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
         self.x32 = None             # high-precision mode: the fp32 residual stream (T, E_phys)
@@ -104,9 +105,9 @@ def _version_key(*params):
 
 
 def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
-                    beta: Optional[torch.Tensor]):
-    """(W' = bf16(W*gamma), c1 = rowsum(W'), c2 = W beta + bias) for the LN-folded GEMM."""
-    wf = (w.float() * gamma.float().unsqueeze(0)).to(torch.bfloat16).contiguous()
+                    beta: Optional[torch.Tensor], dtype=torch.bfloat16):
+    """(W' = bf16(W*gamma), c1 = rowsum(W'), c2 = W beta + bias) for the LN-folded GEMM (`dtype` float16: precision 'half')."""
+    wf = (w.float() * gamma.float().unsqueeze(0)).to(dtype).contiguous()
     c1 = wf.float().sum(dim=1).contiguous()
     c2 = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
     if beta is not None:
@@ -151,6 +152,10 @@ class FlashMultiheadAttention(nn.Module):
         self._pack_key = None
         self._fold = None           # (W', c1, c2) of the LN-folded QKV projection
         self._fold_key = None
+        self._fold16 = None         # the same with W' in float16 (precision 'half'), and the float16 out-projection weight
+        self._fold16_key = None
+        self._out16 = None
+        self._out16_key = None
         self._q4_qkv = None         # esme.quantization.Q4Matrix pair when the layer is 4-bit
         self._q4_out = None
         self._out_w = self._out_b = None    # padded out-projection (padded layouts only)
@@ -197,20 +202,29 @@ class FlashMultiheadAttention(nn.Module):
         self._pack_key = _version_key(self.q.weight, self.k.weight, self.v.weight,
                                       self.q.bias, self.k.bias, self.v.bias)
 
-    def _pack_fold(self):
-        """LN-folded copy of the fused QKV weight (self.norm folded in)."""
+    def _pack_fold(self, f16: bool = False):
+        """LN-folded copy of the fused QKV weight (self.norm folded in); `f16`: W' in float16 (precision 'half')."""
         self._pack()
         key = (self._pack_key, _version_key(self.norm.weight, self.norm.bias))
-        if key != self._fold_key:
+        if key != (self._fold16_key if f16 else self._fold_key):
             with torch.no_grad():
-                self._fold = _fold_layernorm(self._qkv_w, self._qkv_b, _pad_last(self.norm.weight.data, self.phys_dim),
-                                             _pad_last(self.norm.bias.data, self.phys_dim) if self.norm.bias is not None else None)
-            self._fold_key = key
-        return self._fold
+                fold = _fold_layernorm(self._qkv_w, self._qkv_b, _pad_last(self.norm.weight.data, self.phys_dim),
+                                       _pad_last(self.norm.bias.data, self.phys_dim) if self.norm.bias is not None else None,
+                                       torch.float16 if f16 else torch.bfloat16)
+            if f16:
+                self._fold16, self._fold16_key = fold, key
+            else:
+                self._fold, self._fold_key = fold, key
+        return self._fold16 if f16 else self._fold
 
-    def _weights_qkv(self, fold: bool):
+    def _weights_qkv(self, fold: bool, f16: bool = False):
         """(W, bias, c1, c2) of the fused QKV projection: the LN-folded form when `fold`
         (bias inside c2), else the plain one.  4-bit layers expand into the shared scratch."""
+        if f16:
+            if self._q4_qkv is not None or not fold:
+                raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
+            wf, c1, c2 = self._pack_fold(True)
+            return wf, None, c1, c2
         if self._q4_qkv is not None:
             if fold:
                 w, c1, c2 = self._q4_qkv.folded()
@@ -222,7 +236,17 @@ class FlashMultiheadAttention(nn.Module):
         self._pack()
         return self._qkv_w, self._qkv_b, None, None
 
-    def _weights_out(self):
+    def _weights_out(self, f16: bool = False):
+        if f16:
+            if self._q4_out is not None:
+                raise NotImplementedError("precision='half' needs unquantised weights")
+            w, b = self._weights_out()
+            key = _version_key(w)
+            if key != self._out16_key:
+                with torch.no_grad():
+                    self._out16 = w.data.to(torch.float16).contiguous()      # exact for |w| >= 2^-14 (bf16 has 8 significant bits)
+                self._out16_key = key
+            return self._out16, b
         if self._q4_out is not None:
             return self._q4_out.plain()
         if self.padded:
@@ -276,8 +300,11 @@ class FlashMultiheadAttention(nn.Module):
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
         qk_pass = (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128) and E <= 5120)
         qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
+        f16 = bool(ctx is not None and ctx.f16)
+        if f16 and (x_stats is None or resid32 is None or (self.rot_emb is not None and not (rot_fusable or qk_pass))):
+            raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 stream, head dim 16 / 32 / 64 (fused rotary)")
         if x_stats is not None:
-            wf, _, c1, c2 = self._weights_qkv(True)
+            wf, _, c1, c2 = self._weights_qkv(True, f16)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,
                                   q_scale=_q_scale(self.head_dim) if (qp and rot_fusable) else 0.0)
         else:
@@ -300,7 +327,7 @@ class FlashMultiheadAttention(nn.Module):
                     q, k = self.rot_emb(q, k, cu_lens, max_len, inplace=True)
         a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn),
                        order=ctx.order if ctx is not None else None, q_prescaled=qp)
-        wo, bo = self._weights_out()
+        wo, bo = self._weights_out(f16)
         if resid is not None or resid32 is not None:
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)
         return _hip.gemm(a, wo, bo, out=out)
@@ -367,34 +394,49 @@ class FlashTransformerLayer(nn.Module):
         self.final_activation = final_activation
         self._fold = None
         self._fold_key = None
+        self._fold16 = None         # float16 forms (precision 'half'): folded up-projection, down-projection weight
+        self._fold16_key = None
+        self._down16 = None
+        self._down16_key = None
         self._q4_up = None          # esme.quantization.Q4Matrix pair when the layer is 4-bit
         self._q4_down = None
 
-    def _pack_fold(self):
-        """LN-folded copy of the FFN up-projection weight (self.final[0] folded in)."""
+    def _pack_fold(self, f16: bool = False):
+        """LN-folded copy of the FFN up-projection weight (self.final[0] folded in); `f16`: in float16 (precision 'half')."""
         ln = self.final[0]
         beta = ln.bias.data if ln.bias is not None else None
+        dt = torch.float16 if f16 else torch.bfloat16
+        have = self._fold16_key if f16 else self._fold_key
+        fold = None
         if self.final_activation == 'gelu':
             up = self.final[1]
             key = _version_key(up.weight, up.bias, ln.weight, ln.bias)
-            if key != self._fold_key:
+            if key != have:
                 with torch.no_grad():
                     Ep = self.phys_dim
-                    self._fold = _fold_layernorm(_pad_last(up.weight.data, Ep), up.bias.data if up.bias is not None else None,
-                                                 _pad_last(ln.weight.data, Ep), _pad_last(beta, Ep))
-                self._fold_key = key
+                    fold = _fold_layernorm(_pad_last(up.weight.data, Ep), up.bias.data if up.bias is not None else None,
+                                           _pad_last(ln.weight.data, Ep), _pad_last(beta, Ep), dt)
         else:
             sw = self.final[1]
             sw._pack()
             key = (sw._pack_key, _version_key(ln.weight, ln.bias))
-            if key != self._fold_key:
+            if key != have:
                 with torch.no_grad():
-                    self._fold = _fold_layernorm(sw._packed, None, ln.weight.data, beta)
-                self._fold_key = key
-        return self._fold
+                    fold = _fold_layernorm(sw._packed, None, ln.weight.data, beta, dt)
+        if fold is not None:
+            if f16:
+                self._fold16, self._fold16_key = fold, key
+            else:
+                self._fold, self._fold_key = fold, key
+        return self._fold16 if f16 else self._fold
 
-    def _weights_up(self, fold: bool):
+    def _weights_up(self, fold: bool, f16: bool = False):
         """(W, bias, c1, c2) of the FFN up-projection (gate/fc interleaved for SwiGLU)."""
+        if f16:
+            if self._q4_up is not None or not fold:
+                raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
+            wf, c1, c2 = self._pack_fold(True)
+            return wf, None, c1, c2
         if self._q4_up is not None:
             if fold:
                 w, c1, c2 = self._q4_up.folded()
@@ -410,7 +452,17 @@ class FlashTransformerLayer(nn.Module):
         self.final[1]._pack()
         return self.final[1]._packed, None, None, None
 
-    def _weights_down(self):
+    def _weights_down(self, f16: bool = False):
+        if f16:
+            if self._q4_down is not None:
+                raise NotImplementedError("precision='half' needs unquantised weights")
+            w, b = self._weights_down()
+            key = _version_key(w)
+            if key != self._down16_key:
+                with torch.no_grad():
+                    self._down16 = w.data.to(torch.float16).contiguous()
+                self._down16_key = key
+            return self._down16, b
         if self._q4_down is not None:
             return self._q4_down.plain()
         down = self.final[3] if self.final_activation == 'gelu' else self.final[2]
@@ -426,13 +478,14 @@ class FlashTransformerLayer(nn.Module):
 
     def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
+        f16 = x.dtype == torch.float16                       # precision 'half': the operand type travels with the tensors
         if x_stats is not None:
-            wf, _, c1, c2 = self._weights_up(True)
+            wf, _, c1, c2 = self._weights_up(True, f16)
             u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, self.embed_dim, self.final[0].eps, c1, c2))
         else:
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
-        wd, bd = self._weights_down()
+        wd, bd = self._weights_down(f16)
         return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)
 
     def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext):

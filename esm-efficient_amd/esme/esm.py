@@ -71,6 +71,9 @@ class ESM2(nn.Module):
     # LayerNorm statistics + exact online softmax, bf16 only at MFMA operands; slower.
     # 'exact': split-operand mode -- every activation feeding a matrix product is a (hi, lo) bf16 pair, fp32 everywhere else;
     # reproduces the reference's fp32 forward (esme/esm.py:132-141 `dtype=`) to ~1e-5, returns fp32.
+    # 'half': 'high' with IEEE fp16 MFMA operands (weights converted once -- exact for bf16 checkpoints --, activations rounded to 11
+    # significant bits instead of 8, same MFMA rate) and the LM head in split-operand form: fp32 logits within ~5e-4 of the fp32 forward
+    # at ~1.1x the time of 'fast'.  Values must stay inside fp16's range (|x| < 65 504).
     precision = os.environ.get('ESME_PRECISION', 'fast')
     # all layers + final LayerNorm through ONE C call (esme_hip_forward) instead of ~5 Python-issued launches per layer
     c_forward = os.environ.get('ESME_NO_C_FORWARD', '0') != '1'
@@ -150,9 +153,10 @@ class ESM2(nn.Module):
         return ModelDescriptor.supported(self)
 
     def set_precision(self, mode: str):
-        """'fast' (default), 'high' (fp32 residual stream) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to
-        ~1e-5, fp32 outputs, ~2.3x the time); DESIGN.md section 4 has what each achieves."""
-        assert mode in ('fast', 'high', 'exact'), mode
+        """'fast' (default), 'high' (fp32 residual stream), 'half' (fp32 stream + fp16 MFMA operands: ~5e-4 of the fp32 forward, fp32
+        outputs, ~1.1x the time) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to ~1e-5, fp32 outputs, ~2.5x the
+        time); DESIGN.md section 4 has what each achieves."""
+        assert mode in ('fast', 'high', 'half', 'exact'), mode
         self.precision = mode
         self.invalidate_graphs()
         return self
@@ -174,8 +178,9 @@ class ESM2(nn.Module):
         rot = self.layers[0].self_attn.rot_emb if len(self.layers) else None
         cos = sin = None
         if rot is not None:
-            cos, sin = rot.tables(int(max_len), device, torch.float32 if self.precision == 'exact' else torch.bfloat16)
-        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high')
+            cos, sin = rot.tables(int(max_len), device, {'exact': torch.float32, 'half': torch.float16}.get(self.precision, torch.bfloat16))
+        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision in ('high', 'half'),
+                              f16=self.precision == 'half')
 
     def _unpad(self, x, tokens):
         """Boolean-mask row gather: the `unpad_input` contract (esm.py:238)."""
@@ -255,6 +260,26 @@ class ESM2(nn.Module):
             _hip.layernorm_split(ctx.x32, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
             if want_pair:
                 x, taps = pair, []
+        elif self.precision == 'half':
+            # fp32 residual stream, fp16 MFMA operands: x16 = fp16(stream) is what the LayerNorm-folded GEMMs read; the final LayerNorm
+            # and the LM head run in the split-operand form (fp32 representation / logits)
+            assert not self.padded, "precision='half' needs a 64-aligned embedding width and a supported head dim"
+            T = x.shape[0]
+            ctx.x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
+            x16 = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+            ctx.sums = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
+            _hip.stream_operand(ctx.x32, x16, ctx.sums)
+            ctx.order = _hip.seq_order(cu_lens)
+            for i, layer in enumerate(self.layers):
+                layer.forward_high_precision(x16, cu_lens, max_len, ctx)
+                if i in layers:
+                    taps.append(ctx.x32.clone())
+            ln = self.emb_layer_norm_after
+            pair = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=x.device)
+            x = torch.empty(T, E, dtype=torch.float32, device=x.device)
+            _hip.layernorm_split(ctx.x32, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
+            if want_pair:
+                x, taps = pair, []
         elif self.precision == 'high' and len(self.layers):
             # fp32 residual stream; x (bf16) is kept as the rounded copy the GEMMs read
             assert x.shape[1] % 64 == 0, 'high-precision mode needs a 64-aligned physical width'
@@ -285,10 +310,10 @@ class ESM2(nn.Module):
         return torch.concat((x, *taps), dim=-1) if taps else x
 
     def forward(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
-        """Logits (T, V) / (B, S, V), bf16 (fp32 with precision 'exact'), on the model's device (esm.py:268-282)."""
+        """Logits (T, V) / (B, S, V), bf16 (fp32 with precision 'exact' / 'half'), on the model's device (esm.py:268-282)."""
         assert lora_names is None, 'LoRA adapters are outside the inference hot path'
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            if self.precision == 'exact':                     # fp32 logits from the (hi, lo) pair of the final LayerNorm
+            if self.precision in ('exact', 'half'):           # fp32 logits from the (hi, lo) pair of the final LayerNorm
                 pair = self._forward_representation(tokens, pad_args, pad_output, pad_indices, [], want_pair=True)
                 y = self.lm_head.forward_exact(pair.reshape(-1, pair.shape[-1]))
                 return y.view(*pair.shape[:-1], y.shape[-1])

@@ -104,7 +104,7 @@ def masked_row_log_prob(model, token: torch.Tensor, local_pos: torch.Tensor, gra
         lp = model.predict_log_prob(token, pad_output=True)
         return lp[torch.arange(B, device=device), local_pos.to(device)]
     cu_lens = torch.arange(0, (B + 1) * L, L, dtype=torch.int32, device=device)
-    if getattr(model, 'precision', 'fast') == 'exact':      # split-operand mode: fp32 log-probs of every row (the head needs the (hi, lo) pair), then pick
+    if getattr(model, 'precision', 'fast') in ('exact', 'half'):      # split-operand mode: fp32 log-probs of every row (the head needs the (hi, lo) pair), then pick
         lp = model.predict_log_prob(token.reshape(-1), (cu_lens, L))
         return lp[(torch.arange(B, dtype=torch.int64) * L + local_pos.to(torch.int64).cpu()).to(device)]
     if graph:

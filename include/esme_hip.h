@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 6
+#define ESME_HIP_ABI_VERSION 7
 
 enum {
     ESME_OK = 0,
@@ -94,6 +94,14 @@ int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, const void* b,
 int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, int64_t ldo, float alpha, int init,
                           void* x16, int64_t ld16, float* sums, int64_t T, int E, void* stream);
 
+/* The MFMA operand of an fp32 residual stream: x16 = round(x32) -- bf16, or IEEE fp16 when f16 != 0 (precision 'half') -- and, when
+ * sums != NULL, per row {sum, sum of squares} of the ROUNDED values, float (1, T, 2) (pass as ln_partial, ln_nblk = 1).  Starts a
+ * forward whose stream does not begin as bf16 embedding rows (esme_hip_residual_f32 init) or whose operand type is fp16; afterwards the
+ * residual GEMMs (esme_gemm_fusion_t.resid32) keep x16 and the statistics current.  No counterpart in the reference (its stream is
+ * the activation dtype throughout, esme/attention.py:253-255). */
+int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int f16, float* sums,
+                            int64_t T, int E, void* stream);
+
 /* esme_hip_layernorm on an fp32 input (bf16 affine parameters and output): the final LayerNorm of the
  * high-precision mode (esme/esm.py:252). */
 int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const void* b, void* y,
@@ -123,6 +131,14 @@ int esme_hip_qk_norm_rotary_scaled(void* q, void* k, int64_t ld, const void* wq,
                                    const void* bq, const void* bk, float eps, const void* cos,
                                    const void* sin, const int32_t* pos, int64_t T, int H, int d,
                                    int max_len, float q_scale, void* stream);
+
+/* esme_hip_qk_norm_rotary on IEEE fp16 q, k and fp16 rotary tables (precision 'half'; the LayerNorm parameters stay bf16, the LayerNorm
+ * output stays fp32 up to the rotation where the bf16 form rounds it to bf16 as the reference does: the mode answers to the reference's
+ * fp32 forward). */
+int esme_hip_qk_norm_rotary_f16(void* q, void* k, int64_t ld, const void* wq, const void* wk,
+                                const void* bq, const void* bk, float eps, const void* cos,
+                                const void* sin, const int32_t* pos, int64_t T, int H, int d,
+                                int max_len, void* stream);
 
 /* Varlen (block-diagonal) multi-head self-attention, non-causal, no dropout:
  * per sequence i and head h, O = softmax(Q K^T * softmax_scale) V over that sequence's
@@ -159,6 +175,8 @@ typedef struct esme_attn_opts {
     int speculative;
     const int32_t* seq_order;
     int q_prescaled;
+    int f16;                     /* != 0: q, k, v and o are IEEE fp16 (precision 'half'); implies the classic online softmax with exact row
+                                  * maxima (P <= 1 fits fp16), does not combine with q_prescaled */
 } esme_attn_opts_t;
 int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv,
                                   void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
@@ -268,7 +286,13 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              copy of W in memory, its second pass served from L2).  pair_off makes the epilogue emit its fp32 result as
  *              such a pair for the next GEMM (plain + fused rotary, GELU, SwiGLU epilogues); c32 returns it in fp32 (the
  *              (T, V) logits).  Every product the reference's fp32 forward (`dtype=torch.float32`, esme/esm.py:132-141)
- *              forms with an activation is then reproduced to ~2^-17 instead of bf16's 2^-9. */
+ *              forms with an activation is then reproduced to ~2^-17 instead of bf16's 2^-9.
+ *  - f16 != 0 (precision 'half', model.set_precision('half')): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (`bias`
+ *              stays bf16: a checkpoint parameter).  bf16 weights convert to fp16 exactly (|w| >= 2^-14; below that to 2^-24
+ *              absolute), and an fp16 activation carries 11 significant bits instead of 8 at the same MFMA rate: with the fp32
+ *              residual stream (resid32, mandatory for ESME_EPI_RESIDUAL here) the logits land at ~5e-4 of the reference's fp32
+ *              forward in ONE pass over K.  Plain (+ LN-folded fused rotary), GELU, LN-folded SwiGLU and
+ *              resid32 residual epilogues; 16-byte addressable C.  The caller guarantees |values| < 65 504 (fp16's range). */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;
@@ -292,6 +316,7 @@ typedef struct esme_gemm_fusion {
     int64_t pair_off;            /* != 0: C receives the result as a (hi, lo) bf16 pair, lo at column pair_off + n of the same row */
     float* c32;                  /* != NULL: the result is written in fp32 to c32 (M, N), row stride ldc32, instead of C */
     int64_t ldc32;
+    int f16;                     /* != 0: fp16 operands and output (precision 'half'), see above */
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */

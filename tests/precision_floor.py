@@ -15,6 +15,9 @@ shows WHY no mode with bf16 MFMA operands can reach 1e-3, by emulating on the CP
   split-attn:<qk><p><v>  split-gemm plus a choice of WHICH attention operands are pairs ('d') or single bf16 ('s'), e.g.
             split-attn:ssd = only V.  Round 4 used this table to design attn_split_kernel: V matters most
             (9.2e-4 -> 4.7e-4), q/k + V reach 2.7e-4, only all three (= 'split') leave two orders of margin under 1e-3.
+  half      'ideal' with IEEE fp16 instead of bf16 as the operand type (11 significant bits; bf16 weights convert exactly): what
+            precision 'half' builds -- ONE MFMA pass at the bf16 rate.  4.7e-4 at 33 x 1280 (--half also prints it with fp16 rotary
+            tables: 4.8e-4).
   --tables bf16  additionally rounds the rotary tables to bf16 (what the fused QKV epilogue uses): 4.8e-4 on its own, which is why
             the split-operand mode has its own rotary kernel with fp32 tables.
 
@@ -42,6 +45,10 @@ def r16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def h16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
 def make_ops(mode):
     """(operand transform, matmul) for one emulation mode.  `operand(x)` returns what the matrix unit is fed."""
     if mode.startswith('split-attn:'):
@@ -63,6 +70,8 @@ def make_ops(mode):
                 y = y + A[0] @ B[1]
             return y
         return lin, (mm_qk, mm_pv)
+    if mode == 'half':
+        return (lambda x, w, b=None: F.linear(h16(x), w, b)), (lambda a, b_: h16(a) @ h16(b_))
     if mode in ('split', 'split-gemm'):
         def lin(x, w, b=None):                      # 2 passes for a bf16 weight: (hi + lo) @ W^T
             hi = r16(x)
@@ -88,7 +97,7 @@ def make_ops(mode):
 
 def forward(weights, heads, tokens, cu_lens, max_len, mode, tables='fp32'):
     """ESM-2 packed forward -> logits, fp32 with the operand rounding of `mode` ('ideal', 'stream', 'split-gemm', 'split',
-    'split-attn:<qk><p><v>')."""
+    'split-attn:<qk><p><v>', 'half')."""
     lin, mm = make_ops(mode)
     mm_qk, mm_pv = mm if isinstance(mm, tuple) else (mm, mm)
     kind, L, E = O._cfg_of(weights)
@@ -98,6 +107,8 @@ def forward(weights, heads, tokens, cu_lens, max_len, mode, tables='fp32'):
     cos, sin = O.rotary_tables(max_len, d, torch.float32)
     if tables == 'bf16':
         cos, sin = r16(cos), r16(sin)
+    elif tables == 'fp16':
+        cos, sin = h16(cos), h16(sin)
     pos = O.culen_positions(cu_lens)
     x = O.embedding(w, tokens, kind, torch.float32, cu_lens)
     store = r16 if mode == 'stream' else (lambda t: t)
@@ -133,6 +144,8 @@ def floors(L, E, H, lengths, seed=0, extra=(), tables='fp32'):
     out = {'reference-equivalent bf16 forward': rel(O.forward_logits(weights, H, tokens, cu, max(lengths), torch.bfloat16).float())}
     for mode in ('stream', 'ideal', 'split-gemm', 'split') + tuple(extra):
         out[mode] = rel(forward(weights, H, tokens, cu, max(lengths), mode))
+    if 'half' in extra:
+        out['half, fp16 rotary tables'] = rel(forward(weights, H, tokens, cu, max(lengths), 'half', tables='fp16'))
     if tables == 'bf16':
         out['split, bf16 rotary tables'] = rel(forward(weights, H, tokens, cu, max(lengths), 'split', tables='bf16'))
     return out
@@ -145,11 +158,14 @@ if __name__ == '__main__':
     ap.add_argument('--heads', type=int, default=20)
     ap.add_argument('--tokens', type=int, default=300)
     ap.add_argument('--attn', action='store_true', help='also the split-attn:<qk><p><v> table (which attention operands must be pairs)')
+    ap.add_argument('--half', action='store_true', help="also 'half': fp16 operands in one pass (precision 'half')")
     ap.add_argument('--tables', choices=['fp32', 'bf16'], default='fp32')
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
     lengths = [a.tokens - a.tokens // 3, a.tokens // 3]
     extra = tuple(f'split-attn:{q}{p}{v}' for q in 'sd' for p in 'sd' for v in 'sd') if a.attn else ()
+    if a.half:
+        extra += ('half',)
     res = floors(a.layers, a.embed, a.heads, lengths, extra=extra, tables=a.tables)
     print(f'ESM-2 geometry L={a.layers} E={a.embed} H={a.heads}, {a.tokens} residues; rel-Frobenius of the logits vs the fp32-math forward')
     for k, v in res.items():

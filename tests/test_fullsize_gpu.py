@@ -203,6 +203,36 @@ def test_exact_mode_full_depth():
     assert e_lp <= 1.0e-4, e_lp
 
 
+def test_half_mode_full_depth():
+    """north_star "logits within 1e-3 rel-err of the reference forward" at ~1.1x the fast mode's time: `model.set_precision('half')` (fp32
+    residual stream, IEEE fp16 MFMA operands -- the bf16 checkpoint converts exactly --, exact online softmax, split-operand LM head, fp32
+    logits) at the headline size -- ESM2-650M, 33 layers, 50 000 residues -- three whole sequences vs the fp32-math oracle.  The CPU
+    emulation of "fp32 math, fp16 operands" says 4.7e-4 (tests/precision_floor.py --half); the bar is 1e-3."""
+    model, w, H = load('esm2_650m')
+    tokens, cu, max_len, lengths = syn.uniform_batch(50000, 500, seed=0)
+    picks = [0, 57, 99]
+    cul = cu.tolist()
+    sub_t = torch.cat([tokens[cul[i]:cul[i + 1]] for i in picks])
+    sub_cu = syn.cu_lens_of([500] * 3)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    ref32 = O.forward_logits(w, H, sub_t, sub_cu, 500, dtype=torch.float32).float()
+    rows = lambda out: torch.cat([out[cul[i]:cul[i + 1]] for i in picks]).float().cpu()
+    model.set_precision('half')
+    out = model(tokens.to(DEV), (cu.to(DEV), max_len))
+    assert out.dtype == torch.float32 and out.shape == (50000, model.vocab_size) and torch.isfinite(out).all()
+    half = rows(out)
+    alone = model(sub_t.to(DEV), (sub_cu.to(DEV), 500))
+    assert torch.equal(alone.cpu(), half), 'half mode: packed rows differ from the sequences run alone'
+    lp = model.predict_log_prob(sub_t.to(DEV), (sub_cu.to(DEV), 500))
+    model.set_precision('fast')
+    e_half = rel_fro(half, ref32)
+    e_lp = rel_fro(lp.cpu(), torch.log_softmax(ref32, -1))
+    print(f'\n[precision] ESM2-650M x 33 layers, 50 000 residues: rel_fro vs fp32 oracle: half {e_half:.3e} (log-probs {e_lp:.3e}); '
+          f'max|err| {float((half - ref32).abs().max()):.3e}')
+    assert e_half <= 1.0e-3, e_half                           # north_star's tolerance
+    assert e_lp <= 1.0e-3, e_lp
+
+
 def test_exact_mode_esmc_600m_full_depth():
     """The split-operand mode on BASELINE config 5's model at its real depth: ESMC-600M (36 layers, E = 1152, q/k LayerNorm, SwiGLU) on
     32 x 1 002 residues, one whole sequence vs the fp32-math oracle: <= 1e-3 (north_star), measured ~1e-5."""
@@ -222,3 +252,32 @@ def test_exact_mode_esmc_600m_full_depth():
     e = rel_fro(got, ref32)
     print(f'\n[precision] ESMC-600M x 36 layers, 32 x 1 002 residues, exact mode: rel_fro vs fp32 oracle {e:.3e}')
     assert e <= 1.0e-3 and e <= 1.0e-4, e
+
+
+def test_half_mode_esmc_600m_full_depth():
+    """precision 'half' on BASELINE config 5's model at its real depth: ESMC-600M (36 layers, E = 1152, q/k LayerNorm, SwiGLU) on
+    32 x 1 002 residues, one whole sequence vs the fp32-math oracle.  ESM-C is the harder geometry for a single-pass mode: the CPU
+    emulation of "fp32 math, every matrix operand rounded to fp16" sits at 9.2e-4 here (bf16: 7.4e-3; ESM2-650M: 4.7e-4 / 3.8e-3), and
+    the kernel path adds the fp16 rounding of the LayerNorm-folded weights: measured 1.2e-3 -- eight times closer than the fast mode,
+    but NOT inside north_star's 1e-3, which is quoted on ESM2-650M (test_half_mode_full_depth).  The bar here is 2e-3 and a quarter of the
+    fast mode's error; precision 'exact' is the mode that meets 1e-3 on ESM-C (test_exact_mode_esmc_600m_full_depth: 1e-5)."""
+    model, w, H = load('esmc_600m')
+    tokens, cu, max_len, lengths = syn.uniform_batch(32 * 1002, 1002, seed=5)
+    cul = cu.tolist()
+    i = 17
+    sub_t, sub_cu = tokens[cul[i]:cul[i + 1]], syn.cu_lens_of([1002])
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    ref32 = O.forward_logits(w, H, sub_t, sub_cu, 1002, dtype=torch.float32).float()
+    fast = model(tokens.to(DEV), (cu.to(DEV), max_len))[cul[i]:cul[i + 1]].float().cpu()
+    model.set_precision('half')
+    out = model(tokens.to(DEV), (cu.to(DEV), max_len))
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    got = out[cul[i]:cul[i + 1]].cpu()
+    alone = model(sub_t.to(DEV), (sub_cu.to(DEV), 1002))
+    assert torch.equal(alone.cpu(), got), 'half mode (ESM-C): packed rows differ from the sequence run alone'
+    model.set_precision('fast')
+    e = rel_fro(got, ref32)
+    e_fast = rel_fro(fast, ref32)
+    print(f'\n[precision] ESMC-600M x 36 layers, 32 x 1 002 residues: rel_fro vs fp32 oracle: half {e:.3e} | fast {e_fast:.3e}')
+    assert e <= 2.0e-3 and e <= 0.25 * e_fast, (e, e_fast)
+

@@ -5,7 +5,7 @@ to bf16.  This test runs a small instance (ESM2-8M geometry) and pins the orderi
 an ideal bf16-operand forward is already several 1e-3 away from the fp32-math forward (so no kernel schedule, residual-stream
 width or softmax variant can reach 1e-3), splitting only the projections' activations into (hi, lo) bf16 pairs lands near 1e-3,
 and splitting every operand is ~1e-5.  At the headline geometry (33 layers, E = 1280; `python tests/precision_floor.py`):
-reference-equivalent bf16 1.3e-2, bf16 stream 1.2e-2, ideal 3.8e-3, split-gemm 1.0e-3, split 5.7e-6.
+reference-equivalent bf16 1.3e-2, bf16 stream 1.2e-2, ideal 3.8e-3, split-gemm 1.0e-3, split 5.7e-6, fp16 operands ('half') 4.7e-4.
 """
 import torch
 
@@ -14,9 +14,11 @@ from precision_floor import floors
 
 def test_bf16_operand_floor_is_above_1e_3():
     torch.manual_seed(0)
-    res = floors(6, 320, 20, [70, 50], seed=0)
+    res = floors(6, 320, 20, [70, 50], seed=0, extra=('half',))
     print('\n' + '\n'.join(f'[floor] {k:36s} {v:.3e}' for k, v in res.items()))
     assert res['ideal'] > 2e-3, res                      # the floor of ANY forward with single-bf16 operands
     assert res['stream'] > res['ideal'], res             # the bf16 residual stream adds the depth-dependent part
     assert res['reference-equivalent bf16 forward'] > res['ideal'], res
     assert res['split'] < 1e-4 < res['split-gemm'] < res['ideal'], res
+    # fp16 operands (precision 'half': ONE pass at the bf16 MFMA rate): three more significant bits = an eighth of the ideal bf16 floor
+    assert res['half'] < 1e-3 and res['half'] < 0.2 * res['ideal'] and abs(res['half, fp16 rotary tables'] - res['half']) < 0.2 * res['half'], res
