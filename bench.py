@@ -336,8 +336,8 @@ def main():
                    'launcher': 'torch.distributed.run (self-launched)' if os.environ.get('ESME_BENCH_SPAWNED') else
                                ('torch.distributed.run' if launched else 'plain python'),
                    'precision': {'fast': 'fast (bf16 residual stream)', 'high': 'high (fp32 residual stream)',
-                                 'half': 'half (fp32 residual stream, IEEE fp16 MFMA operands converted exactly from the bf16 weights, exact online '
-                                         'softmax, split-operand LM head, fp32 logits)',
+                                 'half': 'half (fp32 residual stream, IEEE fp16 MFMA operands converted exactly from the bf16 weights, '
+                                         'split-operand LM head, fp32 logits)',
                                  'exact': 'exact (split (hi, lo) bf16 operand pairs, fp32 residual stream, fp32 logits; 2 MFMA passes per '
                                           'projection, 3 per attention product)'}[args.precision],
                    'setup': '2 untimed forwards before the warm-up steps (weight packing / LN folding, module load)',

@@ -659,8 +659,9 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 // 64 B (tiles of 4 KB, one LDS-DMA piece per wave and tile), two k-steps per S^T block and ONE 32-row block of O^T, i.e. 8 MFMAs per
 // phase against the same 16 score pairs: two pairs per MFMA slot.  The VALU port bounds it harder than head dim 64 (the softmax work
 // per score is the same, the MFMA work half), but the ping-pong schedule, the LDS-DMA data path and the speculative softmax carry over.
-// F16 (precision 'half'): q, k, v, P and o are IEEE fp16 (11 significant bits).  P must stay <= 1 -- fp16 ends at 65 504 -- so the host runs this
-// form with the classic online softmax only (a.spec = 0, thr = 0: every row maximum exact), never with the speculative / QP passes.
+// F16 (precision 'half'): q, k, v, P and o are IEEE fp16 (11 significant bits).  fp16 ends at 65 504, so there is no QP form (P = exp2(score) with
+// no reference at all); the speculative pass against the FIRST tile's maximum stays (P = 2^(how far a later score beats that maximum): a
+// handful on real data) with the overflow test tightened to fp16's range -- a work item that trips it is redone with exact maxima (P <= 1).
 template <int NW, bool QP = false, int D = 64, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
     static_assert(!F16 || !QP, "fp16 P needs a reference maximum");
@@ -927,7 +928,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         }
         pair_sum_pack(15, pa0, pa1);
         const float psum = (ps0 + ps1) + (ps2 + ps3);
-        if (__any(!(psum < 1e30f))) ovf = 1;                 // overflow (inf / NaN included): the work item is redone exactly
+        // overflow (inf / NaN included): the work item is redone exactly.  fp16 P ends at 65 504: a lane's partial sum below 3e4 bounds each of
+        // its P values (the pack would have produced inf otherwise; those MFMAs are discarded with the redo)
+        if (__any(!(psum < (F16 ? 3.0e4f : 1e30f)))) ovf = 1;
         lrun[bs] += psum;
     };
     using I0 = std::integral_constant<int, 0>;
@@ -1490,8 +1493,7 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn: max_len must be > 0, H and B <= 65535");
     // q_prescaled: q already carries softmax_scale * log2(e) (esme_gemm_fusion_t.q_scale): every kernel then runs with c = 1, and
     // the 4-wave head-dim-64 kernel in its no-reference-maximum form
-    const bool f16 = opts && opts->f16;                         // fp16 operands: P must stay <= 1, i.e. the classic online softmax with exact maxima
-    if (f16) exact = true;
+    const bool f16 = opts && opts->f16;                         // fp16 operands: speculative / defer-max passes bounded to fp16's range (see the kernels)
     const bool qp = opts && opts->q_prescaled;
     ESME_CHECK_ARG(!(f16 && qp), "attn: fp16 operands do not combine with q_prescaled (no reference maximum: P would leave fp16's range)");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,

@@ -447,7 +447,8 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     with every row maximum exact (esme_hip_attn_varlen_fwd_exact; the high-precision mode).  `order` (seq_order(cu_lens)):
     dispatch the longest sequences' work first -- speed only, the result is the same bit for bit.  `q_prescaled`: q already
     carries softmax_scale * log2(e) (gemm_fused(..., q_scale=)); `softmax_scale` is ignored and the head-dim-64 kernel runs its
-    no-reference-maximum form.  float16 q, k, v (precision 'half'): float16 output, always the classic online softmax."""
+    no-reference-maximum form.  float16 q, k, v (precision 'half'): float16 output, P in fp16 (the speculative pass is bounded to fp16's
+    range and falls back to exact maxima per work item)."""
     f16 = q.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
     qp, ld = _rows2d(q, 'attn q', dt)
@@ -471,9 +472,10 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
         if q_prescaled:
             raise ValueError('attn: q_prescaled is not available for float16 operands (P must stay <= 1)')
         base = ao
-        ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0, 0.0, 0,
+        ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0,
+                      0.0 if exact else (base.defer_max_thr if base else 8.0), 0 if exact else (base.speculative if base else 1),
                       _dev(order, 'seq order', torch.int32) if order is not None else None, 0, 1)
-        exact = False                                   # (the options entry: f16 implies the exact softmax)
+        exact = False                                   # (everything fp16 goes through the options entry; `exact` rides in thr = 0, spec = 0)
     elif (order is not None or q_prescaled) and not exact:
         base = ao
         ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0,

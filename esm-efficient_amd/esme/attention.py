@@ -299,8 +299,8 @@ class FlashMultiheadAttention(nn.Module):
                        and d in (16, 32, 64) and E % 32 == 0)
         rot = (ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fusable else None
         qk_pass = (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128) and E <= 5120)
-        qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn)
         f16 = bool(ctx is not None and ctx.f16)
+        qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn and not f16)
         if f16 and (x_stats is None or resid32 is None or (self.rot_emb is not None and not (rot_fusable or qk_pass))):
             raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 stream, head dim 16 / 32 / 64 (fused rotary)")
         if x_stats is not None:

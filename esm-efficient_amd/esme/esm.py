@@ -179,7 +179,7 @@ class ESM2(nn.Module):
         cos = sin = None
         if rot is not None:
             cos, sin = rot.tables(int(max_len), device, {'exact': torch.float32, 'half': torch.float16}.get(self.precision, torch.bfloat16))
-        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision in ('high', 'half'),
+        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high',
                               f16=self.precision == 'half')
 
     def _unpad(self, x, tokens):

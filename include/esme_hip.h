@@ -175,8 +175,9 @@ typedef struct esme_attn_opts {
     int speculative;
     const int32_t* seq_order;
     int q_prescaled;
-    int f16;                     /* != 0: q, k, v and o are IEEE fp16 (precision 'half'); implies the classic online softmax with exact row
-                                  * maxima (P <= 1 fits fp16), does not combine with q_prescaled */
+    int f16;                     /* != 0: q, k, v and o are IEEE fp16 (precision 'half').  P is fp16 as well: the speculative pass keeps its first-tile
+                                  * reference maximum and redoes a work item with exact maxima when a P would leave fp16's range; does not
+                                  * combine with q_prescaled (no reference at all) */
 } esme_attn_opts_t;
 int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv,
                                   void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,

@@ -205,7 +205,7 @@ def test_exact_mode_full_depth():
 
 def test_half_mode_full_depth():
     """north_star "logits within 1e-3 rel-err of the reference forward" at ~1.1x the fast mode's time: `model.set_precision('half')` (fp32
-    residual stream, IEEE fp16 MFMA operands -- the bf16 checkpoint converts exactly --, exact online softmax, split-operand LM head, fp32
+    residual stream, IEEE fp16 MFMA operands -- the bf16 checkpoint converts exactly --, split-operand LM head, fp32
     logits) at the headline size -- ESM2-650M, 33 layers, 50 000 residues -- three whole sequences vs the fp32-math oracle.  The CPU
     emulation of "fp32 math, fp16 operands" says 4.7e-4 (tests/precision_floor.py --half); the bar is 1e-3."""
     model, w, H = load('esm2_650m')

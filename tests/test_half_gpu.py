@@ -117,8 +117,8 @@ def test_gemm_f16_layernorm_fold_and_rotary(d, tile):
 
 @pytest.mark.parametrize('d,H', [(16, 20), (32, 20), (64, 8), (128, 4)])
 def test_attention_f16(d, H):
-    """fp16 q, k, v, P and output; classic online softmax (P <= 1).  vs float64 on the same fp16 inputs: P's rounding (2^-11) averages
-    out over a row, the output rounding is 2^-11: rel-Frobenius <= 6e-4."""
+    """fp16 q, k, v, P and output; the default (speculative / defer-max, P bounded to fp16's range) and the exact-maxima form.  vs float64
+    on the same fp16 inputs: P's rounding (2^-11) averages out over a row, the output rounding is 2^-11: rel-Frobenius <= 6e-4."""
     lengths = [5, 64, 333, 1, 130, 700]
     T, E = sum(lengths), H * d
     g = torch.Generator().manual_seed(7 * d)
@@ -134,6 +134,8 @@ def test_attention_f16(d, H):
         ref[s0:s1] = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(d), dim=-1) @ v).transpose(0, 1).reshape(-1, E)
     assert bool(torch.isfinite(out).all())
     assert rel(out.cpu(), ref) <= 6e-4
+    ex = _hip.attn_varlen(xd[:, :E], xd[:, E:2 * E], xd[:, 2 * E:], cu.to(DEV), max(lengths), H, exact=True)
+    assert ex.dtype == H16 and rel(ex.cpu(), ref) <= 6e-4
     order = _hip.seq_order(cu.to(DEV))
     assert torch.equal(_hip.attn_varlen(xd[:, :E], xd[:, E:2 * E], xd[:, 2 * E:], cu.to(DEV), max(lengths), H, order=order), out)
     with pytest.raises(ValueError):
@@ -141,8 +143,9 @@ def test_attention_f16(d, H):
 
 
 def test_attention_f16_sharp_scores_stay_finite():
-    """Scores spread over +-60 (log2 units ~ +-87): the speculative kernels would produce P far beyond fp16's 65 504; this form subtracts
-    every row maximum, so P <= 1 and the result is finite and right."""
+    """Scores spread over +-60 (log2 units ~ +-87): against a first-tile reference maximum P would leave fp16's range (65 504); the
+    speculative pass notices (partial row sums >= 3e4), the work item is redone with exact maxima (P <= 1): finite and right.  Placed so
+    that the dominant keys sit in LATER key tiles than the first."""
     H, d, S = 4, 64, 300
     g = torch.Generator().manual_seed(5)
     q = h16(torch.randn(S, H * d, generator=g) * 4.0)
