@@ -41,11 +41,15 @@
 
 namespace esme {
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD = 0, bool LNF = false, bool STATS = false, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false, bool RP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+    // RP (precision 'half'): the residual stream is an fp16 PAIR [hi | lo] (x = hi + lo: 22 significant bits), read and written in whole
+    // 128-B lines through the wave slabs -- 8 B per element instead of the fp32 stream's 8 + 2 (x32 in and out, x16 out) in 64-B pieces;
+    // hi IS the next GEMM's MFMA operand.
+    static_assert(!RP || (F16 && EPI == ESME_EPI_RESIDUAL && !R32 && !PAIR && !LNF && ROTD == 0), "pair stream: fp16 residual epilogue");
     // F16 (precision 'half'): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (bias stays bf16, a checkpoint parameter); what
     // changes is the MFMA opcode, the table unpack and the output rounding -- the LDS image, the DMA path and the schedule do not.
-    static_assert(!F16 || (!PAIR && (EPI != ESME_EPI_RESIDUAL || R32)), "fp16 operands: plain / GELU / SwiGLU epilogues and the fp32-stream residual epilogue");
+    static_assert(!F16 || (!PAIR && (EPI != ESME_EPI_RESIDUAL || R32 || RP)), "fp16 operands: plain / GELU / SwiGLU epilogues and the fp32- / pair-stream residual epilogues");
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
     static_assert(!R32 || EPI == ESME_EPI_RESIDUAL, "the fp32 residual stream belongs to the residual epilogue");
     static_assert(!PAIR || (EPI != ESME_EPI_RESIDUAL && !LNF && !STATS && !PERSIST), "(hi, lo) pair output: plain / GELU / SwiGLU epilogues of the split-operand mode");
@@ -524,12 +528,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     constexpr int RPI = 64 / CH;                                       // rows per store instruction
     // PERSIST: the epilogue runs in two passes of WTM / 2 rows through slabs in the stage buffer that held the LAST K-tile
     // (64 KB in all), so that the other stage buffer can already receive the next tile's first K-tile.
-    constexpr int NPASS = (PERSIST || (R32 && BM == 256)) ? 2 : 1;      // (fp32 stream: a pass's quads live in registers -- 64 rows per pass)
+    constexpr int NPASS = RP ? (BM == 256 ? 4 : 1)                     // (pair stream: hi and lo slabs side by side -- 32 rows per pass in the 64 KB of one stage)
+                             : ((PERSIST || (R32 && BM == 256)) ? 2 : 1);    // (fp32 stream: a pass's quads live in registers -- 64 rows per pass)
     constexpr int RPP = WTM / NPASS;                                   // slab rows per pass
     constexpr int FMP = FM / NPASS;                                    // 16-row fragments per pass
     static_assert(!PERSIST || (FM % 2 == 0), "two-pass epilogue");
     const int lastbuf = (a.K / BK - 1 + par) & 1;
-    char* slab = smem + (PERSIST ? lastbuf * STAGE : 0) + wave * (RPP * ROWB);
+    char* slab = smem + (PERSIST ? lastbuf * STAGE : 0) + wave * (RPP * ROWB) * (RP ? 2 : 1);
     const int64_t em0 = m0;                                            // this tile's origin (PERSIST moves m0 / n0 on mid-epilogue)
     const int en0 = n0;
     const int n_out = (EPI == ESME_EPI_SWIGLU) ? (a.N >> 1) : a.N;
@@ -685,6 +690,87 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
         };
+        if constexpr (RP) {
+        char* slab_lo = slab + RPP * ROWB;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slabs
+#pragma unroll
+            for (int it = 0; it < RPP / 8; ++it) {
+                const int r = it * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (r & 7);
+                int64_t m = mw0 + pass * RPP + r;
+                m = m < a.M ? m : a.M - 1;
+                int n = nw0 + c * 8;
+                n = n < a.N - 8 ? n : a.N - 8;
+                ESME_LDS_CHECK(slab_lo + it * 1024, 1024, smem, 2 * STAGE);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.resid + m * a.ldr + n), (lptr_t)(slab + it * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.resid + m * a.ldr + a.pair_off + n), (lptr_t)(slab_lo + it * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int cl = i * 16 + 4 * lq;
+                const float bv[4] = {bf_lo(bq[i][0]), bf_hi(bq[i][0]), bf_lo(bq[i][1]), bf_hi(bq[i][1])};
+#pragma unroll
+                for (int jj = 0; jj < FMP; ++jj) {
+                    const int j = pass * FMP + jj;
+                    const int r = jj * 16 + l15;
+                    const u32x2 hq = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));
+                    const u32x2 lw = *reinterpret_cast<const u32x2*>(slab_lo + slab_off(r, cl));
+                    const float xs[4] = {lo16<true>(hq[0]) + lo16<true>(lw[0]), hi16<true>(hq[0]) + hi16<true>(lw[0]),
+                                         lo16<true>(hq[1]) + lo16<true>(lw[1]), hi16<true>(hq[1]) + hi16<true>(lw[1])};     // exact in fp32
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf(a.alpha, acc[i][j][e] + bv[e], xs[e]);
+                    const u32x2 ph = {pack_f16(o[0], o[1]), pack_f16(o[2], o[3])};
+                    const u32x2 pl = {pack_f16(o[0] - lo16<true>(ph[0]), o[1] - hi16<true>(ph[0])), pack_f16(o[2] - lo16<true>(ph[1]), o[3] - hi16<true>(ph[1]))};
+                    *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = ph;
+                    *reinterpret_cast<u32x2*>(slab_lo + slab_off(r, cl)) = pl;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (PERSIST) {                          // (after HALF the accumulators are dead: the registers the address set-up needs)
+                if (pass == NPASS / 2 - 1) {
+                    __syncthreads();
+                    pid += pid_step;
+                    have_next = pid < pid_end;
+                    if (have_next) {
+                        tile_coords(pid);
+                        set_sources();
+                        par = lastbuf ^ 1;
+                        stage(0, par);                        // (waited for by the next pass's vmcnt(0): the tile's last barrier needs none)
+                    }
+                }
+            }
+            const int rl = lane / CH, ch = lane % CH;
+            const int n = nw0 + ch * 8;
+            const bool col_ok = n < n_out;
+#pragma unroll
+            for (int it = 0; it < RPP / RPI; ++it) {
+                const int r = it * RPI + rl;
+                const int64_t m = mw0 + pass * RPP + r;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
+                const u32x4 vl = *reinterpret_cast<const u32x4*>(slab_lo + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
+                if (col_ok && m < a.M) {
+                    *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
+                    *reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n) = vl;
+                }
+                if constexpr (STATS) {                        // statistics of hi: what the next LayerNorm-folded GEMM multiplies
+                    float f[8];
+                    unpack8t<true>(v, f);
+                    float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                    float t2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) +
+                               ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
+                    t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);
+                    t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);
+                    t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);
+                    if (ch == 0) blkst[wn * BM + wm * WTM + pass * RPP + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
+                }
+            }
+        }
+        } else {
         load_x32(0);
         // PAIR (split-operand mode): every pass runs twice -- first the bf16 rounding hi of the fp32 results (the residuals o - hi
         // replace the accumulators), then lo = bf16(o - hi), stored pair_off columns further right in the same C row.
@@ -835,6 +921,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         if constexpr (PERSIST) { if (pass == 0) ESME_TRACE_SEAM(22, 1); else ESME_TRACE_SEAM(25, 1); }
         }   // half
         }   // pass
+        }   // !RP
         ESME_TRACE_MARK(6);
         if constexpr (STATS) {
             // the block's column waves combine as a tree ((w0 + w1) + (w2 + w3)): the canonical association the consumer
@@ -931,7 +1018,7 @@ static void set_raster(GemmArgs& a) {
     if (a.gn < 1) a.gn = 1;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false>
+template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false, bool RP = false>
 static int launch_one(GemmArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
     set_raster<BM, BN>(a);
@@ -942,11 +1029,11 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
         const bool want = a.opt_persist < 0 ? persist_default() != 0 : a.opt_persist != 0;
-        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16>(a, s);
+        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16, RP>(a, s);
 
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32, PAIR, F16>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, PERSIST, R32, PAIR, F16, RP>;
     if (smem >= 64 * 1024) {
         // the attribute is per (kernel, device): one bit per device ordinal, set once, safe from any host thread
         static std::atomic<unsigned long long> done{0ull};
@@ -967,7 +1054,7 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hipStream_t s) {
 #define ESME_L(E, R, L, S) launch_one<BM, BN, WM, WN, E, R, L, S>(a, s)
-    if (a.pair_off) {                               // split-operand mode: (hi, lo) pair output (checked by the caller: no LN fold, no residual)
+    if (a.pair_off && !a.f16) {                     // split-operand mode: (hi, lo) pair output (checked by the caller: no LN fold, no residual)
 #define ESME_LP(E, R) launch_one<BM, BN, WM, WN, E, R, false, false, false, false, true>(a, s)
         switch (epi) {
             case ESME_EPI_NONE:
@@ -997,7 +1084,11 @@ static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hip
                 }
             case ESME_EPI_GELU: return lnf ? ESME_LH(ESME_EPI_GELU, 0, true, false, false) : ESME_LH(ESME_EPI_GELU, 0, false, false, false);
             case ESME_EPI_SWIGLU: return lnf ? ESME_LH(ESME_EPI_SWIGLU, 0, true, false, false) : fail(ESME_ERR_UNSUPPORTED, "gemm: fp16 SwiGLU runs LayerNorm-folded only");
-            case ESME_EPI_RESIDUAL: return stats ? ESME_LH(ESME_EPI_RESIDUAL, 0, false, true, true) : ESME_LH(ESME_EPI_RESIDUAL, 0, false, false, true);
+            case ESME_EPI_RESIDUAL:
+                if (a.pair_off)                      // the stream as an fp16 pair (resid / C = hi, lo pair_off columns further)
+                    return stats ? launch_one<BM, BN, WM, WN, ESME_EPI_RESIDUAL, 0, false, true, false, false, false, true, true>(a, s)
+                                 : launch_one<BM, BN, WM, WN, ESME_EPI_RESIDUAL, 0, false, false, false, false, false, true, true>(a, s);
+                return stats ? ESME_LH(ESME_EPI_RESIDUAL, 0, false, true, true) : ESME_LH(ESME_EPI_RESIDUAL, 0, false, false, true);
             default: return fail(ESME_ERR_ARG, "gemm: unknown epilogue");
         }
 #undef ESME_LH
@@ -1099,7 +1190,13 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     int rotd = 0;
     bool lnf = false, stats = false;
     if (r32) { a.resid32 = fu->resid32; a.ld32 = fu->ld32; }
-    if (fu && (fu->w_k || fu->pair_off || fu->c32)) {               // split-operand ('exact') mode
+    if (fu && fu->f16 && fu->pair_off) {                             // precision 'half': the residual stream as an fp16 pair [hi | lo]
+        ESME_CHECK_ARG(epilogue == ESME_EPI_RESIDUAL && !r32 && !fu->w_k && !fu->c32 && !fu->ln_partial, "gemm: the fp16 pair stream belongs to the residual epilogue");
+        ESME_CHECK_ARG(fu->pair_off >= N && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + N && ldr >= fu->pair_off + N,
+                       "gemm: pair_off must be a multiple of 8 with N <= pair_off <= ldc - N, ldr - N");
+        if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: the pair stream needs 16-byte addressable rows and N % 8 == 0");
+        a.pair_off = fu->pair_off;
+    } else if (fu && (fu->w_k || fu->pair_off || fu->c32)) {        // split-operand ('exact') mode
         if (fu->w_k) {
             ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && K % fu->w_k == 0, "gemm: w_k (the K of W) must be a multiple of 64 that divides K");
             if (fu->w_k < K) a.kt_wrap = fu->w_k / BK;
@@ -1117,8 +1214,8 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
         }
     }
     if (fu && fu->f16) {                                             // precision 'half': fp16 A, W, tables, C
-        ESME_CHECK_ARG(!fu->w_k && !fu->pair_off && !fu->c32, "gemm: fp16 operands do not combine with the split-operand fields");
-        ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL || r32, "gemm: fp16 operands run the residual epilogue on the fp32 stream only");
+        ESME_CHECK_ARG(!fu->w_k && !fu->c32 && (!fu->pair_off || epilogue == ESME_EPI_RESIDUAL), "gemm: fp16 operands do not combine with the split-operand fields");
+        ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL || r32 || fu->pair_off, "gemm: fp16 operands run the residual epilogue on the fp32 stream or the fp16 pair stream");
         if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: fp16 operands need a 16-byte addressable C and N % 8 == 0");
         a.f16 = 1;
     }

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const void* __rest
             } else {
                 const u16* xr = reinterpret_cast<const u16*>(xv) + row * ldx;
                 float lo[8];
-                unpack8(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
-                unpack8(*reinterpret_cast<const u32x4*>(xr + in_off + e0), lo);
+                unpack8t<IN == 2>(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);          // (IN == 2: an fp16 pair, precision 'half')
+                unpack8t<IN == 2>(*reinterpret_cast<const u32x4*>(xr + in_off + e0), lo);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[c][j] += lo[j];
             }
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
 // bf16 embedding rows, e.g. after the learned-position sum; afterwards the residual GEMMs' epilogues keep both current).
 template <int NCH, bool F16>
 __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __restrict__ x32, int64_t ld32, u16* __restrict__ x16,
-                                                             int64_t ld16, f32x2* __restrict__ sums, int64_t T, int E) {
+                                                             int64_t ld16, int64_t lo_off, f32x2* __restrict__ sums, int64_t T, int E) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -453,6 +453,12 @@ __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __rest
             unpack8t<F16>(pk, r);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1 += r[j]; s2 = fmaf(r[j], r[j], s2); }
+            if (lo_off) {                                  // the stream as a pair: lo = round(x - hi), lo_off columns further in the same row
+                float l[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) l[j] = v[j] - r[j];
+                *reinterpret_cast<u32x4*>(yr + lo_off + e0) = pack8t<F16>(l);
+            }
         }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -767,17 +773,18 @@ extern "C" int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, in
     return check_launch("residual_f32");
 }
 
-extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int f16, float* sums, int64_t T, int E,
-                                       void* stream) {
+extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, float* sums,
+                                       int64_t T, int E, void* stream) {
     ESME_CHECK_ARG(T >= 0 && E > 0, "stream_operand: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(x32 && x16, "stream_operand: null pointer");
     ESME_CHECK_ARG(E % 8 == 0 && ld32 % 4 == 0 && ld16 % 8 == 0 && ld32 >= E && ld16 >= E, "stream_operand: E / row strides not multiples of 8");
+    ESME_CHECK_ARG(lo_off == 0 || (lo_off >= E && lo_off % 8 == 0 && ld16 >= lo_off + E), "stream_operand: lo_off must be a multiple of 8 with E <= lo_off <= ld16 - E");
     ESME_CHECK_ARG(aligned16(x32) && aligned16(x16) && (!sums || (reinterpret_cast<uintptr_t>(sums) & 7u) == 0), "stream_operand: misaligned");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, (f32x2*)sums, T, E); \
-                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, (f32x2*)sums, T, E); } while (0)
+#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, (f32x2*)sums, T, E); \
+                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, (f32x2*)sums, T, E); } while (0)
     if (E <= 512) ESME_SO(1);
     else if (E <= 1024) ESME_SO(2);
     else if (E <= 1536) ESME_SO(3);
@@ -820,7 +827,8 @@ extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair,
                    "layernorm_split: misaligned");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_LNS(N) do { if (in_pair) hipLaunchKernelGGL((layernorm_split_kernel<N, 1>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); \
+#define ESME_LNS(N) do { if (in_pair == 2) hipLaunchKernelGGL((layernorm_split_kernel<N, 2>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); \
+                         else if (in_pair) hipLaunchKernelGGL((layernorm_split_kernel<N, 1>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); \
                          else hipLaunchKernelGGL((layernorm_split_kernel<N, 0>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); } while (0)
     if (E <= 512) ESME_LNS(1);
     else if (E <= 1024) ESME_LNS(2);

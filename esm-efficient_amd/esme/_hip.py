@@ -82,7 +82,7 @@ SIGNATURES = {
                                                c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_qk_norm_rotary_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_void_p]),
     'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
@@ -510,18 +510,19 @@ def residual_f32_(x32: torch.Tensor, o: torch.Tensor, alpha: float, x16: torch.T
                'esme_hip_residual_f32')
 
 
-def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor]) -> None:
+def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor], pair: bool = False) -> None:
     """x16 <- round(x32) in x16's dtype (bfloat16, or float16 for precision 'half'); sums (1, T, 2) <- row {sum, sum sq} of the ROUNDED
-    values: the operand and the statistics the LayerNorm-folded GEMMs read at the start of a forward on an fp32 stream."""
+    values: the operand and the statistics the LayerNorm-folded GEMMs read at the start of a forward on an fp32 stream.  `pair`: x16 is
+    (T, 2E) = [hi | lo] with lo = round(x32 - hi): the stream itself as a 16-bit pair (gemm_fused(resid_pair=))."""
     if x16.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError('stream_operand: x16 must be bfloat16 or float16')
     xp, ld32 = _rows2d(x32, 'stream_operand x32', torch.float32)
     yp, ld16 = _rows2d(x16, 'stream_operand x16', x16.dtype)
     T, E = x32.shape
-    if x16.shape != (T, E):
+    if x16.shape != (T, 2 * E if pair else E):
         raise ValueError('stream_operand: shape mismatch')
     with _Traced('stream_operand', (T, E)):
-        _check(load().esme_hip_stream_operand(xp, ld32, yp, ld16, 1 if x16.dtype == torch.float16 else 0,
+        _check(load().esme_hip_stream_operand(xp, ld32, yp, ld16, E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
                                               _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
                'esme_hip_stream_operand')
 
@@ -545,9 +546,9 @@ def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     the lo half sits relative to the hi half when x / out are the hi views of a wider pair buffer (the q block of a (T, 6E)
     projection: in_off = out_off = 3E)."""
     T = x.shape[0]
-    pair_in = x.dtype == torch.bfloat16
+    pair_in = 1 if x.dtype == torch.bfloat16 else (2 if x.dtype == torch.float16 else 0)     # (float16: the pair stream of precision 'half')
     if pair_in:
-        xp, ldx = _rows2d(x, 'layernorm_split x')
+        xp, ldx = _rows2d(x, 'layernorm_split x', x.dtype)
         if in_off is None and x.shape[1] != 2 * dim:
             raise ValueError('layernorm_split: a pair input is (T, 2 * dim)')
     else:
@@ -561,7 +562,7 @@ def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     if out32 is not None:
         zp, ldz = _rows2d(out32, 'layernorm_split out32', torch.float32)
     with _Traced('layernorm_split', (T, dim)):
-        _check(load().esme_hip_layernorm_split(xp, ldx, 1 if pair_in else 0, dim if in_off is None else int(in_off),
+        _check(load().esme_hip_layernorm_split(xp, ldx, pair_in, dim if in_off is None else int(in_off),
                                                _dev(weight, 'layernorm weight', torch.bfloat16),
                                                _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
                                                yp, ldy, dim if out_off is None else int(out_off), zp, ldz, T, dim, float(eps), _stream()),
@@ -665,7 +666,8 @@ def stats_blocks(M: int, N: int) -> int:
 def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None,
-               q_scale: float = 0.0, split_a: bool = False, pair_out: bool = False, out32: Optional[torch.Tensor] = None) -> torch.Tensor:
+               q_scale: float = 0.0, split_a: bool = False, pair_out: bool = False, out32: Optional[torch.Tensor] = None,
+               resid_pair: Optional[torch.Tensor] = None) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
@@ -677,7 +679,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     `pair_out`: the result is written as a pair, out (M, 2 * n_out) = [hi | lo]; `out32` (M, N) fp32 receives the result instead
     of `out` (scalar store path: the vocab projection).
     float16 `a` and `w` (precision 'half'): fp16 operands, float16 output, float16 rotary tables; `bias` stays bfloat16; the residual
-    epilogue needs `resid32`."""
+    epilogue needs `resid32` or `resid_pair`: the stream as a float16 pair (M, 2N) = [hi | lo], updated in place (x + alpha * (a W^T + b)
+    formed in fp32, written back as a pair); returns its hi half, the next GEMM's operand (a view)."""
     f16 = a.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
     if f16 and (split_a or pair_out or out32 is not None):
@@ -690,6 +693,10 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     if w.shape[1] != (K // 2 if split_a else K):
         raise ValueError(f'gemm: K mismatch {a.shape} x {w.shape}')
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if resid_pair is not None:
+        if not f16 or epilogue != EPI_RESIDUAL or resid32 is not None or resid_pair.shape != (M, 2 * N) or resid_pair.dtype != torch.float16:
+            raise ValueError('gemm: resid_pair is the (M, 2N) float16 pair stream of the residual epilogue with float16 operands')
+        resid = out = resid_pair[:, :N]
     if out is None:
         out = torch.empty(M, 2 * n_out if pair_out else n_out, dtype=dt, device=a.device) if out32 is None else out32
     fu = GemmFusion()
@@ -701,6 +708,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         cp, ldc = _rows2d(out, 'gemm out', dt)
     if split_a:
         fu.w_k = K // 2
+    if resid_pair is not None:
+        fu.pair_off = N
     if pair_out:
         if out.shape[1] != 2 * n_out:
             raise ValueError('gemm: a pair output is (M, 2 * n_out)')
@@ -711,7 +720,7 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
             raise ValueError('gemm: resid32 must be an (M, N) float32 tensor with unit column stride (residual epilogue)')
         fu.resid32, fu.ld32 = _dev(resid32, 'gemm resid32', torch.float32), resid32.stride(0)
     elif epilogue == EPI_RESIDUAL:
-        rp, ldr = _rows2d(resid, 'gemm resid')
+        rp, ldr = _rows2d(resid, 'gemm resid', dt if resid_pair is not None else torch.bfloat16)
     tag = epilogue
     if ln is not None:
         part, dim, eps, c1, c2 = ln
@@ -733,6 +742,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     go = _TLS.gemm_opts
     if resid32 is not None:
         tag = 'residual_f32'
+    if resid_pair is not None:
+        tag = 'residual_pair'
     if split_a or pair_out or out32 is not None:
         tag = f'split:{tag}'
     if f16:

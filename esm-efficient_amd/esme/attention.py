@@ -48,7 +48,7 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs')
 
     def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False):
         self.pos, self.cos, self.sin = pos, cos, sin
@@ -56,6 +56,7 @@ class ForwardContext:
         self.fold = fold            # run the LN-folded fast path
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
         self.x32 = None             # high-precision mode: the fp32 residual stream (T, E_phys)
+        self.xs = None              # precision 'half': the residual stream as a float16 pair (T, 2 E_phys) = [hi | lo]; hi is the GEMMs' operand
         self.order = None           # dispatch order of the sequences for the attention launches (longest first; speed only)
         self.scratch = {}           # split-operand ('exact') mode: activation-pair buffers shared by all layers
         self.sums = None            # partial sums (nblk, T, 2) f32 describing the current residual stream
@@ -285,7 +286,7 @@ class FlashMultiheadAttention(nn.Module):
                                 softmax_scale=self.head_dim ** -0.5, exact=exact, order=order, q_prescaled=q_prescaled)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
-                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None):
+                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None, resid_pair=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
         resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid).
         `x_stats` ((nblk, T, 2) f32 partial row sums of x) selects the LN-folded projection;
@@ -301,7 +302,7 @@ class FlashMultiheadAttention(nn.Module):
         qk_pass = (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128) and E <= 5120)
         f16 = bool(ctx is not None and ctx.f16)
         qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn and not f16)
-        if f16 and (x_stats is None or resid32 is None or (self.rot_emb is not None and not (rot_fusable or qk_pass))):
+        if f16 and (x_stats is None or (resid32 is None and resid_pair is None) or (self.rot_emb is not None and not (rot_fusable or qk_pass))):
             raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 stream, head dim 16 / 32 / 64 (fused rotary)")
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True, f16)
@@ -328,8 +329,8 @@ class FlashMultiheadAttention(nn.Module):
         a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn),
                        order=ctx.order if ctx is not None else None, q_prescaled=qp)
         wo, bo = self._weights_out(f16)
-        if resid is not None or resid32 is not None:
-            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)
+        if resid is not None or resid32 is not None or resid_pair is not None:
+            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair)
         return _hip.gemm(a, wo, bo, out=out)
 
 
@@ -476,7 +477,7 @@ class FlashTransformerLayer(nn.Module):
             return self._down_pad
         return down.weight, down.bias
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None):
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         f16 = x.dtype == torch.float16                       # precision 'half': the operand type travels with the tensors
         if x_stats is not None:
@@ -486,7 +487,7 @@ class FlashTransformerLayer(nn.Module):
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
         wd, bd = self._weights_down(f16)
-        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32)
+        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair)
 
     def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext):
         """One layer with the residual stream in fp32 (`ctx.x32`, updated in place).  `x16` = bf16(stream) is the MFMA
@@ -499,9 +500,12 @@ class FlashTransformerLayer(nn.Module):
         if ctx.part_a is None:
             ctx.part_a = torch.empty(_hip.stats_blocks(T, E), T, 2, dtype=torch.float32, device=x16.device)
             ctx.part_b = torch.empty_like(ctx.part_a)
+        # precision 'half': the stream is the float16 pair ctx.xs = [hi | lo] and x16 is its hi half (a view): the residual epilogues
+        # read and write the pair in place -- no fp32 tensor, no separate operand copy
+        r32, rp = (None, ctx.xs) if ctx.f16 else (ctx.x32, None)
         self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
-                       resid32=ctx.x32)
-        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=ctx.x32)
+                       resid32=r32, resid_pair=rp)
+        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp)
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):

@@ -265,19 +265,23 @@ class ESM2(nn.Module):
             # and the LM head run in the split-operand form (fp32 representation / logits)
             assert not self.padded, "precision='half' needs a 64-aligned embedding width and a supported head dim"
             T = x.shape[0]
-            ctx.x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
-            x16 = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+            x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
+            # the stream as a float16 PAIR [hi | lo] (x = hi + lo: 22 significant bits): hi is the operand of the LayerNorm-folded GEMMs,
+            # the residual GEMMs read and write the pair in place (8 B per element in whole lines; an fp32 stream + operand copy is 10)
+            ctx.xs = torch.empty(T, 2 * E, dtype=torch.float16, device=x.device)
             ctx.sums = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
-            _hip.stream_operand(ctx.x32, x16, ctx.sums)
+            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True)
+            del x32
+            x16 = ctx.xs[:, :E]
             ctx.order = _hip.seq_order(cu_lens)
             for i, layer in enumerate(self.layers):
                 layer.forward_high_precision(x16, cu_lens, max_len, ctx)
                 if i in layers:
-                    taps.append(ctx.x32.clone())
+                    taps.append(ctx.xs[:, :E].float() + ctx.xs[:, E:].float())
             ln = self.emb_layer_norm_after
             pair = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=x.device)
             x = torch.empty(T, E, dtype=torch.float32, device=x.device)
-            _hip.layernorm_split(ctx.x32, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
+            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
             if want_pair:
                 x, taps = pair, []
         elif self.precision == 'high' and len(self.layers):

@@ -94,13 +94,14 @@ int esme_hip_layernorm(const void* x, int64_t ldx, const void* w, const void* b,
 int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, int64_t ldo, float alpha, int init,
                           void* x16, int64_t ld16, float* sums, int64_t T, int E, void* stream);
 
-/* The MFMA operand of an fp32 residual stream: x16 = round(x32) -- bf16, or IEEE fp16 when f16 != 0 (precision 'half') -- and, when
+/* The MFMA operand of an fp32 residual stream: x16 = round(x32) -- bf16, or IEEE fp16 when f16 != 0 (precision 'half') --, when lo_off
+ * != 0 also lo = round(x32 - x16) at column lo_off + e of the same row (the stream as a 16-bit PAIR, esme_gemm_fusion_t.pair_off), and, when
  * sums != NULL, per row {sum, sum of squares} of the ROUNDED values, float (1, T, 2) (pass as ln_partial, ln_nblk = 1).  Starts a
  * forward whose stream does not begin as bf16 embedding rows (esme_hip_residual_f32 init) or whose operand type is fp16; afterwards the
  * residual GEMMs (esme_gemm_fusion_t.resid32) keep x16 and the statistics current.  No counterpart in the reference (its stream is
  * the activation dtype throughout, esme/attention.py:253-255). */
-int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int f16, float* sums,
-                            int64_t T, int E, void* stream);
+int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
+                            float* sums, int64_t T, int E, void* stream);
 
 /* esme_hip_layernorm on an fp32 input (bf16 affine parameters and output): the final LayerNorm of the
  * high-precision mode (esme/esm.py:252). */
@@ -199,7 +200,7 @@ int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, 
  * LayerNorm, attention and softmax of that mode.  Measured: DESIGN.md section 4. */
 
 /* y = LayerNorm(x) (fp32 statistics and arithmetic) written as a (hi, lo) pair -- hi at y[t, e], lo at y[t, out_off + e] --
- * and, when y32 != NULL, also in fp32.  x: fp32 (T, E) with row stride ldx (in_pair = 0), or a pair (in_pair = 1: bf16, hi at
+ * and, when y32 != NULL, also in fp32.  x: fp32 (T, E) with row stride ldx (in_pair = 0), or a pair (in_pair = 1: bf16, in_pair = 2: IEEE fp16 (the pair stream of precision 'half'); hi at
  * x[t, e], lo at x[t, in_off + e], read as hi + lo).  Replaces nn.LayerNorm (esme/attention.py:75,222,230; esme/esm.py:252;
  * esme/head.py:22) of the fp32 forward. */
 int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b,
@@ -291,9 +292,14 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *  - f16 != 0 (precision 'half', model.set_precision('half')): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (`bias`
  *              stays bf16: a checkpoint parameter).  bf16 weights convert to fp16 exactly (|w| >= 2^-14; below that to 2^-24
  *              absolute), and an fp16 activation carries 11 significant bits instead of 8 at the same MFMA rate: with the fp32
- *              residual stream (resid32, mandatory for ESME_EPI_RESIDUAL here) the logits land at ~5e-4 of the reference's fp32
+ *              residual stream (resid32) or the stream as an fp16 PAIR the logits land at ~5e-4 of the reference's fp32
  *              forward in ONE pass over K.  Plain (+ LN-folded fused rotary), GELU, LN-folded SwiGLU and
- *              resid32 residual epilogues; 16-byte addressable C.  The caller guarantees |values| < 65 504 (fp16's range). */
+ *              residual epilogues; 16-byte addressable C.  The caller guarantees |values| < 65 504 (fp16's range).
+ *              ESME_EPI_RESIDUAL with f16 needs resid32 OR pair_off != 0: the residual stream is then the fp16 pair
+ *              x = hi + lo (22 significant bits), hi at resid[m, n], lo at resid[m, pair_off + n]; the epilogue forms
+ *              x + alpha * (acc + bias) in fp32 and writes it back as a pair to C[m, n] / C[m, pair_off + n] (C may be resid: in place);
+ *              hi is the next GEMM's fp16 operand (lda = the pair row stride), stats_out describes hi.  8 bytes per element in whole
+ *              128-byte lines instead of the fp32 stream's 10 in 64-byte pieces: the residual GEMMs' seam is where 'half' pays. */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
     int ln_nblk;

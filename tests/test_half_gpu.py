@@ -78,6 +78,34 @@ def test_gemm_f16_residual_on_the_fp32_stream(M, N, K, tile):
         _hip.gemm_fused(a.to(DEV), w.to(DEV), b.to(DEV), _hip.EPI_RESIDUAL, x16, 1.0)
 
 
+@pytest.mark.parametrize('M,N,K', [(513, 320, 1280), (4099, 1280, 5120), (30000, 640, 640), (70000, 1280, 1280)])
+@pytest.mark.parametrize('tile', [1, 2])
+def test_gemm_f16_residual_on_the_pair_stream(M, N, K, tile):
+    """The stream as a float16 pair [hi | lo] (x = hi + lo, 22 significant bits), updated in place: x + alpha * (a W^T + b) formed in
+    fp32 and written back as a pair (2^-23 relative), hi = the next operand, statistics of hi.  (70 000 x 1280: the persistent
+    256 x 256 workgroups, four 32-row passes per tile.)"""
+    g = torch.Generator().manual_seed(N + 1)
+    a = h16(torch.randn(M, K, generator=g))
+    w = h16(torch.randn(N, K, generator=g) * K ** -0.5)
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+    x32 = torch.randn(M, N, generator=g) * 3
+    xs = torch.empty(M, 2 * N, dtype=H16, device=DEV)
+    _hip.stream_operand(x32.to(DEV), xs, None, pair=True)
+    x_in = xs[:, :N].cpu().double() + xs[:, N:].cpu().double()
+    assert rel(x_in, x32) <= 2e-7                         # the pair holds an fp32 value to 2^-23
+    ref = x_in + 0.7 * (a.double() @ w.double().T + b.double())
+    with _hip.gemm_options(tile=tile):
+        stats = torch.empty(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=DEV)
+        hi = _hip.gemm_fused(a.to(DEV), w.to(DEV), b.to(DEV), _hip.EPI_RESIDUAL, None, 0.7, stats_out=stats, resid_pair=xs)
+    assert hi.data_ptr() == xs.data_ptr() and hi.shape == (M, N) and hi.dtype == H16
+    got = xs[:, :N].cpu().double() + xs[:, N:].cpu().double()
+    assert rel(got, ref) <= 5e-7, rel(got, ref)           # (fp32 accumulation of K <= 5 120 products + the 2^-23 of the pair)
+    assert rel(hi.cpu(), ref) <= 3e-4                     # hi alone is the fp16 rounding
+    st = stats.sum(dim=0).cpu().double()
+    r = hi.cpu().double()
+    assert torch.allclose(st[:, 0], r.sum(dim=1), atol=5e-3, rtol=1e-5) and torch.allclose(st[:, 1], (r * r).sum(dim=1), rtol=1e-5)
+
+
 @pytest.mark.parametrize('d', [16, 32, 64])
 @pytest.mark.parametrize('tile', [1, 2])
 def test_gemm_f16_layernorm_fold_and_rotary(d, tile):
