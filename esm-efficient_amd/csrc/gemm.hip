@@ -717,6 +717,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 for (int jj = 0; jj < FMP; ++jj) {
                     const int j = pass * FMP + jj;
                     const int r = jj * 16 + l15;
+                    ESME_LDS_CHECK(slab + slab_off(r, cl), 8, smem, 2 * STAGE); ESME_LDS_CHECK(slab_lo + slab_off(r, cl), 8, smem, 2 * STAGE);
                     const u32x2 hq = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));
                     const u32x2 lw = *reinterpret_cast<const u32x2*>(slab_lo + slab_off(r, cl));
                     const float xs[4] = {lo16<true>(hq[0]) + lo16<true>(lw[0]), hi16<true>(hq[0]) + hi16<true>(lw[0]),
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int r = it * RPI + rl;
                 const int64_t m = mw0 + pass * RPP + r;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
+                ESME_LDS_CHECK(slab_lo + r * ROWB + ((ch ^ (r & (CH - 1))) << 4), 16, smem, 2 * STAGE);
                 const u32x4 vl = *reinterpret_cast<const u32x4*>(slab_lo + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (col_ok && m < a.M) {
                     *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
