@@ -1041,8 +1041,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         }
         if constexpr (QP) {
             // no reference maximum: a row whose every score sits below ~-100 (log2 units) has lost its sum -- redo it exactly.
-            // (Per-lane partial sums: a lane whose half of the keys is entirely masked -- sequences of <= 8 residues -- also trips it.)
-            if (!exact && (__any(!(lrun[0] > 1e-30f)) || __any(!(lrun[1] > 1e-30f)))) ovf = 1;      // (idle waves carry lrun = 1)
+            // (The ROW's sum, i.e. both key halves: lane and lane ^ 32 combined -- a lane whose half of the keys is entirely masked, as in
+            // sequences of <= 8 residues, holds 0 by itself and used to send such sequences through the loop twice.)
+            if (!exact) {
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
+                    if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > 1e-30f))) ovf = 1;      // (idle waves carry lrun = 1)
+                }
+            }
         }
         if (exact || !__syncthreads_or(ovf)) break;
         exact = true;

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // PERSIST: the epilogue runs in two passes of WTM / 2 rows through slabs in the stage buffer that held the LAST K-tile
     // (64 KB in all), so that the other stage buffer can already receive the next tile's first K-tile.
     constexpr int NPASS = RP ? (BM == 256 ? 4 : 1)                     // (pair stream: hi and lo slabs side by side -- 32 rows per pass in the 64 KB of one stage)
-                             : ((PERSIST || (R32 && BM == 256)) ? 2 : 1);    // (fp32 stream: a pass's quads live in registers -- 64 rows per pass)
+                             : ((R32 && BM == 256) ? 4 : ((PERSIST || (PAIR && BM == 256)) ? 2 : 1));    // (fp32 stream: a pass's quads live in registers -- 64 rows per pass; pair output: two passes halve what the epilogue keeps live)
     constexpr int RPP = WTM / NPASS;                                   // slab rows per pass
     constexpr int FMP = FM / NPASS;                                    // 16-row fragments per pass
     static_assert(!PERSIST || (FM % 2 == 0), "two-pass epilogue");
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         // set-up below needs): every wave is past its last fragment / strip / table read after this barrier, so the free
         // stage buffer and the strips are refilled for the NEXT tile while this one's results are stored.
         if constexpr (PERSIST) {
-            if (pass == 0) {
+            if (pass == NPASS / 2 - 1) {              // (half of the accumulators are packed by now)
                 ESME_TRACE_SEAM(19, 1);
                 __syncthreads();
                 ESME_TRACE_SEAM(20, 1);
