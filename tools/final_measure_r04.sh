@@ -11,6 +11,11 @@ timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 python bench.py --gpus 1 --spawn --no-cpu-baseline > $O/bench_spawn.json 2>/dev/null
 timeout 900 python bench.py --batch proteome --no-cpu-baseline > $O/bench_proteome.json 2>/dev/null
 timeout 900 python bench.py --high-precision --no-cpu-baseline > $O/bench_high_precision.json 2>/dev/null
+timeout 900 python bench.py --precision half --no-cpu-baseline > $O/bench_half.json 2>/dev/null
+timeout 900 python bench.py --precision half --batch proteome --no-cpu-baseline > $O/bench_half_proteome.json 2>/dev/null
+timeout 900 python bench.py --precision half --model esmc_600m --tokens 32064 --seq-len 1002 --no-cpu-baseline > $O/bench_half_esmc600m.json 2>/dev/null
+timeout 900 python bench.py --precision half --model esm2_3b --tokens 50000 --no-cpu-baseline --steps 5 > $O/bench_half_3b.json 2>/dev/null
+timeout 900 python bench.py --precision half --model esm2_150m --tokens 8192 --seq-len 512 --no-cpu-baseline --steps 30 > $O/bench_half_150m.json 2>/dev/null
 timeout 900 python bench.py --precision exact > $O/bench_exact.json 2>/dev/null
 timeout 900 python bench.py --precision exact --model esmc_600m --tokens 32064 --seq-len 1002 --no-cpu-baseline > $O/bench_exact_esmc600m.json 2>/dev/null
 timeout 900 python bench.py --model esm2_3b --tokens 50000 --no-cpu-baseline --steps 5 > $O/bench_3b.json 2>/dev/null
@@ -37,6 +42,7 @@ for p in mfma_issue_probe dma_role_probe mfma_shape_probe; do [ -x tools/lab/bin
 ESME_GEMM_PERSIST=0 timeout 900 python bench.py --no-cpu-baseline > $O/bench_nopersist.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/prof -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /root/repo/$O/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/prof_half -- python /root/repo/bench.py --precision half --steps 3 --warmup 1 --no-cpu-baseline > /root/repo/$O/prof_half.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /root/repo/$O/pmc_fetch -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /root/repo/$O/pmc_write -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_write.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d /root/repo/$O/pmc_sq -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_sq.log 2>&1

@@ -20,13 +20,13 @@ def short(name):
     return name.replace('void esme::', '').replace('esme::', '').split('(')[0][:70]
 
 
-def kernel_stats():
-    f = sorted(glob.glob(os.path.join(O, 'prof', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
+def kernel_stats(sub='prof', out='r04_kernel_stats.md', flags=''):
+    f = sorted(glob.glob(os.path.join(O, sub, '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime, reverse=True)
     if not f:
         return                                   # (newest run first: gpurun_out/ accumulates the runs of a round)
     rows = list(csv.DictReader(open(f[0])))
     tot = sum(float(r['TotalDurationNs']) for r in rows)
-    lines = ['# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (round 4, headline workload)', '',
+    lines = [f'# rocprofv3 --kernel-trace --stats -- python bench.py{flags} --steps 3 --warmup 1 --no-cpu-baseline (round 4, headline workload)', '',
              f'source: `{os.path.relpath(f[0], ROOT)}`; durations in microseconds; 1 + 2 + 3 + instrumented 3 forwards = 9 forwards',
              '', '| kernel | calls | total us | avg us | % |', '|---|---:|---:|---:|---:|']
     for r in rows:
@@ -34,7 +34,7 @@ def kernel_stats():
         if pct < 0.02:
             continue
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e3:.0f} | {float(r['AverageNs']) / 1e3:.1f} | {pct:.2f} |")
-    open(os.path.join(P, 'r04_kernel_stats.md'), 'w').write('\n'.join(lines) + '\n')
+    open(os.path.join(P, out), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:16]))
 
 
@@ -62,6 +62,11 @@ def main():
         json.dump(b, open(os.path.join(P, 'r04_bench.json'), 'w'), indent=1)
         print('headline', b['value'], b['ms_per_step'], b['e2e'], b['roofline']['frac'], b.get('attention'))
     kernel_stats()
+    kernel_stats('prof_half', 'r04_kernel_stats_half.md', ' --precision half')
+    for src, dst in (('bench_half.json', 'r04_bench_half.json'), ('bench_exact.json', 'r04_bench_exact.json')):
+        d = load(src)
+        if d:
+            json.dump(d, open(os.path.join(P, dst), 'w'), indent=1)
     agg = pmc(['pmc_fetch', 'pmc_write'], 'r04_pmc_traffic.md', 'HBM / fabric traffic counters (FETCH_SIZE, WRITE_SIZE in KiB)')
     key = [k for k in agg if k.startswith('gemm_bf16_kernel<256, 256, 2, 4, 1, 0, true')]
     if key:
@@ -94,6 +99,11 @@ def main():
             ('same, self-launched through torch.distributed.run (--gpus 1 --spawn, RCCL world 1)', 'bench_spawn.json'),
             ('ESM2-650M, 50 000 residues, proteome-like lengths', 'bench_proteome.json'),
             ('ESM2-650M, 50 000 residues, high-precision mode (fp32 residual stream)', 'bench_high_precision.json'),
+            ("ESM2-650M, 50 000 residues, precision 'half' (fp16 MFMA operands, fp16-pair residual stream, fp32 logits: 5.3e-4 vs the fp32 forward)", 'bench_half.json'),
+            ("same, proteome-like lengths", 'bench_half_proteome.json'),
+            ("ESM2-3B, 50 000 residues, precision 'half'", 'bench_half_3b.json'),
+            ("ESMC-600M, 32 x 1 002 residues, precision 'half' (1.2e-3 vs the fp32 forward)", 'bench_half_esmc600m.json'),
+            ("ESM2-150M, 8 192 residues, precision 'half' (module-by-module launches)", 'bench_half_150m.json'),
             ("ESM2-650M, 50 000 residues, split-operand mode (precision 'exact': fp32 logits, 5.8e-6 vs the fp32 forward)", 'bench_exact.json'),
             ("ESMC-600M, 32 x 1 002 residues, split-operand mode", 'bench_exact_esmc600m.json'),
             ('ESM2-650M, 50 000 residues, 4-bit (esme-q4) layer weights', 'bench_650m_q4.json'),
