@@ -260,6 +260,21 @@ def test_half_mode_alone_vs_packed_2d_input_and_taps():
     assert torch.equal(model.set_precision('fast')(tokens.to(DEV), (cu.to(DEV), max(lengths))), fast0)
 
 
+def test_half_mode_graph_replay_equals_eager():
+    """model.graphed(...) in precision 'half': the hipGraph replay (fp16 weight copies, pair stream and fp32 logits captured once) returns
+    the eager result bit for bit, also after the mode is switched back and forth (the graph cache is dropped with the mode)."""
+    model = build('esm2', 3, 640, 20, seed=5).set_precision('half')
+    lengths = [100, 37, 260]
+    tokens, cu = syn.random_tokens(lengths, seed=2).to(DEV), syn.cu_lens_of(lengths).to(DEV)
+    eager = model(tokens, (cu, max(lengths)))
+    for _ in range(2):
+        g = model.graphed(tokens, (cu, max(lengths)), 'forward')
+        assert g.dtype == torch.float32 and torch.equal(g, eager)
+    fast = model.set_precision('fast').graphed(tokens, (cu, max(lengths)), 'forward')
+    assert fast.dtype == torch.bfloat16
+    assert torch.equal(model.set_precision('half').graphed(tokens, (cu, max(lengths)), 'forward'), eager)
+
+
 @pytest.mark.parametrize('kind', ['esm1b', 'esm1v'])
 def test_half_mode_esm1_vs_reference_fp32_golden(kind):
     import os, tempfile
