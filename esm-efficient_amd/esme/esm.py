@@ -261,27 +261,28 @@ class ESM2(nn.Module):
             if want_pair:
                 x, taps = pair, []
         elif self.precision == 'half':
-            # fp32 residual stream, fp16 MFMA operands: x16 = fp16(stream) is what the LayerNorm-folded GEMMs read; the final LayerNorm
-            # and the LM head run in the split-operand form (fp32 representation / logits)
-            assert not self.padded, "precision='half' needs a 64-aligned embedding width and a supported head dim"
-            T = x.shape[0]
+            # fp16 MFMA operands: x16 = fp16(stream) is what the LayerNorm-folded GEMMs read; the final LayerNorm and the LM head run in
+            # the split-operand form (fp32 representation / logits)
+            T, Ep = x.shape
             x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
             # the stream as a float16 PAIR [hi | lo] (x = hi + lo: 22 significant bits): hi is the operand of the LayerNorm-folded GEMMs,
-            # the residual GEMMs read and write the pair in place (8 B per element in whole lines; an fp32 stream + operand copy is 10)
-            ctx.xs = torch.empty(T, 2 * E, dtype=torch.float16, device=x.device)
+            # the residual GEMMs read and write the pair in place (8 B per element in whole lines; an fp32 stream + operand copy is 10).
+            # Padded layouts (ESM2-35M): everything at the physical width, pad columns zero as in the fast mode.
+            ctx.xs = torch.empty(T, 2 * Ep, dtype=torch.float16, device=x.device)
             ctx.sums = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
             _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True)
             del x32
-            x16 = ctx.xs[:, :E]
+            x16 = ctx.xs[:, :Ep]
             ctx.order = _hip.seq_order(cu_lens)
             for i, layer in enumerate(self.layers):
                 layer.forward_high_precision(x16, cu_lens, max_len, ctx)
                 if i in layers:
-                    taps.append(ctx.xs[:, :E].float() + ctx.xs[:, E:].float())
+                    taps.append(ctx.xs[:, :Ep].float() + ctx.xs[:, Ep:].float())
             ln = self.emb_layer_norm_after
-            pair = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=x.device)
-            x = torch.empty(T, E, dtype=torch.float32, device=x.device)
-            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
+            alloc = torch.zeros if self.padded else torch.empty
+            pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
+            x = alloc(T, Ep, dtype=torch.float32, device=x.device)
+            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x, in_off=Ep, out_off=Ep)
             if want_pair:
                 x, taps = pair, []
         elif self.precision == 'high' and len(self.layers):

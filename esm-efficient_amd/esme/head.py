@@ -34,15 +34,19 @@ class RobertaLMHead(nn.Module):
         return self._pad
 
     def forward_exact(self, pair):
-        """Split-operand ('exact') mode: `pair` (T, 2E) = [hi | lo] of the final-LayerNorm output -> fp32 logits (T, V)."""
-        if self.phys_dim != self.embed_dim:
-            raise NotImplementedError("precision='exact' needs a 64-aligned embedding width")
-        T, E = pair.shape[0], self.embed_dim
-        h = _hip.gemm_fused(pair, self.dense.weight, self.dense.bias, _hip.EPI_GELU, split_a=True, pair_out=True)
+        """Split-operand ('exact' / 'half') modes: `pair` (T, 2 E_phys) = [hi | lo] of the final-LayerNorm output -> fp32 logits (T, V)."""
+        T, E, Ep = pair.shape[0], self.embed_dim, self.phys_dim
+        if pair.shape[1] != 2 * Ep:
+            raise ValueError('forward_exact: the pair is (T, 2 * physical width) = [hi | lo]')
+        if Ep != E:                                    # padded layout (ESM2-35M): zero-padded weight copies, pad columns stay zero (gelu(0) = 0)
+            dw, db, fw = self._padded_weights()
+        else:
+            dw, db, fw = self.dense.weight, self.dense.bias, self.final.weight
+        h = _hip.gemm_fused(pair, dw, db, _hip.EPI_GELU, split_a=True, pair_out=True)
         ln = self.layer_norm
-        _hip.layernorm_split(h, ln.weight, ln.bias, ln.eps, E, out=h)
+        _hip.layernorm_split(h, ln.weight, ln.bias, ln.eps, E, out=h, in_off=Ep, out_off=Ep)
         y = torch.empty(T, self.final.out_features, dtype=torch.float32, device=pair.device)
-        _hip.gemm_fused(h, self.final.weight, self.final.bias, split_a=True, out32=y)
+        _hip.gemm_fused(h, fw, self.final.bias, split_a=True, out32=y)
         return y
 
     def forward(self, features):

@@ -289,11 +289,36 @@ def test_half_mode_esm1_vs_reference_fp32_golden(kind):
     assert e <= 1e-3
 
 
+def test_half_mode_padded_layout_esm2_35m_geometry():
+    """ESM2-35M's geometry (E = 480 -> a 512-wide stream, head dim 24 -> 32-wide heads): the pair stream, the fp16 weight copies and the
+    split-operand head all run at the physical width with zero pad columns; logical-width fp32 outputs, packed and 2-D input."""
+    model = build('esm2', 3, 480, 20, seed=4).set_precision('half')
+    w = syn.synthetic_state_dict('esm2', 3, 480, seed=4)
+    lengths = [40, 131, 7]
+    tokens, cu = syn.random_tokens(lengths, seed=3), syn.cu_lens_of(lengths)
+    out = model(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    ref = O.forward_logits(w, 20, tokens, cu, max(lengths), dtype=torch.float32)
+    e = rel_fro(out.cpu(), ref)
+    rep = model.forward_representation(tokens.to(DEV), (cu.to(DEV), max(lengths)), layers=[0])
+    ref_rep = O.forward_representation(w, 20, tokens, cu, max(lengths), torch.float32, layers=[0])
+    e_rep = rel_fro(rep.cpu(), ref_rep)
+    print(f'\n[half] ESM2-35M geometry (padded layout): logits {e:.2e}, representation + tap {e_rep:.2e} vs the fp32 oracle')
+    assert out.dtype == torch.float32 and out.shape == (sum(lengths), 33) and e <= 1e-3
+    assert rep.shape == (sum(lengths), 2 * 480) and rep.dtype == torch.float32 and e_rep <= 1e-3
+    cul = cu.tolist()
+    alone = model(tokens[cul[1]:cul[2]].to(DEV), (syn.cu_lens_of([131]).to(DEV), 131))
+    assert torch.equal(alone, out[cul[1]:cul[2]])
+
+
 def test_half_mode_rejects_what_it_does_not_cover():
-    """Padded layouts (ESM2-35M) and 4-bit weights have no fp16 form: a loud error, never a silent bf16 answer."""
-    m = build('esm2', 2, 480, 20, seed=0).set_precision('half')
+    """4-bit weights have no fp16 form: a loud error, never a silent bf16 answer."""
+    import os, tempfile
+    from esme import ESM
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), 'esm2_q', 2, 320, 20, seed=0)
+        m = ESM.from_pretrained(path, quantization='4bit', device=DEV).set_precision('half')
     tokens, cu = syn.random_tokens([40], seed=0), syn.cu_lens_of([40])
-    with pytest.raises((NotImplementedError, AssertionError)):
+    with pytest.raises(NotImplementedError):
         m(tokens.to(DEV), (cu.to(DEV), 40))
 
 
