@@ -105,10 +105,19 @@ def _version_key(*params):
     return tuple((p.data_ptr(), p._version) for p in params if p is not None)
 
 
+def _check_fp16_range(w16: torch.Tensor) -> None:
+    """precision 'half': a weight (or weight x LayerNorm gain) beyond fp16's 65 504 became inf in the conversion -- refuse the mode loudly
+    (one check per derived weight copy, at preparation time; precision 'exact' has no range limit)."""
+    if not bool(torch.isfinite(w16).all()):
+        raise OverflowError("precision='half': a weight leaves IEEE fp16's range (|w| >= 65 504); use precision 'exact' for this checkpoint")
+
+
 def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
                     beta: Optional[torch.Tensor], dtype=torch.bfloat16):
     """(W' = bf16(W*gamma), c1 = rowsum(W'), c2 = W beta + bias) for the LN-folded GEMM (`dtype` float16: precision 'half')."""
     wf = (w.float() * gamma.float().unsqueeze(0)).to(dtype).contiguous()
+    if dtype == torch.float16:
+        _check_fp16_range(wf)
     c1 = wf.float().sum(dim=1).contiguous()
     c2 = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
     if beta is not None:
@@ -246,6 +255,7 @@ class FlashMultiheadAttention(nn.Module):
             if key != self._out16_key:
                 with torch.no_grad():
                     self._out16 = w.data.to(torch.float16).contiguous()      # exact for |w| >= 2^-14 (bf16 has 8 significant bits)
+                    _check_fp16_range(self._out16)
                 self._out16_key = key
             return self._out16, b
         if self._q4_out is not None:
@@ -462,6 +472,7 @@ class FlashTransformerLayer(nn.Module):
             if key != self._down16_key:
                 with torch.no_grad():
                     self._down16 = w.data.to(torch.float16).contiguous()
+                    _check_fp16_range(self._down16)
                 self._down16_key = key
             return self._down16, b
         if self._q4_down is not None:

@@ -330,3 +330,65 @@ def test_half_mode_mask_margin_scores():
     half = predict_mask_margin(model.set_precision('half'), seq, batch_size=8)['score'].to_numpy()
     exact = predict_mask_margin(model.set_precision('exact'), seq, batch_size=8)['score'].to_numpy()
     assert abs(half - exact).max() <= 5e-3 and abs(half - exact).max() < abs(fast - exact).max()
+
+
+def test_f16_entry_points_reject_bad_arguments():
+    """The fp16 forms check their arguments on the host before launching: the bf16-stream residual epilogue, the split-operand fields,
+    q_prescaled attention, a pair offset that overlaps the hi block or leaves the row -- ESME_ERR_ARG / ESME_ERR_UNSUPPORTED with a message."""
+    import ctypes
+    lib = _hip.load()
+    s = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(32, 128, dtype=H16, device=DEV)
+    w = torch.zeros(64, 128, dtype=H16, device=DEV)
+    c = torch.zeros(32, 128, dtype=H16, device=DEV)
+    fu = _hip.GemmFusion()
+    fu.f16 = 1
+    # residual epilogue with fp16 operands and neither resid32 nor a pair stream
+    rc = lib.esme_hip_gemm_bf16_fused(a.data_ptr(), 128, w.data_ptr(), None, c.data_ptr(), 128, c.data_ptr(), 128, 32, 64, 128, _hip.EPI_RESIDUAL, 1.0, ctypes.byref(fu), s)
+    assert rc == -1 and b'fp16 operands' in lib.esme_hip_last_error()
+    # pair stream whose lo block would overlap the hi block (pair_off < N) / leave the row (ldc < pair_off + N)
+    for off, ld in ((32, 128), (64, 120)):
+        fu2 = _hip.GemmFusion()
+        fu2.f16, fu2.pair_off = 1, off
+        rc = lib.esme_hip_gemm_bf16_fused(a.data_ptr(), 128, w.data_ptr(), None, c.data_ptr(), ld, c.data_ptr(), ld, 32, 64, 128, _hip.EPI_RESIDUAL, 1.0, ctypes.byref(fu2), s)
+        assert rc == -1 and b'pair_off' in lib.esme_hip_last_error()
+    # fp16 operands + the split-operand K wrap
+    fu3 = _hip.GemmFusion()
+    fu3.f16, fu3.w_k = 1, 64
+    rc = lib.esme_hip_gemm_bf16_fused(a.data_ptr(), 128, w.data_ptr(), None, None, 0, c.data_ptr(), 128, 32, 64, 128, 0, 1.0, ctypes.byref(fu3), s)
+    assert rc == -1
+    # fp16 output rows that are not 16-byte addressable (N = 33: the vocab projection has no fp16 form)
+    w33 = torch.zeros(33, 128, dtype=H16, device=DEV)
+    rc = lib.esme_hip_gemm_bf16_fused(a.data_ptr(), 128, w33.data_ptr(), None, None, 0, c.data_ptr(), 128, 32, 33, 128, 0, 1.0, ctypes.byref(fu), s)
+    assert rc == -2
+    # attention: fp16 + q_prescaled
+    cu = torch.tensor([0, 32], dtype=torch.int32, device=DEV)
+    ao = _hip.AttnOpts(ctypes.sizeof(_hip.AttnOpts), 0, 0, 8.0, 1, None, 1, 1)
+    rc = lib.esme_hip_attn_varlen_fwd_opts(a.data_ptr(), a.data_ptr(), a.data_ptr(), 128, c.data_ptr(), 128, cu.data_ptr(), 1, 32, 2, 64, 32, 0.125, ctypes.byref(ao), s)
+    assert rc == -1 and b'q_prescaled' in lib.esme_hip_last_error()
+    # stream operand: a lo offset inside the hi block
+    x32 = torch.zeros(32, 64, dtype=torch.float32, device=DEV)
+    rc = lib.esme_hip_stream_operand(x32.data_ptr(), 64, c.data_ptr(), 128, 32, 1, None, 32, 64, s)
+    assert rc == -1 and b'lo_off' in lib.esme_hip_last_error()
+    # and the bf16 form of the pass (x16 = bf16(x32), statistics of the rounded values)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(40, 320, generator=g)
+    y = torch.empty(40, 320, dtype=torch.bfloat16, device=DEV)
+    sums = torch.empty(1, 40, 2, dtype=torch.float32, device=DEV)
+    _hip.stream_operand(x.to(DEV), y, sums)
+    r = x.to(torch.bfloat16)
+    assert torch.equal(y.cpu(), r)
+    assert torch.allclose(sums[0, :, 0].cpu(), r.float().sum(dim=1), atol=1e-3) and torch.allclose(sums[0, :, 1].cpu(), (r.float() ** 2).sum(dim=1), rtol=1e-5)
+
+
+def test_half_mode_refuses_weights_beyond_fp16_range():
+    """A weight x LayerNorm gain beyond 65 504 has no fp16 form: the mode says so when it prepares its weight copies."""
+    model = build('esm2', 2, 320, 20, seed=1)
+    with torch.no_grad():
+        model.layers[1].final[1].weight[3, 5] = 3.0e4
+        model.layers[1].final[0].weight[5] = 4.0            # W * gamma = 1.2e5
+    model.set_precision('half')
+    tokens, cu = syn.random_tokens([30], seed=0), syn.cu_lens_of([30])
+    with pytest.raises(OverflowError):
+        model(tokens.to(DEV), (cu.to(DEV), 30))
+    assert torch.isfinite(model.set_precision('fast')(tokens.to(DEV), (cu.to(DEV), 30)).float()).all()
