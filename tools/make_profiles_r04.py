@@ -17,7 +17,7 @@ def load(name):
 
 
 def short(name):
-    return name.replace('void esme::', '').replace('esme::', '').split('(')[0][:70]
+    return name.replace('void esme::', '').replace('esme::', '').split('(')[0][:120]
 
 
 def kernel_stats(sub='prof', out='r04_kernel_stats.md', flags=''):
