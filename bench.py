@@ -68,7 +68,7 @@ def parse():
                     help="model.set_precision(...): 'fast' = the headline mode (bf16 storage at the reference's rounding points); 'high' = fp32 "
                          "residual stream; 'half' = fp32 residual stream + IEEE fp16 MFMA operands, fp32 logits within ~5e-4 of the fp32 forward at "
                          "~1.1x the time (the line then says dtype f16); 'exact' = split (hi, lo) bf16 operand pairs, fp32 logits: the "
-                         "reference's fp32 forward to ~1e-5 at ~2.5x the time (DESIGN.md section 4).  Not the headline; the line says which mode ran.")
+                         "reference's fp32 forward to ~1e-5 at ~2.2x the time (DESIGN.md section 4).  Not the headline; the line says which mode ran.")
     ap.add_argument('--no-half', action='store_true',
                     help="skip the extra leg of the default single-GPU run that also times model.set_precision('half') on the same batch "
                          "(a few steps after the timed region; reported under 'precision_half', never in 'value')")

@@ -154,7 +154,7 @@ class ESM2(nn.Module):
 
     def set_precision(self, mode: str):
         """'fast' (default), 'high' (fp32 residual stream), 'half' (fp32 stream + fp16 MFMA operands: ~5e-4 of the fp32 forward, fp32
-        outputs, ~1.1x the time) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to ~1e-5, fp32 outputs, ~2.5x the
+        outputs, ~1.1x the time) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to ~1e-5, fp32 outputs, ~2.2x the
         time); DESIGN.md section 4 has what each achieves."""
         assert mode in ('fast', 'high', 'half', 'exact'), mode
         self.precision = mode
