@@ -42,11 +42,18 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         path = syn.write_checkpoint(os.path.join(td, f'm{rank}.safetensors'), 'esm2_shard', 3, 320, 20, seed=11)
         model = ESM.from_pretrained(path, device=str(dev))
-    with torch.no_grad():
-        full = shard.sharded_forward(lambda t, pa: model(t, pa), tokens, cu, dev)
-        single = model(tokens.to(dev), (cu.to(dev), max(lengths)))
-    torch.cuda.synchronize()
-    ok = bool(torch.equal(full, single))
+    ok = True
+    for mode in ('fast', 'half', 'exact'):              # bf16 logits, then the two fp32-logit modes through the same gather
+        model.set_precision(mode)
+        with torch.no_grad():
+            full = shard.sharded_forward(lambda t, pa: model(t, pa), tokens, cu, dev)
+            single = model(tokens.to(dev), (cu.to(dev), max(lengths)))
+            graphed = model.graphed(tokens.to(dev), (cu.to(dev), max(lengths)), 'forward')
+        torch.cuda.synchronize()
+        ok_mode = bool(torch.equal(full, single)) and full.dtype == single.dtype and bool(torch.equal(graphed, single))
+        ok = ok and ok_mode
+        if rank == 0:
+            print(f'world {world}, precision {mode}: sharded == single == hipGraph replay: {ok_mode}; logits {tuple(full.shape)} {full.dtype}')
     if rank == 0:
         print(f'world {world}: sharded == single: {ok}; logits {tuple(full.shape)}')
     dist.barrier()
