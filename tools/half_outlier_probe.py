@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""precision 'half' on a model with MASSIVE stream channels (what real checkpoints have and N(0, 0.02) synthetic weights do not): a few
+embedding columns, LayerNorm gains and FFN biases scaled up by 10-100x.  Prints rel-Frobenius of the logits vs the fp32 oracle for fast /
+half / exact, so the margin of the fp16 operand mode under outliers is a measured number."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'esm-efficient_amd')):
+    sys.path.insert(0, p)
+import torch
+from esme import synthetic as syn
+from oracle import esm_oracle as O          # (a measurement tool of the test infrastructure, like tests/precision_floor.py)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from test_model_gpu import build
+
+DEV = 'cuda:0'
+L, E, H = int(os.environ.get('L', 12)), int(os.environ.get('E', 640)), 20
+lengths = [150, 61, 300]
+tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+for scale in (1.0, 10.0, 50.0, 200.0):
+    w = syn.synthetic_state_dict('esm2', L, E, seed=2)
+    g = torch.Generator().manual_seed(0)
+    cols = torch.randperm(E, generator=g)[:4]
+    w['embed_tokens.weight'][:, cols] *= scale                       # massive stream channels from the start
+    for i in range(L):
+        w[f'layers.{i}.final.3.bias'][cols] *= scale                 # ... fed again by every FFN
+        w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= min(scale, 10.0)
+    model = build('esm2', L, E, H, seed=2)
+    model.load_state_dict({k: v.clone() for k, v in w.items()}, strict=False)
+    model.to(DEV)
+    ref = O.forward_logits(w, H, tokens, cu, max(lengths), torch.float32).float()
+    out = {}
+    for mode in ('fast', 'half', 'exact'):
+        out[mode] = rel(model.set_precision(mode)(tokens.to(DEV), (cu.to(DEV), max(lengths))).float().cpu(), ref)
+    x = O.forward_representation(w, H, tokens, cu, max(lengths), torch.float32)
+    print(f'outlier scale {scale:6.0f}: fast {out["fast"]:.2e}  half {out["half"]:.2e}  exact {out["exact"]:.2e}   (max |final-LN output| {float(x.abs().max()):.1f})', flush=True)
