@@ -104,3 +104,87 @@ def test_attention_long_sequences(lengths, H, d):
     ref = O.varlen_attention(q, k, v, cu).reshape(T, E)
     for a, b in zip(cu[:-1].tolist(), cu[1:].tolist()):          # per sequence: output magnitudes scale with 1/sqrt(S)
         check(got[a:b], ref[a:b], rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn {lengths} rows {a}:{b}')
+
+
+# ---- precision 'half' (fp16 operands): the same sweeps on the fp16 forms -----------------------------------------------------------------
+@pytest.mark.parametrize('seed', range(16))
+def test_fuzz_gemm_f16_pair_stream(seed):
+    """Residual epilogue on the fp16 pair stream at odd row counts / edge tiles in both tile configurations: the pair holds
+    x + alpha (a W^T + b) to ~2^-22, hi is its fp16 rounding, nothing outside the (M, N) blocks of hi and lo is written."""
+    from esme import _hip
+    rng = np.random.Generator(np.random.PCG64(5000 + seed))
+    M = int(rng.choice([1, 3, 17, 64, 129, 255, 256, 257, 511, 700, 1025, 2049]))
+    N = int(rng.choice([8, 24, 64, 72, 128, 136, 256, 264, 320, 512, 520]))
+    K = 64 * int(rng.integers(1, 9))
+    tile = int(rng.choice([1, 2]))
+    pad = int(rng.choice([0, 8, 64]))                         # extra columns between / after the two halves must stay untouched
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, K, generator=g).to(torch.float16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.float16)
+    b = (torch.randn(N, generator=g) * 0.3).to(torch.bfloat16) if rng.integers(0, 2) else None
+    x = torch.randn(M, N, generator=g) * 2
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    xs = torch.full((M, 2 * N + pad), 7.0, dtype=torch.float16)
+    xs[:, :N], xs[:, N:2 * N] = hi, lo
+    xs = xs.to(dev())
+    ref = hi.double() + lo.double() + 0.6 * (a.double() @ w.double().T + (b.double() if b is not None else 0.0))
+    with _hip.gemm_options(tile=tile):
+        if N % 64 == 0:
+            stats = torch.empty(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=dev())
+        else:
+            stats = None
+        out = _hip.gemm_fused(a.to(dev()), w.to(dev()), b.to(dev()) if b is not None else None, _hip.EPI_RESIDUAL, None, 0.6,
+                              stats_out=stats, resid_pair=xs[:, :2 * N])
+    got = xs[:, :N].cpu().double() + xs[:, N:2 * N].cpu().double()
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= 1e-6, f'pair stream M={M} N={N} K={K} tile={tile}: {err:.2e}'
+    assert torch.equal(out.cpu(), xs[:, :N].cpu()) and bool((xs[:, 2 * N:] == 7.0).all())
+    assert float((xs[:, :N].cpu().double() - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max()) + 1e-6
+    if stats is not None:
+        r = xs[:, :N].cpu().double()
+        st = stats.sum(dim=0).cpu().double()
+        assert torch.allclose(st[:, 0], r.sum(dim=1), atol=5e-3, rtol=1e-5) and torch.allclose(st[:, 1], (r * r).sum(dim=1), rtol=1e-5)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_fuzz_attention_f16(seed):
+    from esme import _hip
+    rng = np.random.Generator(np.random.PCG64(6000 + seed))
+    d = int(rng.choice([16, 32, 64, 128]))
+    H = int(rng.integers(1, 6))
+    nseq = int(rng.integers(1, 7))
+    lengths = [int(v) for v in rng.choice([1, 2, 8, 31, 32, 33, 63, 64, 65, 127, 129, 200, 257, 300, 513], size=nseq)]
+    T, E = sum(lengths), H * d
+    g = torch.Generator().manual_seed(seed)
+    qkv = (torch.randn(T, 3 * E, generator=g) * float(rng.choice([0.5, 1.0, 2.5]))).to(torch.float16)
+    cu = torch.tensor(np.r_[0, np.cumsum(lengths)], dtype=torch.int32)
+    x = qkv.to(dev())
+    got = _hip.attn_varlen(x[:, :E], x[:, E:2 * E], x[:, 2 * E:], cu.to(dev()), max(lengths), H)
+    q, k, v = (qkv[:, i * E:(i + 1) * E].double().view(T, H, d) for i in range(3))
+    ref = O.varlen_attention(q, k, v, cu).reshape(T, E)
+    err = float((got.cpu().double() - ref).norm() / ref.norm())
+    assert got.dtype == torch.float16 and bool(torch.isfinite(got).all()) and err <= 8e-4, f'attn f16 lengths={lengths} H={H} d={d}: {err:.2e}'
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_fuzz_half_mode_model(seed):
+    """Random small ESM-2 geometries and ragged batches (1-residue sequences included) in precision 'half': inside 1e-3 of the fp32 oracle,
+    and every sequence bit-identical alone and packed."""
+    from esme import synthetic as syn
+    from test_model_gpu import build
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    E, H = [(320, 20), (384, 6), (640, 20), (480, 20), (512, 8), (256, 16)][seed]
+    L = int(rng.integers(1, 4))
+    lengths = [int(v) for v in rng.choice([1, 2, 9, 33, 64, 100, 257, 300], size=int(rng.integers(1, 6)))]
+    model = build('esm2', L, E, H, seed=seed).set_precision('half')
+    w = syn.synthetic_state_dict('esm2', L, E, seed=seed)
+    tokens, cu = syn.random_tokens(lengths, seed=seed), syn.cu_lens_of(lengths)
+    out = model(tokens.to(dev()), (cu.to(dev()), max(lengths)))
+    ref = O.forward_logits(w, H, tokens, cu, max(lengths), dtype=torch.float32)
+    err = float((out.cpu().double() - ref.double()).norm() / ref.double().norm())
+    assert out.dtype == torch.float32 and err <= 1e-3, f'half E={E} H={H} L={L} lengths={lengths}: {err:.2e}'
+    cul = cu.tolist()
+    i = int(rng.integers(0, len(lengths)))
+    alone = model(tokens[cul[i]:cul[i + 1]].to(dev()), (syn.cu_lens_of([lengths[i]]).to(dev()), lengths[i]))
+    assert torch.equal(alone, out[cul[i]:cul[i + 1]])
