@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const u16* __restrict__ x
 // One lane per (row, tensor, head, 8-wide chunk of the first half of the head): it
 // rotates that chunk together with its partner chunk d/2 further on.  Tables are tiny
 // (max_len*d*2 B) and L2 resident; q and k rows are read and written once: 8*E B/row.
+template <bool F16>          // (true: q, k and the tables are IEEE fp16 -- precision 'half' at head dims the QKV epilogue does not rotate)
 __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* __restrict__ k, int64_t ld,
                                                      const u16* __restrict__ cosT, const u16* __restrict__ sinT,
                                                      const int32_t* __restrict__ pos, int64_t T, int H, int d,
@@ -363,18 +364,18 @@ __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* _
         p = p < max_len ? p : max_len - 1;
         u16* xp = base + t * ld + h * d + jc * 8;
         float lo[8], hi[8], c[8], s[8], olo[8], ohi[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xp), lo);
-        unpack8(*reinterpret_cast<const u32x4*>(xp + (d >> 1)), hi);
-        unpack8(*reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc * 8), c);
-        unpack8(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc * 8), s);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp), lo);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp + (d >> 1)), hi);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc * 8), c);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc * 8), s);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // one product rounded, one fused, spelled out: the same contraction in every kernel that rotates
             olo[j] = fmaf(lo[j], c[j], -__fmul_rn(hi[j], s[j]));
             ohi[j] = fmaf(hi[j], c[j], __fmul_rn(lo[j], s[j]));
         }
-        *reinterpret_cast<u32x4*>(xp) = pack8(olo);
-        *reinterpret_cast<u32x4*>(xp + (d >> 1)) = pack8(ohi);
+        *reinterpret_cast<u32x4*>(xp) = pack8t<F16>(olo);
+        *reinterpret_cast<u32x4*>(xp + (d >> 1)) = pack8t<F16>(ohi);
     }
 }
 
@@ -881,8 +882,8 @@ extern "C" int esme_hip_row_sums(const void* x, int64_t ldx, int64_t T, int E, f
     return check_launch("row_sums");
 }
 
-extern "C" int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,
-                                      const int32_t* pos, int64_t T, int H, int d, int max_len, void* stream) {
+static int rotary_impl(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,
+                       const int32_t* pos, int64_t T, int H, int d, int max_len, bool f16, void* stream) {
     ESME_CHECK_ARG(T >= 0 && H > 0 && d > 0 && max_len > 0, "rotary: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && cosT && sinT && pos, "rotary: null pointer");
@@ -890,9 +891,21 @@ extern "C" int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* 
     ESME_CHECK_ARG(ld % 8 == 0 && ld >= (int64_t)H * d, "rotary: bad row stride");
     ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(cosT) && aligned16(sinT), "rotary: misaligned");
     const int64_t items = T * 2 * H * (d / 16);
-    hipLaunchKernelGGL(rotary_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)q,
-                       (u16*)k, ld, (const u16*)cosT, (const u16*)sinT, pos, T, H, d, max_len);
+    if (f16) hipLaunchKernelGGL(rotary_kernel<true>, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)q,
+                                (u16*)k, ld, (const u16*)cosT, (const u16*)sinT, pos, T, H, d, max_len);
+    else hipLaunchKernelGGL(rotary_kernel<false>, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)q,
+                            (u16*)k, ld, (const u16*)cosT, (const u16*)sinT, pos, T, H, d, max_len);
     return check_launch("rotary");
+}
+
+extern "C" int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,
+                                      const int32_t* pos, int64_t T, int H, int d, int max_len, void* stream) {
+    return rotary_impl(q, k, ld, cosT, sinT, pos, T, H, d, max_len, false, stream);
+}
+
+extern "C" int esme_hip_rotary_varlen_f16(void* q, void* k, int64_t ld, const void* cosT, const void* sinT,
+                                          const int32_t* pos, int64_t T, int H, int d, int max_len, void* stream) {
+    return rotary_impl(q, k, ld, cosT, sinT, pos, T, H, d, max_len, true, stream);
 }
 
 extern "C" int esme_hip_softmax_rows(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t T, int V,

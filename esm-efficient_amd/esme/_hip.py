@@ -70,6 +70,8 @@ SIGNATURES = {
                                    c_float, c_void_p]),
     'esme_hip_rotary_varlen': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                        c_int, c_int, c_void_p]),
+    'esme_hip_rotary_varlen_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                           c_int, c_int, c_void_p]),
     'esme_hip_qk_norm_rotary': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                         c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_qk_norm_rotary_scaled': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
@@ -396,16 +398,17 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
 
 def rotary_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor,
             heads: int) -> None:
-    """In-place rotary on q and k, each a (T, H*d) view (same row stride) of bf16."""
-    qp, ld = _rows2d(q, 'rotary q')
-    kp, ldk = _rows2d(k, 'rotary k')
+    """In-place rotary on q and k, each a (T, H*d) view (same row stride) of bf16 (or float16 with float16 tables: precision 'half')."""
+    dt = torch.float16 if q.dtype == torch.float16 else torch.bfloat16
+    qp, ld = _rows2d(q, 'rotary q', dt)
+    kp, ldk = _rows2d(k, 'rotary k', dt)
     if ld != ldk:
         raise ValueError('rotary: q and k must share a row stride')
     T, E = q.shape
     d = E // heads
+    fn = load().esme_hip_rotary_varlen_f16 if dt == torch.float16 else load().esme_hip_rotary_varlen
     with _Traced('rotary', (T, E)):
-        _check(load().esme_hip_rotary_varlen(qp, kp, ld, _dev(cos, 'cos', torch.bfloat16), _dev(sin, 'sin', torch.bfloat16),
-                                             _dev(pos, 'pos', torch.int32), T, heads, d, cos.shape[0], _stream()),
+        _check(fn(qp, kp, ld, _dev(cos, 'cos', dt), _dev(sin, 'sin', dt), _dev(pos, 'pos', torch.int32), T, heads, d, cos.shape[0], _stream()),
                'esme_hip_rotary_varlen')
 
 

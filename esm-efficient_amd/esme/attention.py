@@ -312,8 +312,8 @@ class FlashMultiheadAttention(nn.Module):
         qk_pass = (self.pre_layernorm and self.rot_emb is not None and ctx is not None and d in (16, 32, 64, 128) and E <= 5120)
         f16 = bool(ctx is not None and ctx.f16)
         qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn and not f16)
-        if f16 and (x_stats is None or (resid32 is None and resid_pair is None) or (self.rot_emb is not None and not (rot_fusable or qk_pass))):
-            raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 stream, head dim 16 / 32 / 64 (fused rotary)")
+        if f16 and (x_stats is None or (resid32 is None and resid_pair is None) or (self.pre_layernorm and not qk_pass)):
+            raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 / pair stream (ESM-C: with the fused q/k pass)")
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True, f16)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,

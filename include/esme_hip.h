@@ -116,6 +116,10 @@ int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const voi
 int esme_hip_rotary_varlen(void* q, void* k, int64_t ld, const void* cos, const void* sin,
                            const int32_t* pos, int64_t T, int H, int d, int max_len,
                            void* stream);
+/* The same on IEEE fp16 q, k and fp16 tables (precision 'half' at head dims the QKV epilogue does not rotate, e.g. 128). */
+int esme_hip_rotary_varlen_f16(void* q, void* k, int64_t ld, const void* cos, const void* sin,
+                           const int32_t* pos, int64_t T, int H, int d, int max_len,
+                           void* stream);
 
 /* ESM-C's q/k normalisation + rotary in one in-place pass: for x in {q, k} (each (T, H*d) with
  * row stride ld):  x <- rotary(bf16(LayerNorm_{H*d}(x) * w + b)), b may be NULL.  Bit-identical

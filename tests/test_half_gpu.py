@@ -392,3 +392,18 @@ def test_half_mode_refuses_weights_beyond_fp16_range():
     with pytest.raises(OverflowError):
         model(tokens.to(DEV), (cu.to(DEV), 30))
     assert torch.isfinite(model.set_precision('fast')(tokens.to(DEV), (cu.to(DEV), 30)).float()).all()
+
+
+def test_half_mode_head_dim_128():
+    """Head dim 128 (ESM2-15B's): the QKV epilogue does not rotate there, so q and k go through the stand-alone rotary kernel in its fp16
+    form (fp16 tables) and the first-generation attention kernel on fp16 operands."""
+    model = build('esm2', 2, 256, 2, seed=6).set_precision('half')
+    w = syn.synthetic_state_dict('esm2', 2, 256, seed=6)
+    lengths = [70, 9, 200]
+    tokens, cu = syn.random_tokens(lengths, seed=4), syn.cu_lens_of(lengths)
+    out = model(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    ref = O.forward_logits(w, 2, tokens, cu, max(lengths), dtype=torch.float32)
+    e = rel_fro(out.cpu(), ref)
+    fast = rel_fro(model.set_precision('fast')(tokens.to(DEV), (cu.to(DEV), max(lengths))).float().cpu(), ref)
+    print(f'\n[half] head dim 128: logits {e:.2e} vs the fp32 oracle (fast {fast:.2e})')
+    assert out.dtype == torch.float32 and e <= 1e-3 and e < 0.25 * fast
