@@ -221,6 +221,7 @@ def test_half_mode_full_depth():
     out = model(tokens.to(DEV), (cu.to(DEV), max_len))
     assert out.dtype == torch.float32 and out.shape == (50000, model.vocab_size) and torch.isfinite(out).all()
     half = rows(out)
+    assert torch.equal(model(tokens.to(DEV), (cu.to(DEV), max_len)), out), 'half mode: two forwards of the same batch differ'
     alone = model(sub_t.to(DEV), (sub_cu.to(DEV), 500))
     assert torch.equal(alone.cpu(), half), 'half mode: packed rows differ from the sequences run alone'
     lp = model.predict_log_prob(sub_t.to(DEV), (sub_cu.to(DEV), 500))
