@@ -240,6 +240,9 @@ def test_half_mode_alone_vs_packed_2d_input_and_taps():
     assert out.dtype == torch.float32 and rel_fro(out.cpu(), ref) <= 1e-3
     lp = model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), max(lengths)))
     assert lp.dtype == torch.float32 and rel_fro(lp.cpu(), torch.log_softmax(ref, dim=-1)) <= 1e-3
+    pr = model.predict_prob(tokens.to(DEV), pad_args=(cu.to(DEV), max(lengths)))
+    assert pr.dtype == torch.float32 and torch.allclose(pr.sum(dim=-1).cpu(), torch.ones(sum(lengths)), atol=1e-5)
+    assert rel_fro(pr.cpu(), torch.softmax(ref, dim=-1)) <= 1e-3
     cul = cu.tolist()
     for i, n in enumerate(lengths):                                   # a sequence's logits do not depend on what it is packed with
         alone = model(tokens[cul[i]:cul[i + 1]].to(DEV), (syn.cu_lens_of([n]).to(DEV), n))
@@ -253,8 +256,11 @@ def test_half_mode_alone_vs_packed_2d_input_and_taps():
     assert out2.shape == (len(lengths), S, model.vocab_size) and out2.dtype == torch.float32
     for i, n in enumerate(lengths):
         assert torch.equal(out2[i, :n], out[cul[i]:cul[i + 1]])
+    rep2 = model.forward_representation(t2.to(DEV))
+    assert rep2.shape == (len(lengths), S, 320) and rep2.dtype == torch.float32
     taps = model.forward_representation(tokens.to(DEV), (cu.to(DEV), max(lengths)), layers=[1, 3])
     assert taps.shape == (sum(lengths), 3 * 320) and taps.dtype == torch.float32
+    assert torch.equal(rep2[1, :lengths[1]], taps[cul[1]:cul[2], :320])
     # switching back restores the bf16 fast path bit for bit (the fp16 weight copies are separate caches)
     fast0 = build('esm2', 4, 320, 20, seed=3)(tokens.to(DEV), (cu.to(DEV), max(lengths)))
     assert torch.equal(model.set_precision('fast')(tokens.to(DEV), (cu.to(DEV), max(lengths))), fast0)
