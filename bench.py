@@ -337,7 +337,8 @@ def main():
                    'residues_per_gpu': T, 'sequences_per_gpu': len(lengths), 'max_len': max_len,
                    'parallelism': f'dp{world} (protein-sharded, logits all-gather over RCCL)' if world > 1 else 'single GPU',
                    'launch': 'hipGraph replay' if use_graph else
-                             ('eager (one C call for the layer stack: esme_hip_forward)' if (model.c_forward and model._c_forward_ok())
+                             ('eager (one C call for the layer stack: esme_hip_forward' + ('_half)' if args.precision == 'half' else ')')
+                              if (model.c_forward and args.precision in ('fast', 'half') and model._c_forward_ok(args.precision))
                               else 'eager (one ctypes launch per kernel)'),
                    'launcher': 'torch.distributed.run (self-launched)' if os.environ.get('ESME_BENCH_SPAWNED') else
                                ('torch.distributed.run' if launched else 'plain python'),

@@ -118,3 +118,101 @@ extern "C" int esme_hip_forward(const esme_model_desc_t* m, void* x, int64_t ldx
 #undef ESME_TRY
     return ESME_OK;
 }
+
+// ---- precision 'half' (DESIGN.md section 4): the same layer stack on IEEE fp16 operands with the residual stream as an fp16 pair.
+// The descriptor's layer weights are then the fp16 copies (W' = fp16(W diag(gamma)) with ITS row sums c1; out / down weights converted
+// exactly from bf16), cos / sin are fp16 tables.  x32 is the fp32 stream at the start (embedding rows; ESM-1b / 1v: token + position sums);
+// the result is the final LayerNorm in the split-operand form: `pair` (T, 2 * phys_dim) bf16 = [hi | lo] (the LM head's operand,
+// esme/head.py forward_exact) and, when rep32 != NULL, its fp32 value (T, phys_dim).  Same launches as the module-by-module path
+// (esme/attention.py forward_high_precision with ctx.f16): bit-identical.
+namespace {
+
+struct WsHalf { char* xs; char* qkv; char* attn; char* mid; float* sums; float* part_a; float* part_b; int32_t* order; };
+
+int64_t carve_half(const esme_model_desc_t* m, int64_t T, WsHalf* w, char* base) {
+    const int64_t Ea = (int64_t)m->heads * m->head_pad, Ep = m->phys_dim;
+    const int64_t nblk = esme_hip_gemm_stats_blocks(T, (int)Ep);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off += align256(bytes); return base ? base + o : (char*)nullptr; };
+    char* xs = take(T * 2 * Ep * 2);
+    char* qkv = take(T * 3 * Ea * 2);
+    char* attn = take(T * Ea * 2);
+    char* mid = take(T * (int64_t)m->ffn_dim * 2);
+    char* sums = take(T * 2 * 4);
+    char* pa = take(nblk * T * 2 * 4);
+    char* pb = take(nblk * T * 2 * 4);
+    char* ord = take(1024 * 4);
+    if (w) *w = WsHalf{xs, qkv, attn, mid, (float*)sums, (float*)pa, (float*)pb, (int32_t*)ord};
+    return off;
+}
+
+}  // namespace
+
+extern "C" int64_t esme_hip_forward_half_workspace_bytes(const esme_model_desc_t* m, int64_t T) {
+    if (!m || T < 0) return -1;
+    return carve_half(m, T, nullptr, nullptr);
+}
+
+extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x32, int64_t ld32, const int32_t* cu_lens, int B, int64_t T,
+                                     int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes, void* pair, int64_t ld_pair,
+                                     float* rep32, int64_t ld_rep, void* stream) {
+    ESME_CHECK_ARG(m && m->struct_bytes == (int)sizeof(esme_model_desc_t), "forward_half: descriptor missing or of another ABI");
+    ESME_CHECK_ARG(T >= 0 && B >= 0 && max_len >= 0, "forward_half: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x32 && cu_lens && workspace && pair && m->layers && m->n_layers > 0, "forward_half: null pointer");
+    ESME_CHECK_ARG(m->phys_dim % 64 == 0 && m->embed_dim > 0 && m->embed_dim <= m->phys_dim && ld32 >= m->phys_dim && ld_pair >= 2 * (int64_t)m->phys_dim,
+                   "forward_half: the physical width must be a multiple of 64, ld_pair >= 2 * phys_dim");
+    ESME_CHECK_ARG(ws_bytes >= carve_half(m, T, nullptr, nullptr) && aligned16(workspace), "forward_half: workspace too small or misaligned");
+    ESME_CHECK_ARG(!m->rotary || (m->cos && m->sin && pos), "forward_half: rotary models need cos, sin and pos");
+    WsHalf w;
+    carve_half(m, T, &w, (char*)workspace);
+    const int Ep = m->phys_dim, E = m->embed_dim, H = m->heads, dp = m->head_pad;
+    const int64_t Ea = (int64_t)H * dp;
+    const int nblk = esme_hip_gemm_stats_blocks(T, Ep);
+    const bool rot_fused = m->rotary && !m->qk_norm && (dp == 16 || dp == 32 || dp == 64) && Ea % 32 == 0;
+    int rc;
+#define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
+    esme_attn_opts_t aopts{(int)sizeof(esme_attn_opts_t), 0, 0, 8.0f, 1, nullptr, 0, 1};
+    if (B > 1 && B <= 1024) {
+        ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));
+        aopts.seq_order = w.order;
+    }
+    // the stream as an fp16 pair [hi | lo] + the statistics of hi
+    ESME_TRY(esme_hip_stream_operand(x32, ld32, w.xs, 2 * (int64_t)Ep, Ep, 1, w.sums, T, Ep, stream));
+    const float* stats = w.sums;
+    int stats_nblk = 1;
+    for (int i = 0; i < m->n_layers; ++i) {
+        const esme_layer_weights_t& L = m->layers[i];
+        esme_gemm_fusion_t fu{};
+        fu.f16 = 1;
+        fu.ln_partial = stats; fu.ln_nblk = stats_nblk; fu.ln_dim = E; fu.ln_eps = m->ln_eps; fu.ln_c1 = L.qkv_c1; fu.ln_c2 = L.qkv_c2;
+        if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, 2 * (int64_t)Ep, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Ep, ESME_EPI_NONE, 1.0f, &fu, stream));
+        char* q = w.qkv; char* k = w.qkv + Ea * 2; char* v = w.qkv + 2 * Ea * 2;
+        if (m->qk_norm) {
+            ESME_TRY(esme_hip_qk_norm_rotary_f16(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+        } else if (m->rotary && !rot_fused) {
+            ESME_TRY(esme_hip_rotary_varlen_f16(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+        }
+        ESME_TRY(esme_hip_attn_varlen_fwd_opts(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, &aopts, stream));
+        esme_gemm_fusion_t fo{};
+        fo.f16 = 1; fo.pair_off = Ep; fo.stats_out = w.part_b;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, 2 * (int64_t)Ep, w.xs, 2 * (int64_t)Ep, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
+        esme_gemm_fusion_t fup{};
+        fup.f16 = 1;
+        fup.ln_partial = w.part_b; fup.ln_nblk = nblk; fup.ln_dim = E; fup.ln_eps = m->ln_eps; fup.ln_c1 = L.up_c1; fup.ln_c2 = L.up_c2;
+        const int up_rows = m->swiglu ? 2 * m->ffn_dim : m->ffn_dim;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, 2 * (int64_t)Ep, L.up_w, nullptr, nullptr, 0, w.mid, m->ffn_dim, T, up_rows, Ep,
+                                          m->swiglu ? ESME_EPI_SWIGLU : ESME_EPI_GELU, 1.0f, &fup, stream));
+        esme_gemm_fusion_t fd{};
+        fd.f16 = 1; fd.pair_off = Ep; fd.stats_out = w.part_a;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, w.xs, 2 * (int64_t)Ep, w.xs, 2 * (int64_t)Ep, T, Ep, m->ffn_dim,
+                                          ESME_EPI_RESIDUAL, m->alpha, &fd, stream));
+        stats = w.part_a; stats_nblk = nblk;
+    }
+    // final LayerNorm over the logical width, from the fp16 pair, written as the bf16 pair the split-operand LM head reads (+ fp32)
+    ESME_TRY(esme_hip_layernorm_split(w.xs, 2 * (int64_t)Ep, 2, Ep, m->final_ln_w, m->final_ln_b, pair, ld_pair, Ep, rep32, ld_rep, T, E, m->ln_eps, stream));
+#undef ESME_TRY
+    return ESME_OK;
+}
+

@@ -109,6 +109,9 @@ SIGNATURES = {
     'esme_hip_forward_workspace_bytes': (c_int64, [POINTER(ModelDesc), c_int64]),
     'esme_hip_forward': (c_int, [POINTER(ModelDesc), c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p,
                                  c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    'esme_hip_forward_half_workspace_bytes': (c_int64, [POINTER(ModelDesc), c_int64]),
+    'esme_hip_forward_half': (c_int, [POINTER(ModelDesc), c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                      c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     'esme_hip_row_sums': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     'esme_hip_softmax_rows': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'esme_hip_gather_rows': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

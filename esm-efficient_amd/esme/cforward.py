@@ -34,7 +34,8 @@ _VERSION = operator.attrgetter('_version')
 class ModelDescriptor:
     """esme_model_desc_t of one model instance + the tensors it points to."""
 
-    def __init__(self, model):
+    def __init__(self, model, f16: bool = False):
+        """`f16`: the descriptor of esme_hip_forward_half -- the float16 derived copies (precision 'half')."""
         from esme.attention import _version_key
         self.key = self.signature(model)
         layers = model.layers
@@ -44,10 +45,10 @@ class ModelDescriptor:
         arr = (LayerWeights * len(layers))()
         for i, layer in enumerate(layers):
             att = layer.self_attn
-            wq, _, c1, c2 = att._weights_qkv(True)
-            wo, bo = att._weights_out()
-            wu, _, u1, u2 = layer._weights_up(True)
-            wd, bd = layer._weights_down()
+            wq, _, c1, c2 = att._weights_qkv(True, f16)
+            wo, bo = att._weights_out(f16)
+            wu, _, u1, u2 = layer._weights_up(True, f16)
+            wd, bd = layer._weights_down(f16)
             lw = arr[i]
             lw.qkv_w, lw.qkv_c1, lw.qkv_c2 = _ptr(wq), _ptr(c1), _ptr(c2)
             lw.out_w, lw.out_b = _ptr(wo), _ptr(bo)
@@ -91,8 +92,8 @@ class ModelDescriptor:
         return (ep, tuple(map(_VERSION, cache[1])))
 
     @staticmethod
-    def supported(model) -> bool:
-        if not len(model.layers) or not model.fold_layernorm or model.precision != 'fast' or model.phys_dim % 64:
+    def supported(model, precision: str = 'fast') -> bool:
+        if not len(model.layers) or not model.fold_layernorm or model.precision != precision or model.phys_dim % 64:
             return False
         for layer in model.layers:
             att = layer.self_attn
@@ -127,3 +128,31 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
                                      _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
                                      _ptr(pos), ws.data_ptr(), ws.numel(), None, 0, _hip._stream()), 'esme_hip_forward')
     return x
+
+
+
+def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32):
+    """precision 'half': fp32 stream at the start `x32` (T, phys_dim) -> all layers + final LayerNorm through ONE C call
+    (esme_hip_forward_half); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32."""
+    lib = _bind()
+    md = getattr(model, '_cdesc16', None)
+    if md is None or md.key != ModelDescriptor.signature(model):
+        md = ModelDescriptor(model, f16=True)
+        model._cdesc16 = md
+    d = md.desc
+    d.cos, d.sin = _ptr(cos), _ptr(sin)
+    d.table_len = int(cos.shape[0]) if cos is not None else 0
+    T = x32.shape[0]
+    nbytes = int(lib.esme_hip_forward_half_workspace_bytes(ctypes.byref(d), T))
+    key = (x32.device.index, _hip._stream(), 'half')
+    pool = model.__dict__.setdefault('_cws', {})
+    ws = pool.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(pool) >= 8:
+            pool.clear()
+        ws = pool[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x32.device)
+    _hip._check(lib.esme_hip_forward_half(ctypes.byref(d), _hip._dev(x32, 'forward x32', torch.float32), x32.stride(0),
+                                          _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
+                                          _ptr(pos), ws.data_ptr(), ws.numel(), _hip._dev(pair, 'forward pair', torch.bfloat16), pair.stride(0),
+                                          _hip._dev(rep32, 'forward rep32', torch.float32), rep32.stride(0), _hip._stream()),
+                'esme_hip_forward_half')

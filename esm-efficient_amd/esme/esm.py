@@ -149,9 +149,9 @@ class ESM2(nn.Module):
         _hip.residual_f32_(x32, x, 1.0, x, None, init=True)
         return x32
 
-    def _c_forward_ok(self) -> bool:
+    def _c_forward_ok(self, precision: str = 'fast') -> bool:
         from esme.cforward import ModelDescriptor
-        return ModelDescriptor.supported(self)
+        return ModelDescriptor.supported(self, precision)
 
     def set_precision(self, mode: str):
         """'fast' (default), 'high' (fp32 residual stream), 'half' (fp32 stream + fp16 MFMA operands: ~5e-4 of the fp32 forward, fp32
@@ -266,6 +266,16 @@ class ESM2(nn.Module):
             # the split-operand form (fp32 representation / logits)
             T, Ep = x.shape
             x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
+            if self.c_forward and not layers and _hip.TRACE is None and self._c_forward_ok('half'):
+                # all layers + the final LayerNorm through ONE C call (esme_hip_forward_half: the launches below, bit-identical)
+                from esme import cforward
+                alloc = torch.zeros if self.padded else torch.empty
+                pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
+                x = alloc(T, Ep, dtype=torch.float32, device=x.device)
+                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x)
+                if want_pair:
+                    x = pair
+                return self._finish_representation(x, [], pad_output, pad_args, pad_indices, cu_lens, pad_width)
             # the stream as a float16 PAIR [hi | lo] (x = hi + lo: 22 significant bits): hi is the operand of the LayerNorm-folded GEMMs,
             # the residual GEMMs read and write the pair in place (8 B per element in whole lines; an fp32 stream + operand copy is 10).
             # Padded layouts (ESM2-35M): everything at the physical width, pad columns zero as in the fast mode.
@@ -309,6 +319,9 @@ class ESM2(nn.Module):
                     taps.append(x.clone())
             self.emb_layer_norm_after(x[:, :E], out=x[:, :E])        # pad columns (if any) stay zero
 
+        return self._finish_representation(x, taps, pad_output, pad_args, pad_indices, cu_lens, pad_width)
+
+    def _finish_representation(self, x, taps, pad_output, pad_args, pad_indices, cu_lens, pad_width):
         if pad_output or (pad_args is None):
             nseq = cu_lens.numel() - 1
             x = self._pad(x, pad_indices, nseq, pad_width)
@@ -351,6 +364,7 @@ class ESM2(nn.Module):
         if getattr(self, '_graph_cache', None) is not None:
             self._graph_cache.clear()
         self.__dict__.pop('_cdesc', None)
+        self.__dict__.pop('_cdesc16', None)
         self.__dict__.pop('_cparams', None)
         self.__dict__.pop('_cws', None)
         from esme.nn import bump_epoch

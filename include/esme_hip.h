@@ -468,6 +468,21 @@ int esme_hip_forward(const esme_model_desc_t* model, void* x, int64_t ldx, const
                      int64_t T, int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes,
                      void* logits, int64_t ld_logits, void* stream);
 
+/* The layer stack in precision 'half' (see esme_gemm_fusion_t.f16) through ONE call: IEEE fp16 MFMA operands, the residual stream as an
+ * fp16 pair updated in place by the residual GEMMs.  The descriptor is the same struct with the fp16 DERIVED copies: qkv_w / up_w =
+ * fp16(W diag(gamma)) with c1 = ITS row sums, out_w / down_w = the bf16 weights converted to fp16 (exact), cos / sin fp16 tables; biases and
+ * LayerNorm parameters stay bf16; attn_q_prescale is ignored (P must fit fp16).
+ *  x32:   fp32 (T, phys_dim), row stride ld32: the stream at the start (embedding rows; ESM-1b / 1v: token + learned-position sums);
+ *  pair:  bf16 (T, 2 * phys_dim) = [hi | lo], row stride ld_pair: the final LayerNorm's output as the split-operand LM head reads it
+ *         (pad columns, if any, are left as they are: pass zeros); rep32: the same in fp32 (T, phys_dim), row stride ld_rep, or NULL;
+ *  workspace: esme_hip_forward_half_workspace_bytes(desc, T) bytes, 16-byte aligned.
+ * Issues the launches of the module-by-module path (esme/attention.py forward_high_precision): bit-identical results.  No counterpart in
+ * the reference (its arithmetic type is the constructor's dtype, esme/esm.py:132-141). */
+int64_t esme_hip_forward_half_workspace_bytes(const esme_model_desc_t* model, int64_t T);
+int esme_hip_forward_half(const esme_model_desc_t* model, const float* x32, int64_t ld32, const int32_t* cu_lens, int B,
+                          int64_t T, int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes,
+                          void* pair, int64_t ld_pair, float* rep32, int64_t ld_rep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -413,3 +413,22 @@ def test_half_mode_head_dim_128():
     fast = rel_fro(model.set_precision('fast')(tokens.to(DEV), (cu.to(DEV), max(lengths))).float().cpu(), ref)
     print(f'\n[half] head dim 128: logits {e:.2e} vs the fp32 oracle (fast {fast:.2e})')
     assert out.dtype == torch.float32 and e <= 1e-3 and e < 0.25 * fast
+
+
+@pytest.mark.parametrize('kind,L,E,H', [('esm2', 3, 640, 20), ('esm2', 2, 480, 20), ('esm2', 2, 256, 2), ('esmc', 2, 960, 15)])
+def test_half_mode_c_forward_entry_equals_module_path(kind, L, E, H):
+    """esme_hip_forward_half (ONE C call for the layer stack + final LayerNorm) issues the launches of the module-by-module path: logits
+    and representations are bit-identical (head dim 32 / padded 24 -> 32 / 128 / ESM-C with its q/k pass)."""
+    lengths = [70, 9, 200, 33]
+    tokens, cu = syn.random_tokens(lengths, seed=4).to(DEV), syn.cu_lens_of(lengths).to(DEV)
+    model = build(kind, L, E, H, seed=9).set_precision('half')
+    assert model.c_forward and model._c_forward_ok('half')
+    out_c = model(tokens, (cu, max(lengths)))
+    rep_c = model.forward_representation(tokens, (cu, max(lengths)))
+    model.c_forward = False
+    out_m = model(tokens, (cu, max(lengths)))
+    rep_m = model.forward_representation(tokens, (cu, max(lengths)))
+    model.c_forward = True
+    assert out_c.dtype == torch.float32 and torch.equal(out_c, out_m) and torch.equal(rep_c, rep_m)
+    assert torch.equal(model(tokens, (cu, max(lengths))), out_c)          # (descriptor and workspace reused)
+
