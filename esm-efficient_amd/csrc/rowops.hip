@@ -466,6 +466,23 @@ __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __rest
     if (lane == 0 && sums) sums[row] = f32x2{s1, s2};
 }
 
+// out32 = hi + lo of a 16-bit pair stream (bf16 or fp16): the raw layer outputs `forward_representation(layers=[...])` returns in the pair modes
+template <bool F16>
+__global__ __launch_bounds__(256) void pair_to_f32_kernel(const u16* __restrict__ x, int64_t ld, int64_t lo_off, float* __restrict__ out,
+                                                          int64_t ld32, int64_t T, int chunks) {
+    const int64_t total = T * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / chunks;
+        const int c = (int)(i - t * chunks);
+        float h[8], l[8];
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(x + t * ld + c * 8), h);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(x + t * ld + lo_off + c * 8), l);
+        float* o = out + t * ld32 + c * 8;
+        *reinterpret_cast<f32x4*>(o) = f32x4{h[0] + l[0], h[1] + l[1], h[2] + l[2], h[3] + l[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{h[4] + l[4], h[5] + l[5], h[6] + l[6], h[7] + l[7]};
+    }
+}
+
 // ------------------------------------------- q/k LayerNorm + rotary (ESM-C)
 // ESM-C normalises q and k over the FULL embedding width between the projection and the rotary
 // (attention.py:104-105), so that LayerNorm cannot ride in a GEMM epilogue (a row spans several
@@ -794,6 +811,19 @@ extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "stream_operand: E > 5120 unsupported");
 #undef ESME_SO
     return check_launch("stream_operand");
+}
+
+extern "C" int esme_hip_pair_to_f32(const void* x, int64_t ld, int64_t lo_off, int f16, float* out, int64_t ld32, int64_t T, int E, void* stream) {
+    ESME_CHECK_ARG(T >= 0 && E > 0, "pair_to_f32: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x && out, "pair_to_f32: null pointer");
+    ESME_CHECK_ARG(E % 8 == 0 && ld % 8 == 0 && lo_off % 8 == 0 && lo_off >= E && ld >= lo_off + E && ld32 % 4 == 0 && ld32 >= E, "pair_to_f32: bad layout");
+    ESME_CHECK_ARG(aligned16(x) && aligned16(out), "pair_to_f32: misaligned");
+    const int chunks = E / 8;
+    const dim3 grid(grid_for(T * chunks, 256)), block(256);
+    if (f16) hipLaunchKernelGGL(pair_to_f32_kernel<true>, grid, block, 0, (hipStream_t)stream, (const u16*)x, ld, lo_off, out, ld32, T, chunks);
+    else hipLaunchKernelGGL(pair_to_f32_kernel<false>, grid, block, 0, (hipStream_t)stream, (const u16*)x, ld, lo_off, out, ld32, T, chunks);
+    return check_launch("pair_to_f32");
 }
 
 extern "C" int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy,

@@ -84,6 +84,7 @@ SIGNATURES = {
                                                c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_qk_norm_rotary_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_pair_to_f32': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_void_p]),
@@ -531,6 +532,19 @@ def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Te
         _check(load().esme_hip_stream_operand(xp, ld32, yp, ld16, E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
                                               _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
                'esme_hip_stream_operand')
+
+
+def pair_to_f32(xs: torch.Tensor) -> torch.Tensor:
+    """(T, 2E) 16-bit pair [hi | lo] (bfloat16 or float16) -> (T, E) float32 hi + lo."""
+    if xs.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError('pair_to_f32: the pair is bfloat16 or float16')
+    xp, ld = _rows2d(xs, 'pair_to_f32 x', xs.dtype)
+    T, E = xs.shape[0], xs.shape[1] // 2
+    out = torch.empty(T, E, dtype=torch.float32, device=xs.device)
+    with _Traced('pair_to_f32', (T, E)):
+        _check(load().esme_hip_pair_to_f32(xp, ld, E, 1 if xs.dtype == torch.float16 else 0, out.data_ptr(), out.stride(0), T, E, _stream()),
+               'esme_hip_pair_to_f32')
+    return out
 
 
 def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, out: torch.Tensor) -> torch.Tensor:

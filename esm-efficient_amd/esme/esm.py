@@ -288,7 +288,7 @@ class ESM2(nn.Module):
             for i, layer in enumerate(self.layers):
                 layer.forward_high_precision(x16, cu_lens, max_len, ctx)
                 if i in layers:
-                    taps.append(ctx.xs[:, :Ep].float() + ctx.xs[:, Ep:].float())
+                    taps.append(_hip.pair_to_f32(ctx.xs))
             ln = self.emb_layer_norm_after
             alloc = torch.zeros if self.padded else torch.empty
             pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)

@@ -103,6 +103,10 @@ int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, int64_t ldo, 
 int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
                             float* sums, int64_t T, int E, void* stream);
 
+/* out[t, e] = x[t, e] + x[t, lo_off + e] in fp32 for a 16-bit pair stream (bf16, or IEEE fp16 when f16 != 0): the raw layer outputs that
+ * forward_representation(layers=[...]) (esme/esm.py:225-227,249-264) returns when the stream is a pair (precision 'half'). */
+int esme_hip_pair_to_f32(const void* x, int64_t ld, int64_t lo_off, int f16, float* out, int64_t ld32, int64_t T, int E, void* stream);
+
 /* esme_hip_layernorm on an fp32 input (bf16 affine parameters and output): the final LayerNorm of the
  * high-precision mode (esme/esm.py:252). */
 int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w, const void* b, void* y,
