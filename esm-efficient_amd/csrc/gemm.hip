@@ -756,8 +756,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 ESME_LDS_CHECK(slab_lo + r * ROWB + ((ch ^ (r & (CH - 1))) << 4), 16, smem, 2 * STAGE);
                 const u32x4 vl = *reinterpret_cast<const u32x4*>(slab_lo + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (col_ok && m < a.M) {
-                    *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n) = v;
-                    *reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n) = vl;
+                    store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n), v, a.stream_out);
+                    store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n), vl, a.stream_out);
                 }
                 if constexpr (STATS) {                        // statistics of hi: what the next LayerNorm-folded GEMM multiplies
                     float f[8];
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         const int64_t m = mw0 + pass * RPP + r;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = fmaf(a.alpha, o[e], xr[i][jj][e]);
-                        if (m < a.M && n < a.N) *reinterpret_cast<f32x4*>(a.resid32 + m * a.ld32 + n) = f32x4{o[0], o[1], o[2], o[3]};
+                        if (m < a.M && n < a.N) store_stream(reinterpret_cast<f32x4*>(a.resid32 + m * a.ld32 + n), f32x4{o[0], o[1], o[2], o[3]}, a.stream_out);
                     } else if constexpr (EPI == ESME_EPI_RESIDUAL) {
                         const u32x2 rw = *reinterpret_cast<const u32x2*>(slab + slab_off(r, cl));
                         o[0] = bf_lo(rw[0]) + a.alpha * o[0]; o[1] = bf_hi(rw[0]) + a.alpha * o[1];
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int64_t m = mw0 + pass * RPP + r;
                 ESME_LDS_CHECK(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4), 16, smem, 2 * STAGE);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
-                if (col_ok && m < a.M && ESME_TUNE_STORE_OK) *reinterpret_cast<u32x4*>(a.C + m * a.ldc + n + (PAIR ? half * a.pair_off : 0)) = v;
+                if (col_ok && m < a.M && ESME_TUNE_STORE_OK) store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n + (PAIR ? half * a.pair_off : 0)), v, a.stream_out);
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
@@ -1258,6 +1258,13 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     }
     const hipStream_t s = (hipStream_t)stream;
     a.stat_ld = M;
+#ifndef ESME_NT_MIN_MB
+#define ESME_NT_MIN_MB 256          // the 256 MB memory-side cache (Infinity Cache): smaller results are worth keeping there for the next kernel
+#endif
+    {   // bytes this launch writes: C (16-bit) [+ its lo half] [+ the fp32 stream]
+        const double out_bytes = (double)M * n_out * 2.0 * (a.pair_off ? 2.0 : 1.0) + (a.resid32 ? (double)M * N * 4.0 : 0.0);
+        a.stream_out = out_bytes > ESME_NT_MIN_MB * 1048576.0;
+    }
     const int tile = pick_tile(M, N, opts);
     if (tile == 1) return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
     // 256 x 256 tiles run one workgroup per CU, so a launch takes ceil(tiles / CUs) rounds.  (Round 2 measured a "tail split"
