@@ -177,8 +177,8 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));
         aopts.seq_order = w.order;
     }
-    // the stream as an fp16 pair [hi | lo] + the statistics of hi
-    ESME_TRY(esme_hip_stream_operand(x32, ld32, w.xs, 2 * (int64_t)Ep, Ep, 1, w.sums, T, Ep, stream));
+    // the stream as an fp16 pair [hi | lo] (scaled per column for the first LayerNorm-folded GEMM) + the statistics of the fp32 rows
+    ESME_TRY(esme_hip_stream_operand_scaled(x32, ld32, w.xs, 2 * (int64_t)Ep, Ep, 1, m->layers[0].ps_attn, w.sums, T, Ep, stream));
     const float* stats = w.sums;
     int stats_nblk = 1;
     for (int i = 0; i < m->n_layers; ++i) {
@@ -197,6 +197,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         ESME_TRY(esme_hip_attn_varlen_fwd_opts(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, &aopts, stream));
         esme_gemm_fusion_t fo{};
         fo.f16 = 1; fo.pair_off = Ep; fo.stats_out = w.part_b;
+        fo.pair_scale_in = L.ps_attn_inv; fo.pair_scale_out = L.ps_ffn;               // the stream arrives scaled for this layer's attention LayerNorm, leaves scaled for its FFN LayerNorm
         ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, 2 * (int64_t)Ep, w.xs, 2 * (int64_t)Ep, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
         esme_gemm_fusion_t fup{};
         fup.f16 = 1;
@@ -206,6 +207,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
                                           m->swiglu ? ESME_EPI_SWIGLU : ESME_EPI_GELU, 1.0f, &fup, stream));
         esme_gemm_fusion_t fd{};
         fd.f16 = 1; fd.pair_off = Ep; fd.stats_out = w.part_a;
+        fd.pair_scale_in = L.ps_ffn_inv; fd.pair_scale_out = i + 1 < m->n_layers ? m->layers[i + 1].ps_attn : nullptr;    // (the final LayerNorm reads the stream unscaled)
         ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, w.xs, 2 * (int64_t)Ep, w.xs, 2 * (int64_t)Ep, T, Ep, m->ffn_dim,
                                           ESME_EPI_RESIDUAL, m->alpha, &fd, stream));
         stats = w.part_a; stats_nblk = nblk;

@@ -41,6 +41,7 @@ struct GemmArgs {
     // the same C row; c32: fp32 result through the scalar store path (the (T, V) logits)
     int kt_wrap = 0; int64_t pair_off = 0; float* c32 = nullptr; int64_t ldc32 = 0;
     int f16 = 0;                 // precision 'half': A, W, rotary tables and C are IEEE fp16 (esme_gemm_fusion_t.f16)
+    const float* ps_in = nullptr; const float* ps_out = nullptr;   // pair stream stored scaled per column (esme_gemm_fusion_t.pair_scale_in / _out); nullptr = 1
     int stream_out = 0;          // host side: the results are larger than the memory-side cache -> stored with the non-temporal hint (common.h store_stream)
 };
 

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     static_assert(EPI != ESME_EPI_SWIGLU || WTN == 64, "swiglu needs 64-wide wave tiles");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LDS_BYTES = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);      // = launch_one's request
+    constexpr int LDS_BYTES = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0) + (RP ? 2 * BN * 8 : 0);      // = launch_one's request
     (void)LDS_BYTES;
 
     const int tid = threadIdx.x;
@@ -247,6 +247,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
     };
+    // RP (pair stream): the stream is stored SCALED per column -- stored[m, n] = rho[n] * x[m, n], rho = gamma / pow2(gamma) of the LayerNorm
+    // whose folded GEMM reads it next (esme_gemm_fusion_t.pair_scale_in / _out) -- so the tile's {1 / rho_in, rho_out} columns sit in
+    // a double-buffered LDS strip behind the statistics (a persistent workgroup fills the next tile's half mid-epilogue).
+    f32x4* pscale = reinterpret_cast<f32x4*>(smem + 2 * STAGE + (STATS ? WN * BM * 8 : 0));     // [2][{in, out}][BN / 4]
+    int sp = 0;
+    auto fill_scales = [&](const int half) {
+        if constexpr (RP) {
+            if (tid < BN / 4) {
+                int n = n0 + tid * 4;
+                n = n < a.N - 4 ? n : a.N - 4;
+                const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+                ESME_LDS_CHECK(&pscale[half * (BN / 2) + BN / 4 + tid], 16, smem, LDS_BYTES);
+                pscale[half * (BN / 2) + tid] = a.ps_in ? *reinterpret_cast<const f32x4*>(a.ps_in + n) : one;
+                pscale[half * (BN / 2) + BN / 4 + tid] = a.ps_out ? *reinterpret_cast<const f32x4*>(a.ps_out + n) : one;
+            }
+        }
+    };
     int par = 0;                              // stage buffer that holds K-tile 0 of the current tile
     stage(0, 0);
     // The tile's LDS strips (rotary positions, LayerNorm row statistics, c1 / c2 columns); the next barrier publishes them.
@@ -327,6 +344,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 
     };
     make_strips();
+    fill_scales(0);
     __syncthreads();                          // drains the LDS-DMA (vmcnt) + barrier; publishes the LN strip
     FragW w0;
     FragA a0, a1;
@@ -692,6 +710,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         };
         if constexpr (RP) {
         char* slab_lo = slab + RPP * ROWB;
+        const f32x4* sc_in = pscale + sp * (BN / 2) + ((wn * WTN) >> 2);     // this wave's 64 columns of {1 / rho_in, rho_out}
+        const f32x4* sc_out = sc_in + BN / 4;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slabs
@@ -709,10 +729,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            // statistics of the UNSCALED fp32 stream value x (what the next LayerNorm normalises), accumulated in the accumulator
+            // layout: lane (l15, lq) holds 16 of row (jj, l15)'s 64 wave columns.  Canonical association (the same in every tile
+            // configuration, so a row's statistics do not depend on the batch it is packed into): per fragment (o0 + o1) + (o2 + o3),
+            // fragments ((f0 + f1) + (f2 + f3)), then the four column quads of the row: (lq ^ 1 pairs) then (lq ^ 2 pairs).
+            float t1[FMP][FN], t2[FMP][FN];
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const int cl = i * 16 + 4 * lq;
                 const float bv[4] = {bf_lo(bq[i][0]), bf_hi(bq[i][0]), bf_lo(bq[i][1]), bf_hi(bq[i][1])};
+                const f32x4 si = sc_in[cl >> 2], so = sc_out[cl >> 2];
 #pragma unroll
                 for (int jj = 0; jj < FMP; ++jj) {
                     const int j = pass * FMP + jj;
@@ -722,13 +748,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     const u32x2 lw = *reinterpret_cast<const u32x2*>(slab_lo + slab_off(r, cl));
                     const float xs[4] = {lo16<true>(hq[0]) + lo16<true>(lw[0]), hi16<true>(hq[0]) + hi16<true>(lw[0]),
                                          lo16<true>(hq[1]) + lo16<true>(lw[1]), hi16<true>(hq[1]) + hi16<true>(lw[1])};     // exact in fp32
-                    float o[4];
+                    float o[4], st[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaf(a.alpha, acc[i][j][e] + bv[e], xs[e]);
-                    const u32x2 ph = {pack_f16(o[0], o[1]), pack_f16(o[2], o[3])};
-                    const u32x2 pl = {pack_f16(o[0] - lo16<true>(ph[0]), o[1] - hi16<true>(ph[0])), pack_f16(o[2] - lo16<true>(ph[1]), o[3] - hi16<true>(ph[1]))};
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = fmaf(a.alpha, acc[i][j][e] + bv[e], __fmul_rn(xs[e], si[e]));      // x + alpha * (acc + bias), x = stored / rho_in
+                        st[e] = __fmul_rn(o[e], so[e]);                                          // stored = rho_out * x
+                    }
+                    if constexpr (STATS) {
+                        t1[jj][i] = (o[0] + o[1]) + (o[2] + o[3]);
+                        t2[jj][i] = (__fmul_rn(o[0], o[0]) + __fmul_rn(o[1], o[1])) + (__fmul_rn(o[2], o[2]) + __fmul_rn(o[3], o[3]));
+                    }
+                    const u32x2 ph = {pack_f16(st[0], st[1]), pack_f16(st[2], st[3])};
+                    const u32x2 pl = {pack_f16(st[0] - lo16<true>(ph[0]), st[1] - hi16<true>(ph[0])), pack_f16(st[2] - lo16<true>(ph[1]), st[3] - hi16<true>(ph[1]))};
                     *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = ph;
                     *reinterpret_cast<u32x2*>(slab_lo + slab_off(r, cl)) = pl;
+                }
+            }
+            if constexpr (STATS) {
+                const bool cols_ok = nw0 < n_out;                 // (wave-uniform: N % 64 == 0 on this path)
+#pragma unroll
+                for (int jj = 0; jj < FMP; ++jj) {
+                    float u1 = (t1[jj][0] + t1[jj][1]) + (t1[jj][2] + t1[jj][3]);
+                    float u2 = (t2[jj][0] + t2[jj][1]) + (t2[jj][2] + t2[jj][3]);
+                    {   // lanes 16 apart (lq ^ 1), then 32 apart (lq ^ 2): v_permlane16_swap / v_permlane32_swap, no LDS traffic
+                        const auto a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u1), __float_as_uint(u1), false, false);
+                        const auto a2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u2), __float_as_uint(u2), false, false);
+                        u1 = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
+                        u2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                        const auto b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u1), __float_as_uint(u1), false, false);
+                        const auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(u2), __float_as_uint(u2), false, false);
+                        u1 = __uint_as_float(b1[0]) + __uint_as_float(b1[1]);
+                        u2 = __uint_as_float(b2[0]) + __uint_as_float(b2[1]);
+                    }
+                    ESME_LDS_CHECK(&blkst[wn * BM + wm * WTM + pass * RPP + jj * 16 + l15], 8, smem, LDS_BYTES);
+                    if (lq == 0) blkst[wn * BM + wm * WTM + pass * RPP + jj * 16 + l15] = cols_ok ? f32x2{u1, u2} : f32x2{0.f, 0.f};
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -742,6 +795,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         set_sources();
                         par = lastbuf ^ 1;
                         stage(0, par);                        // (waited for by the next pass's vmcnt(0): the tile's last barrier needs none)
+                        fill_scales(sp ^ 1);                  // the next tile's scale columns (published by the barrier that ends this tile)
                     }
                 }
             }
@@ -759,19 +813,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n), v, a.stream_out);
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n), vl, a.stream_out);
                 }
-                if constexpr (STATS) {                        // statistics of hi: what the next LayerNorm-folded GEMM multiplies
-                    float f[8];
-                    unpack8t<true>(v, f);
-                    float t1 = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-                    float t2 = ((f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3])) +
-                               ((f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]));
-                    t1 += dpp_f32<0xB1>(t1); t2 += dpp_f32<0xB1>(t2);
-                    t1 += dpp_f32<0x4E>(t1); t2 += dpp_f32<0x4E>(t2);
-                    t1 += dpp_f32<0x141>(t1); t2 += dpp_f32<0x141>(t2);
-                    if (ch == 0) blkst[wn * BM + wm * WTM + pass * RPP + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
-                }
             }
         }
+        sp ^= 1;
         } else {
         load_x32(0);
         // PAIR (split-operand mode): every pass runs twice -- first the bf16 rounding hi of the fp32 results (the residuals o - hi
@@ -1022,7 +1066,7 @@ static void set_raster(GemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int ROTD, bool LNF, bool STATS, bool PERSIST = false, bool R32 = false, bool PAIR = false, bool F16 = false, bool RP = false>
 static int launch_one(GemmArgs& a, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0);
+    constexpr int smem = 2 * (BM + BN) * 128 + ((LNF || ROTD > 0) ? BM * 12 + BN * 8 : 0) + (STATS ? WN * BM * 8 : 0) + (RP ? 2 * BN * 8 : 0);
     set_raster<BM, BN>(a);
     int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
@@ -1192,12 +1236,17 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     int rotd = 0;
     bool lnf = false, stats = false;
     if (r32) { a.resid32 = fu->resid32; a.ld32 = fu->ld32; }
+    ESME_CHECK_ARG(!fu || (!fu->pair_scale_in && !fu->pair_scale_out) || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_RESIDUAL),
+                   "gemm: pair_scale_in / pair_scale_out belong to the fp16 pair stream's residual epilogue");
     if (fu && fu->f16 && fu->pair_off) {                             // precision 'half': the residual stream as an fp16 pair [hi | lo]
         ESME_CHECK_ARG(epilogue == ESME_EPI_RESIDUAL && !r32 && !fu->w_k && !fu->c32 && !fu->ln_partial, "gemm: the fp16 pair stream belongs to the residual epilogue");
         ESME_CHECK_ARG(fu->pair_off >= N && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + N && ldr >= fu->pair_off + N,
                        "gemm: pair_off must be a multiple of 8 with N <= pair_off <= ldc - N, ldr - N");
         if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: the pair stream needs 16-byte addressable rows and N % 8 == 0");
         a.pair_off = fu->pair_off;
+        ESME_CHECK_ARG((!fu->pair_scale_in || aligned16(fu->pair_scale_in)) && (!fu->pair_scale_out || aligned16(fu->pair_scale_out)) && (N % 4 == 0),
+                       "gemm: pair_scale_in / pair_scale_out must be 16-byte aligned float (N) vectors");
+        a.ps_in = fu->pair_scale_in; a.ps_out = fu->pair_scale_out;
     } else if (fu && (fu->w_k || fu->pair_off || fu->c32)) {        // split-operand ('exact') mode
         if (fu->w_k) {
             ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && K % fu->w_k == 0, "gemm: w_k (the K of W) must be a multiple of 64 that divides K");

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
 // bf16 embedding rows, e.g. after the learned-position sum; afterwards the residual GEMMs' epilogues keep both current).
 template <int NCH, bool F16>
 __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __restrict__ x32, int64_t ld32, u16* __restrict__ x16,
-                                                             int64_t ld16, int64_t lo_off, f32x2* __restrict__ sums, int64_t T, int E) {
+                                                             int64_t ld16, int64_t lo_off, const float* __restrict__ scale,
+                                                             f32x2* __restrict__ sums, int64_t T, int E) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -447,18 +448,28 @@ __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __rest
         const int e0 = (c * 64 + lane) * 8;
         if (e0 < E) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + e0), a1 = *reinterpret_cast<const f32x4*>(xr + e0 + 4);
-            const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            if (lo_off) {                                  // pair stream: statistics of the fp32 value itself (what the residual epilogues emit later)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                if (scale) {                               // stored = rho * x (esme_gemm_fusion_t.pair_scale_in / _out)
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(scale + e0), c1 = *reinterpret_cast<const f32x4*>(scale + e0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = __fmul_rn(v[j], c0[j]); v[4 + j] = __fmul_rn(v[4 + j], c1[j]); }
+                }
+            }
             const u32x4 pk = pack8t<F16>(v);
             *reinterpret_cast<u32x4*>(yr + e0) = pk;
             float r[8];
             unpack8t<F16>(pk, r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s1 += r[j]; s2 = fmaf(r[j], r[j], s2); }
-            if (lo_off) {                                  // the stream as a pair: lo = round(x - hi), lo_off columns further in the same row
+            if (lo_off) {                                  // lo = round(x - hi), lo_off columns further in the same row
                 float l[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) l[j] = v[j] - r[j];
                 *reinterpret_cast<u32x4*>(yr + lo_off + e0) = pack8t<F16>(l);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1 += r[j]; s2 = fmaf(r[j], r[j], s2); }
             }
         }
     }
@@ -791,18 +802,19 @@ extern "C" int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, in
     return check_launch("residual_f32");
 }
 
-extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, float* sums,
-                                       int64_t T, int E, void* stream) {
+extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, const float* scale,
+                                              float* sums, int64_t T, int E, void* stream) {
     ESME_CHECK_ARG(T >= 0 && E > 0, "stream_operand: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(x32 && x16, "stream_operand: null pointer");
     ESME_CHECK_ARG(E % 8 == 0 && ld32 % 4 == 0 && ld16 % 8 == 0 && ld32 >= E && ld16 >= E, "stream_operand: E / row strides not multiples of 8");
     ESME_CHECK_ARG(lo_off == 0 || (lo_off >= E && lo_off % 8 == 0 && ld16 >= lo_off + E), "stream_operand: lo_off must be a multiple of 8 with E <= lo_off <= ld16 - E");
     ESME_CHECK_ARG(aligned16(x32) && aligned16(x16) && (!sums || (reinterpret_cast<uintptr_t>(sums) & 7u) == 0), "stream_operand: misaligned");
+    ESME_CHECK_ARG(!scale || (lo_off != 0 && aligned16(scale)), "stream_operand: a column scale belongs to the pair form (lo_off != 0) and must be 16-byte aligned");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, (f32x2*)sums, T, E); \
-                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, (f32x2*)sums, T, E); } while (0)
+#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, (f32x2*)sums, T, E); \
+                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, (f32x2*)sums, T, E); } while (0)
     if (E <= 512) ESME_SO(1);
     else if (E <= 1024) ESME_SO(2);
     else if (E <= 1536) ESME_SO(3);
@@ -811,6 +823,11 @@ extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "stream_operand: E > 5120 unsupported");
 #undef ESME_SO
     return check_launch("stream_operand");
+}
+
+extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, float* sums,
+                                       int64_t T, int E, void* stream) {
+    return esme_hip_stream_operand_scaled(x32, ld32, x16, ld16, lo_off, f16, nullptr, sums, T, E, stream);
 }
 
 extern "C" int esme_hip_pair_to_f32(const void* x, int64_t ld, int64_t lo_off, int f16, float* out, int64_t ld32, int64_t T, int E, void* stream) {

@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -27,7 +27,8 @@ class GemmFusion(Structure):
     _fields_ = [('ln_partial', c_void_p), ('ln_nblk', c_int), ('ln_dim', c_int), ('ln_eps', c_float), ('ln_c1', c_void_p), ('ln_c2', c_void_p), ('stats_out', c_void_p),
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int),
-                ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64), ('f16', c_int)]
+                ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64), ('f16', c_int),
+                ('pair_scale_in', c_void_p), ('pair_scale_out', c_void_p)]
 
 
 class GemmOpts(Structure):
@@ -44,7 +45,8 @@ class AttnOpts(Structure):
 class LayerWeights(Structure):
     """esme_layer_weights_t (include/esme_hip.h)."""
     _fields_ = [(n, c_void_p) for n in ('qkv_w', 'qkv_c1', 'qkv_c2', 'out_w', 'out_b', 'up_w', 'up_c1', 'up_c2',
-                                        'down_w', 'down_b', 'lnq_w', 'lnk_w', 'lnq_b', 'lnk_b')]
+                                        'down_w', 'down_b', 'lnq_w', 'lnk_w', 'lnq_b', 'lnk_b',
+                                        'ps_attn', 'ps_attn_inv', 'ps_ffn', 'ps_ffn_inv')]
 
 
 class ModelDesc(Structure):
@@ -86,6 +88,7 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_pair_to_f32': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_stream_operand_scaled': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_void_p]),
     'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
@@ -517,32 +520,38 @@ def residual_f32_(x32: torch.Tensor, o: torch.Tensor, alpha: float, x16: torch.T
                'esme_hip_residual_f32')
 
 
-def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor], pair: bool = False) -> None:
+def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor], pair: bool = False,
+                   scale: Optional[torch.Tensor] = None) -> None:
     """x16 <- round(x32) in x16's dtype (bfloat16, or float16 for precision 'half'); sums (1, T, 2) <- row {sum, sum sq} of the ROUNDED
     values: the operand and the statistics the LayerNorm-folded GEMMs read at the start of a forward on an fp32 stream.  `pair`: x16 is
-    (T, 2E) = [hi | lo] with lo = round(x32 - hi): the stream itself as a 16-bit pair (gemm_fused(resid_pair=))."""
+    (T, W >= 2E) = [hi | ... | lo] (lo in the last E columns) with lo = round(v - hi), v = scale * x32 (`scale`: float32 (E) or None = 1):
+    the stream itself as a 16-bit pair (gemm_fused(resid_pair=, pair_scale=)); `sums` then describes the fp32 values x32 themselves."""
     if x16.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError('stream_operand: x16 must be bfloat16 or float16')
     xp, ld32 = _rows2d(x32, 'stream_operand x32', torch.float32)
     yp, ld16 = _rows2d(x16, 'stream_operand x16', x16.dtype)
     T, E = x32.shape
-    if x16.shape != (T, 2 * E if pair else E):
+    if x16.shape[0] != T or (x16.shape[1] < 2 * E if pair else x16.shape[1] != E):
         raise ValueError('stream_operand: shape mismatch')
+    if scale is not None and (not pair or scale.numel() != E):
+        raise ValueError('stream_operand: `scale` is a float32 (E) vector of the pair form')
     with _Traced('stream_operand', (T, E)):
-        _check(load().esme_hip_stream_operand(xp, ld32, yp, ld16, E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
-                                              _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
-               'esme_hip_stream_operand')
+        _check(load().esme_hip_stream_operand_scaled(xp, ld32, yp, ld16, x16.shape[1] - E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
+                                                     _dev(scale, 'stream scale', torch.float32) if scale is not None else None,
+                                                     _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
+               'esme_hip_stream_operand_scaled')
 
 
-def pair_to_f32(xs: torch.Tensor) -> torch.Tensor:
-    """(T, 2E) 16-bit pair [hi | lo] (bfloat16 or float16) -> (T, E) float32 hi + lo."""
+def pair_to_f32(xs: torch.Tensor, width: Optional[int] = None) -> torch.Tensor:
+    """(T, 2E) 16-bit pair [hi | lo] (bfloat16 or float16) -> (T, E) float32 hi + lo (`width` = E when the row is wider than 2E: lo sits in
+    the LAST E columns)."""
     if xs.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError('pair_to_f32: the pair is bfloat16 or float16')
     xp, ld = _rows2d(xs, 'pair_to_f32 x', xs.dtype)
-    T, E = xs.shape[0], xs.shape[1] // 2
+    T, E = xs.shape[0], (xs.shape[1] // 2 if width is None else int(width))
     out = torch.empty(T, E, dtype=torch.float32, device=xs.device)
     with _Traced('pair_to_f32', (T, E)):
-        _check(load().esme_hip_pair_to_f32(xp, ld, E, 1 if xs.dtype == torch.float16 else 0, out.data_ptr(), out.stride(0), T, E, _stream()),
+        _check(load().esme_hip_pair_to_f32(xp, ld, xs.shape[1] - E, 1 if xs.dtype == torch.float16 else 0, out.data_ptr(), out.stride(0), T, E, _stream()),
                'esme_hip_pair_to_f32')
     return out
 
@@ -687,7 +696,7 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None,
                q_scale: float = 0.0, split_a: bool = False, pair_out: bool = False, out32: Optional[torch.Tensor] = None,
-               resid_pair: Optional[torch.Tensor] = None) -> torch.Tensor:
+               resid_pair: Optional[torch.Tensor] = None, pair_scale=None) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
@@ -700,7 +709,9 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     of `out` (scalar store path: the vocab projection).
     float16 `a` and `w` (precision 'half'): fp16 operands, float16 output, float16 rotary tables; `bias` stays bfloat16; the residual
     epilogue needs `resid32` or `resid_pair`: the stream as a float16 pair (M, 2N) = [hi | lo], updated in place (x + alpha * (a W^T + b)
-    formed in fp32, written back as a pair); returns its hi half, the next GEMM's operand (a view)."""
+    formed in fp32, written back as a pair); returns its hi half, the next GEMM's operand (a view).  The pair may be wider than 2N (lo in
+    the LAST N columns).  `pair_scale` = (scale_in, scale_out), float32 (N) or None each: the stream is stored scaled per column
+    (esme_gemm_fusion_t.pair_scale_in / _out: x = (hi + lo) * scale_in on entry, (x_new * scale_out) written back)."""
     f16 = a.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
     if f16 and (split_a or pair_out or out32 is not None):
@@ -714,8 +725,9 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         raise ValueError(f'gemm: K mismatch {a.shape} x {w.shape}')
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if resid_pair is not None:
-        if not f16 or epilogue != EPI_RESIDUAL or resid32 is not None or resid_pair.shape != (M, 2 * N) or resid_pair.dtype != torch.float16:
-            raise ValueError('gemm: resid_pair is the (M, 2N) float16 pair stream of the residual epilogue with float16 operands')
+        if (not f16 or epilogue != EPI_RESIDUAL or resid32 is not None or resid_pair.dim() != 2 or resid_pair.shape[0] != M
+                or resid_pair.shape[1] < 2 * N or resid_pair.dtype != torch.float16):
+            raise ValueError('gemm: resid_pair is the (M, >= 2N) float16 pair stream of the residual epilogue with float16 operands')
         resid = out = resid_pair[:, :N]
     if out is None:
         out = torch.empty(M, 2 * n_out if pair_out else n_out, dtype=dt, device=a.device) if out32 is None else out32
@@ -729,7 +741,16 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     if split_a:
         fu.w_k = K // 2
     if resid_pair is not None:
-        fu.pair_off = N
+        fu.pair_off = resid_pair.shape[1] - N
+        if pair_scale is not None:
+            sc_in, sc_out = pair_scale
+            for t in (sc_in, sc_out):
+                if t is not None and t.numel() != N:
+                    raise ValueError('gemm: pair_scale vectors are float32 (N)')
+            fu.pair_scale_in = _dev(sc_in, 'pair scale in', torch.float32) if sc_in is not None else None
+            fu.pair_scale_out = _dev(sc_out, 'pair scale out', torch.float32) if sc_out is not None else None
+    elif pair_scale is not None:
+        raise ValueError('gemm: pair_scale belongs to resid_pair')
     if pair_out:
         if out.shape[1] != 2 * n_out:
             raise ValueError('gemm: a pair output is (M, 2 * n_out)')

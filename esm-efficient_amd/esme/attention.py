@@ -127,6 +127,28 @@ def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.
     return wf, c1, c2.contiguous()
 
 
+def _fold_layernorm_pow2(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: Optional[torch.Tensor]):
+    """The LN fold of precision 'half' (round 5): gamma = g2 * rho with g2 a signed power of two (0 where gamma is 0) and rho in
+    [2^-1/2, 2^1/2].  W' = fp16(W * g2) is EXACT (a bf16 weight times a power of two; only values below fp16's normal range lose bits,
+    at 2^-25 absolute) where fp16(W * gamma) rounds every weight by 2^-12 -- a fixed perturbation of the model that the emulation
+    (tests/half_emulate.py) prices at a quarter of the mode's error; rho travels on the residual stream instead (the pair stream is
+    stored as rho * x: esme_gemm_fusion_t.pair_scale_in / _out).  Returns (W', c1 = sum_k gamma_k W[n, k] in fp32, c2 = W beta + bias,
+    rho, 1 / rho) -- c1 multiplies the mean of the UNSCALED row."""
+    g = gamma.float()
+    mag = g.abs()
+    g2 = torch.where(mag > 0, torch.sign(g) * torch.exp2(torch.round(torch.log2(mag.clamp_min(1e-37)))), torch.zeros_like(g))
+    rho = torch.where(mag > 0, g / torch.where(g2 == 0, torch.ones_like(g2), g2), torch.ones_like(g)).contiguous()
+    wf = (w.float() * g2.unsqueeze(0)).to(torch.float16).contiguous()
+    _check_fp16_range(wf)
+    c1 = (w.float() * g.unsqueeze(0)).sum(dim=1).contiguous()
+    c2 = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+    if beta is not None:
+        c2 += w.float() @ beta.float()
+    if bias is not None:
+        c2 += bias.float()
+    return wf, c1, c2.contiguous(), rho, (1.0 / rho).contiguous()
+
+
 class FlashMultiheadAttention(nn.Module):
     def __init__(self, embed_dim: int, num_heads: int, dropout=0.0, pre_layernorm=True,
                  rotary_embedding=True, bias=False, dtype=torch.bfloat16, phys_dim: Optional[int] = None,
@@ -162,8 +184,9 @@ class FlashMultiheadAttention(nn.Module):
         self._pack_key = None
         self._fold = None           # (W', c1, c2) of the LN-folded QKV projection
         self._fold_key = None
-        self._fold16 = None         # the same with W' in float16 (precision 'half'), and the float16 out-projection weight
+        self._fold16 = None         # the same with W' = W * pow2(gamma) in float16 (precision 'half'), and the float16 out-projection weight
         self._fold16_key = None
+        self._rho16 = None          # (rho, 1 / rho) float32 (phys_dim): the part of gamma that rides on the pair stream (_fold_layernorm_pow2)
         self._out16 = None
         self._out16_key = None
         self._q4_qkv = None         # esme.quantization.Q4Matrix pair when the layer is 4-bit
@@ -218,14 +241,26 @@ class FlashMultiheadAttention(nn.Module):
         key = (self._pack_key, _version_key(self.norm.weight, self.norm.bias))
         if key != (self._fold16_key if f16 else self._fold_key):
             with torch.no_grad():
-                fold = _fold_layernorm(self._qkv_w, self._qkv_b, _pad_last(self.norm.weight.data, self.phys_dim),
-                                       _pad_last(self.norm.bias.data, self.phys_dim) if self.norm.bias is not None else None,
-                                       torch.float16 if f16 else torch.bfloat16)
+                gamma = _pad_last(self.norm.weight.data, self.phys_dim)
+                beta = _pad_last(self.norm.bias.data, self.phys_dim) if self.norm.bias is not None else None
+                if f16:
+                    *fold, rho, rho_inv = _fold_layernorm_pow2(self._qkv_w, self._qkv_b, gamma, beta)
+                    fold, self._rho16 = tuple(fold), (rho, rho_inv)
+                else:
+                    fold = _fold_layernorm(self._qkv_w, self._qkv_b, gamma, beta, torch.bfloat16)
             if f16:
                 self._fold16, self._fold16_key = fold, key
             else:
                 self._fold, self._fold_key = fold, key
         return self._fold16 if f16 else self._fold
+
+    def stream_scale(self):
+        """precision 'half': (rho, 1 / rho) of this block's LayerNorm -- the per-column scaling the pair stream carries when the
+        LayerNorm-folded QKV projection reads it."""
+        if self._q4_qkv is not None:
+            raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
+        self._pack_fold(True)
+        return self._rho16
 
     def _weights_qkv(self, fold: bool, f16: bool = False):
         """(W, bias, c1, c2) of the fused QKV projection: the LN-folded form when `fold`
@@ -296,7 +331,7 @@ class FlashMultiheadAttention(nn.Module):
                                 softmax_scale=self.head_dim ** -0.5, exact=exact, order=order, q_prescaled=q_prescaled)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
-                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None, resid_pair=None):
+                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
         resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid).
         `x_stats` ((nblk, T, 2) f32 partial row sums of x) selects the LN-folded projection;
@@ -340,7 +375,8 @@ class FlashMultiheadAttention(nn.Module):
                        order=ctx.order if ctx is not None else None, q_prescaled=qp)
         wo, bo = self._weights_out(f16)
         if resid is not None or resid32 is not None or resid_pair is not None:
-            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair)
+            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair,
+                                   pair_scale=pair_scale)
         return _hip.gemm(a, wo, bo, out=out)
 
 
@@ -405,8 +441,9 @@ class FlashTransformerLayer(nn.Module):
         self.final_activation = final_activation
         self._fold = None
         self._fold_key = None
-        self._fold16 = None         # float16 forms (precision 'half'): folded up-projection, down-projection weight
+        self._fold16 = None         # float16 forms (precision 'half'): folded up-projection (W * pow2(gamma)), down-projection weight
         self._fold16_key = None
+        self._rho16 = None          # (rho, 1 / rho) of the FFN LayerNorm (see FlashMultiheadAttention._rho16)
         self._down16 = None
         self._down16_key = None
         self._q4_up = None          # esme.quantization.Q4Matrix pair when the layer is 4-bit
@@ -425,21 +462,36 @@ class FlashTransformerLayer(nn.Module):
             if key != have:
                 with torch.no_grad():
                     Ep = self.phys_dim
-                    fold = _fold_layernorm(_pad_last(up.weight.data, Ep), up.bias.data if up.bias is not None else None,
-                                           _pad_last(ln.weight.data, Ep), _pad_last(beta, Ep), dt)
+                    args = (_pad_last(up.weight.data, Ep), up.bias.data if up.bias is not None else None, _pad_last(ln.weight.data, Ep), _pad_last(beta, Ep))
+                    if f16:
+                        *fold, rho, rho_inv = _fold_layernorm_pow2(*args)
+                        fold, self._rho16 = tuple(fold), (rho, rho_inv)
+                    else:
+                        fold = _fold_layernorm(*args, dt)
         else:
             sw = self.final[1]
             sw._pack()
             key = (sw._pack_key, _version_key(ln.weight, ln.bias))
             if key != have:
                 with torch.no_grad():
-                    fold = _fold_layernorm(sw._packed, None, ln.weight.data, beta, dt)
+                    if f16:
+                        *fold, rho, rho_inv = _fold_layernorm_pow2(sw._packed, None, ln.weight.data, beta)
+                        fold, self._rho16 = tuple(fold), (rho, rho_inv)
+                    else:
+                        fold = _fold_layernorm(sw._packed, None, ln.weight.data, beta, dt)
         if fold is not None:
             if f16:
                 self._fold16, self._fold16_key = fold, key
             else:
                 self._fold, self._fold_key = fold, key
         return self._fold16 if f16 else self._fold
+
+    def stream_scale(self):
+        """precision 'half': (rho, 1 / rho) of the FFN LayerNorm (the scaling the pair stream carries into the up-projection)."""
+        if self._q4_up is not None:
+            raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
+        self._pack_fold(True)
+        return self._rho16
 
     def _weights_up(self, fold: bool, f16: bool = False):
         """(W, bias, c1, c2) of the FFN up-projection (gate/fc interleaved for SwiGLU)."""
@@ -488,7 +540,7 @@ class FlashTransformerLayer(nn.Module):
             return self._down_pad
         return down.weight, down.bias
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None):
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         f16 = x.dtype == torch.float16                       # precision 'half': the operand type travels with the tensors
         if x_stats is not None:
@@ -498,9 +550,10 @@ class FlashTransformerLayer(nn.Module):
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
         wd, bd = self._weights_down(f16)
-        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair)
+        return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair,
+                               pair_scale=pair_scale)
 
-    def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext):
+    def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext, next_scale=None):
         """One layer with the residual stream in fp32 (`ctx.x32`, updated in place).  `x16` = bf16(stream) is the MFMA
         operand of the LayerNorm-folded GEMMs.  The two residual GEMMs add their fp32 accumulators straight into the stream
         (`esme_gemm_fusion_t.resid32`: the branch output is never rounded to bf16 on the way), write the stream's bf16
@@ -513,10 +566,17 @@ class FlashTransformerLayer(nn.Module):
             ctx.part_b = torch.empty_like(ctx.part_a)
         # precision 'half': the stream is the float16 pair ctx.xs = [hi | lo] and x16 is its hi half (a view): the residual epilogues
         # read and write the pair in place -- no fp32 tensor, no separate operand copy
+        # The pair travels SCALED per column by rho of the LayerNorm whose folded GEMM reads it next (_fold_layernorm_pow2): it arrives
+        # scaled for this layer's attention LayerNorm, the out-projection hands it on scaled for the FFN LayerNorm, the down-projection
+        # for the next layer's attention LayerNorm (`next_scale` = its rho; None after the last layer: the final LayerNorm reads x itself).
         r32, rp = (None, ctx.xs) if ctx.f16 else (ctx.x32, None)
+        sa = sf = None
+        if ctx.f16:
+            (_, a_inv), (f_rho, f_inv) = self.self_attn.stream_scale(), self.stream_scale()
+            sa, sf = (a_inv, f_rho), (f_inv, next_scale)
         self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
-                       resid32=r32, resid_pair=rp)
-        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp)
+                       resid32=r32, resid_pair=rp, pair_scale=sa)
+        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf)
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):

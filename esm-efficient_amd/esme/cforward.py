@@ -58,6 +58,10 @@ class ModelDescriptor:
                 lw.lnq_w, lw.lnk_w = _ptr(att.layernorm_q.weight), _ptr(att.layernorm_k.weight)
                 lw.lnq_b, lw.lnk_b = _ptr(att.layernorm_q.bias), _ptr(att.layernorm_k.bias)
             self.keep += [wq, c1, c2, wo, bo, wu, u1, u2, wd, bd]
+            if f16:                                            # the pair stream's column scalings (attention._fold_layernorm_pow2)
+                (a_rho, a_inv), (f_rho, f_inv) = att.stream_scale(), layer.stream_scale()
+                lw.ps_attn, lw.ps_attn_inv, lw.ps_ffn, lw.ps_ffn_inv = _ptr(a_rho), _ptr(a_inv), _ptr(f_rho), _ptr(f_inv)
+                self.keep += [a_rho, a_inv, f_rho, f_inv]
         d = ModelDesc()
         d.struct_bytes = ctypes.sizeof(ModelDesc)
         d.n_layers, d.embed_dim, d.phys_dim = len(layers), model.embed_dim, model.phys_dim

@@ -281,14 +281,18 @@ class ESM2(nn.Module):
             # Padded layouts (ESM2-35M): everything at the physical width, pad columns zero as in the fast mode.
             ctx.xs = torch.empty(T, 2 * Ep, dtype=torch.float16, device=x.device)
             ctx.sums = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
-            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True)
+            # (stored scaled per column by rho of the first attention LayerNorm: attention._fold_layernorm_pow2)
+            scales = [layer.self_attn.stream_scale() for layer in self.layers]
+            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True, scale=scales[0][0])
             del x32
             x16 = ctx.xs[:, :Ep]
             ctx.order = _hip.seq_order(cu_lens)
+            last = len(self.layers) - 1
             for i, layer in enumerate(self.layers):
-                layer.forward_high_precision(x16, cu_lens, max_len, ctx)
+                layer.forward_high_precision(x16, cu_lens, max_len, ctx, next_scale=scales[i + 1][0] if i < last else None)
                 if i in layers:
-                    taps.append(_hip.pair_to_f32(ctx.xs))
+                    tap = _hip.pair_to_f32(ctx.xs)
+                    taps.append(tap * scales[i + 1][1] if i < last else tap)          # the raw layer output: undo the stream's column scaling
             ln = self.emb_layer_norm_after
             alloc = torch.zeros if self.padded else torch.empty
             pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)

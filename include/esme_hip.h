@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 7
+#define ESME_HIP_ABI_VERSION 8
 
 enum {
     ESME_OK = 0,
@@ -96,12 +96,17 @@ int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, int64_t ldo, 
 
 /* The MFMA operand of an fp32 residual stream: x16 = round(x32) -- bf16, or IEEE fp16 when f16 != 0 (precision 'half') --, when lo_off
  * != 0 also lo = round(x32 - x16) at column lo_off + e of the same row (the stream as a 16-bit PAIR, esme_gemm_fusion_t.pair_off), and, when
- * sums != NULL, per row {sum, sum of squares} of the ROUNDED values, float (1, T, 2) (pass as ln_partial, ln_nblk = 1).  Starts a
+ * sums != NULL, per row {sum, sum of squares} of the ROUNDED values (lo_off != 0: of the fp32 values), float (1, T, 2) (pass as ln_partial, ln_nblk = 1).  Starts a
  * forward whose stream does not begin as bf16 embedding rows (esme_hip_residual_f32 init) or whose operand type is fp16; afterwards the
  * residual GEMMs (esme_gemm_fusion_t.resid32) keep x16 and the statistics current.  No counterpart in the reference (its stream is
  * the activation dtype throughout, esme/attention.py:253-255). */
 int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
                             float* sums, int64_t T, int E, void* stream);
+/* The pair form (lo_off != 0) with the stream stored SCALED per column: [hi | lo] = split(scale[e] * x32[t, e]) (scale: float (E), 16-byte
+ * aligned, or NULL = 1; see esme_gemm_fusion_t.pair_scale_in / _out).  In the pair form `sums` describes the fp32 values x32 themselves
+ * (unscaled, unrounded), as the residual epilogues on the pair stream do afterwards. */
+int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
+                                   const float* scale, float* sums, int64_t T, int E, void* stream);
 
 /* out[t, e] = x[t, e] + x[t, lo_off + e] in fp32 for a 16-bit pair stream (bf16, or IEEE fp16 when f16 != 0): the raw layer outputs that
  * forward_representation(layers=[...]) (esme/esm.py:225-227,249-264) returns when the stream is a pair (precision 'half'). */
@@ -306,7 +311,7 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *              ESME_EPI_RESIDUAL with f16 needs resid32 OR pair_off != 0: the residual stream is then the fp16 pair
  *              x = hi + lo (22 significant bits), hi at resid[m, n], lo at resid[m, pair_off + n]; the epilogue forms
  *              x + alpha * (acc + bias) in fp32 and writes it back as a pair to C[m, n] / C[m, pair_off + n] (C may be resid: in place);
- *              hi is the next GEMM's fp16 operand (lda = the pair row stride), stats_out describes hi.  8 bytes per element in whole
+ *              hi is the next GEMM's fp16 operand (lda = the pair row stride), stats_out describes the fp32 value x (before the split).  8 bytes per element in whole
  *              128-byte lines instead of the fp32 stream's 10 in 64-byte pieces: the residual GEMMs' seam is where 'half' pays. */
 typedef struct esme_gemm_fusion {
     const float* ln_partial;
@@ -332,6 +337,14 @@ typedef struct esme_gemm_fusion {
     float* c32;                  /* != NULL: the result is written in fp32 to c32 (M, N), row stride ldc32, instead of C */
     int64_t ldc32;
     int f16;                     /* != 0: fp16 operands and output (precision 'half'), see above */
+    /* fp16 pair stream only (f16, pair_off, ESME_EPI_RESIDUAL): the stream is stored SCALED per column, stored[m, n] = rho[n] * x[m, n],
+     * so that the LayerNorm-folded GEMM that reads hi next can carry an EXACT fp16 weight: gamma = pow2(gamma) * rho with rho in
+     * [2^-1/2, 2^1/2]; the power of two goes into the weight (W * pow2(gamma) is exact in fp16, where fp16(W * gamma) costs a rounding of
+     * 2^-12 per weight -- a quarter of the mode's error), rho onto the stream.  The epilogue reads x = (hi + lo) * pair_scale_in[n]
+     * (= 1 / rho of the scaling the stream carries on entry), adds alpha * (acc + bias) and writes (x_new * pair_scale_out[n]) back as a
+     * pair (rho of the NEXT consumer).  float (N) each, 16-byte aligned; NULL = 1.  stats_out describes the UNSCALED fp32 x_new. */
+    const float* pair_scale_in;
+    const float* pair_scale_out;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
@@ -445,6 +458,11 @@ typedef struct esme_layer_weights {
     const void* up_w; const float* up_c1; const float* up_c2;
     const void* down_w; const void* down_b;               /* (phys_dim, ffn_dim), bias or NULL */
     const void* lnq_w; const void* lnk_w; const void* lnq_b; const void* lnk_b;   /* ESM-C q/k LayerNorm (qk_norm) */
+    /* esme_hip_forward_half only (esme_hip_forward ignores them): the per-column scalings of the pair stream, float (phys_dim), 16-byte
+     * aligned, all four or none (NULL = 1).  ps_attn = rho of the attention LayerNorm (gamma = pow2(gamma) * rho; qkv_w then carries
+     * W * pow2(gamma), exact in fp16, and qkv_c1 = sum_k gamma_k W[n, k] in fp32), ps_ffn = rho of the FFN LayerNorm (up_w likewise),
+     * *_inv their reciprocals (1 / rho in fp32).  See esme_gemm_fusion_t.pair_scale_in / _out. */
+    const float* ps_attn; const float* ps_attn_inv; const float* ps_ffn; const float* ps_ffn_inv;
 } esme_layer_weights_t;
 
 typedef struct esme_model_desc {
@@ -475,7 +493,9 @@ int esme_hip_forward(const esme_model_desc_t* model, void* x, int64_t ldx, const
 /* The layer stack in precision 'half' (see esme_gemm_fusion_t.f16) through ONE call: IEEE fp16 MFMA operands, the residual stream as an
  * fp16 pair updated in place by the residual GEMMs.  The descriptor is the same struct with the fp16 DERIVED copies: qkv_w / up_w =
  * fp16(W diag(gamma)) with c1 = ITS row sums, out_w / down_w = the bf16 weights converted to fp16 (exact), cos / sin fp16 tables; biases and
- * LayerNorm parameters stay bf16; attn_q_prescale is ignored (P must fit fp16).
+ * LayerNorm parameters stay bf16; attn_q_prescale is ignored (P must fit fp16).  With esme_layer_weights_t.ps_* set, qkv_w / up_w =
+ * fp16(W diag(pow2(gamma))) (exact) and the stream travels scaled by rho = gamma / pow2(gamma) of its next LayerNorm (the form the Python
+ * package builds: it removes the fp16 rounding of W * gamma, a quarter of the mode's error).
  *  x32:   fp32 (T, phys_dim), row stride ld32: the stream at the start (embedding rows; ESM-1b / 1v: token + learned-position sums);
  *  pair:  bf16 (T, 2 * phys_dim) = [hi | lo], row stride ld_pair: the final LayerNorm's output as the split-operand LM head reads it
  *         (pad columns, if any, are left as they are: pass zeros); rep32: the same in fp32 (T, phys_dim), row stride ld_rep, or NULL;

@@ -80,30 +80,42 @@ def test_gemm_f16_residual_on_the_fp32_stream(M, N, K, tile):
 
 @pytest.mark.parametrize('M,N,K', [(513, 320, 1280), (4099, 1280, 5120), (30000, 640, 640), (70000, 1280, 1280)])
 @pytest.mark.parametrize('tile', [1, 2])
-def test_gemm_f16_residual_on_the_pair_stream(M, N, K, tile):
+@pytest.mark.parametrize('scaled', [False, True])
+def test_gemm_f16_residual_on_the_pair_stream(M, N, K, tile, scaled):
     """The stream as a float16 pair [hi | lo] (x = hi + lo, 22 significant bits), updated in place: x + alpha * (a W^T + b) formed in
-    fp32 and written back as a pair (2^-23 relative), hi = the next operand, statistics of hi.  (70 000 x 1280: the persistent
-    256 x 256 workgroups, four 32-row passes per tile.)"""
+    fp32 and written back as a pair (2^-23 relative), hi = the next operand, statistics of the fp32 value x.  `scaled`: the stream is
+    stored as rho * x per column (rho_in on entry, rho_out on exit: the power-of-two LayerNorm fold of precision 'half'); the statistics
+    stay those of the unscaled x.  (70 000 x 1280: the persistent 256 x 256 workgroups, four 32-row passes per tile.)"""
     g = torch.Generator().manual_seed(N + 1)
     a = h16(torch.randn(M, K, generator=g))
     w = h16(torch.randn(N, K, generator=g) * K ** -0.5)
     b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
     x32 = torch.randn(M, N, generator=g) * 3
+    rho_in = (0.71 + 0.7 * torch.rand(N, generator=g)) if scaled else None
+    rho_out = (0.71 + 0.7 * torch.rand(N, generator=g)) if scaled else None
     xs = torch.empty(M, 2 * N, dtype=H16, device=DEV)
-    _hip.stream_operand(x32.to(DEV), xs, None, pair=True)
+    sums = torch.empty(1, M, 2, dtype=torch.float32, device=DEV)
+    _hip.stream_operand(x32.to(DEV), xs, sums, pair=True, scale=rho_in.to(DEV) if scaled else None)
     x_in = xs[:, :N].cpu().double() + xs[:, N:].cpu().double()
+    if scaled:
+        x_in = x_in / rho_in.double()
     assert rel(x_in, x32) <= 2e-7                         # the pair holds an fp32 value to 2^-23
+    s0 = sums[0].cpu().double()                           # statistics of the fp32 rows themselves
+    assert torch.allclose(s0[:, 0], x32.double().sum(dim=1), atol=2e-3, rtol=1e-5) and torch.allclose(s0[:, 1], (x32.double() ** 2).sum(dim=1), rtol=1e-5)
     ref = x_in + 0.7 * (a.double() @ w.double().T + b.double())
     with _hip.gemm_options(tile=tile):
         stats = torch.empty(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=DEV)
-        hi = _hip.gemm_fused(a.to(DEV), w.to(DEV), b.to(DEV), _hip.EPI_RESIDUAL, None, 0.7, stats_out=stats, resid_pair=xs)
+        ps = ((1.0 / rho_in).to(DEV), rho_out.to(DEV)) if scaled else None
+        hi = _hip.gemm_fused(a.to(DEV), w.to(DEV), b.to(DEV), _hip.EPI_RESIDUAL, None, 0.7, stats_out=stats, resid_pair=xs, pair_scale=ps)
     assert hi.data_ptr() == xs.data_ptr() and hi.shape == (M, N) and hi.dtype == H16
     got = xs[:, :N].cpu().double() + xs[:, N:].cpu().double()
-    assert rel(got, ref) <= 5e-7, rel(got, ref)           # (fp32 accumulation of K <= 5 120 products + the 2^-23 of the pair)
-    assert rel(hi.cpu(), ref) <= 3e-4                     # hi alone is the fp16 rounding
+    hi_x = hi.cpu().double()
+    if scaled:
+        got, hi_x = got / rho_out.double(), hi_x / rho_out.double()
+    assert rel(got, ref) <= 6e-7, rel(got, ref)           # (fp32 accumulation of K <= 5 120 products + the 2^-23 of the pair)
+    assert rel(hi_x, ref) <= 3e-4                         # hi alone is the fp16 rounding
     st = stats.sum(dim=0).cpu().double()
-    r = hi.cpu().double()
-    assert torch.allclose(st[:, 0], r.sum(dim=1), atol=5e-3, rtol=1e-5) and torch.allclose(st[:, 1], (r * r).sum(dim=1), rtol=1e-5)
+    assert torch.allclose(st[:, 0], ref.sum(dim=1), atol=5e-3, rtol=1e-5) and torch.allclose(st[:, 1], (ref * ref).sum(dim=1), rtol=1e-5)
 
 
 @pytest.mark.parametrize('d', [16, 32, 64])
