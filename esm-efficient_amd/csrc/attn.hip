@@ -347,8 +347,13 @@ struct AttnSplitArgs {
     int64_t lo_in, lo_out;
 };
 
-template <int D>
+// QKP (precision 'half' on a model whose attention scores are large, round 5): IEEE fp16 operands with ONLY q and k as pairs --
+//     S = Qh Kh^T + Qh Kl^T + Ql Kh^T   (scores to ~2^-21 of |q||k|: an fp16 q / k alone costs 2^-12 |q||k|, i.e. several tenths of a
+//     score unit once the projections of massive stream channels push |score| into the hundreds),   O = P V  single pass, fp16 P, V, O.
+template <int D, bool F16 = false, bool QKP = false>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs sa) {
+    static_assert(!QKP || F16, "q/k-only pairs: the fp16 form");
+    constexpr int NPT = QKP ? 1 : 2;                   // V (and P, O) parts
     const AttnArgs& a = sa.a;
     constexpr int DS = D / 16;
     constexpr int DB = (D + 31) / 32;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
     constexpr int VI = (16 * DQ + 255) / 256;
     constexpr int K_BYTES = KT * D * 2;
     constexpr int V_BYTES = D * 128;
-    constexpr int BUF = 2 * (K_BYTES + V_BYTES);       // [K hi | K lo | V^T hi | V^T lo]
+    constexpr int BUF = 2 * K_BYTES + NPT * V_BYTES;   // [K hi | K lo | V^T hi | V^T lo]  (QKP: one V^T)
     static_assert(D == 16 || D == 32 || D == 64, "split-operand attention: head dims 16, 32, 64");
 
     extern __shared__ __attribute__((aligned(16))) char smem_split[];
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
         v_kq[i] = ((lane >> 2) & 3) | ((rest >> DQ_HI_BITS) << 2);
     }
     u32x4 kreg[2][KI];
-    u32x2 vreg[2][VI][4];
+    u32x2 vreg[NPT][VI][4];
     auto load_tile = [&](int kv0) {
         const bool full = kv0 + KT <= S;
 #pragma unroll
@@ -419,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
                     kreg[pt][i] = *reinterpret_cast<const u32x4*>(kb + pt * sa.lo_in + (row * ld + koff[i]));
                 }
             }
+            if (pt >= NPT) continue;
 #pragma unroll
             for (int i = 0; i < VI; ++i) {
                 if (v_kq[i] < 16) {
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
                     *reinterpret_cast<u32x4*>(Ks + row * (D * 2) + ((ch ^ kswz<D>(row)) << 4)) = kreg[pt][i];
                 }
             }
+            if (pt >= NPT) continue;
 #pragma unroll
             for (int i = 0; i < VI; ++i) {
                 if (v_kq[i] < 16) {
@@ -503,9 +510,9 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
                     const bf16x8 kh = *reinterpret_cast<const bf16x8*>(rp + (((ds * 2 + hi) ^ sw) << 4));
                     ESME_LDS_CHECK(rp + K_BYTES + (((ds * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
                     const bf16x8 kl = *reinterpret_cast<const bf16x8*>(rp + K_BYTES + (((ds * 2 + hi) ^ sw) << 4));
-                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][ds], sacc[kbk], 0, 0, 0);      // small terms first
-                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[1][ds], sacc[kbk], 0, 0, 0);
-                    sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qf[0][ds], sacc[kbk], 0, 0, 0);
+                    sacc[kbk] = mfma_32x32x16<F16>(kl, qf[0][ds], sacc[kbk]);      // small terms first
+                    sacc[kbk] = mfma_32x32x16<F16>(kh, qf[1][ds], sacc[kbk]);
+                    sacc[kbk] = mfma_32x32x16<F16>(kh, qf[0][ds], sacc[kbk]);
                 }
             }
             if (kv0 + KT > S) {
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
             }
-            bf16x8 pf[2][2][2];                            // [hi / lo][key block][k-step]
+            bf16x8 pf[NPT][2][2];                          // [hi / lo][key block][k-step]
             float psum = 0.f;
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
@@ -544,12 +551,14 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
                         p[j] = __builtin_amdgcn_exp2f(fmaf(sacc[kbk][8 * s + j], c, -mc));
                         psum += p[j];
                     }
-                    const u32x4 pk = pack8(p);
-                    unpack8(pk, ph);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) p[j] -= ph[j];
+                    const u32x4 pk = pack8t<F16>(p);
                     pf[0][kbk][s] = __builtin_bit_cast(bf16x8, pk);
-                    pf[1][kbk][s] = __builtin_bit_cast(bf16x8, pack8(p));
+                    if constexpr (!QKP) {
+                        unpack8t<F16>(pk, ph);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) p[j] -= ph[j];
+                        pf[NPT - 1][kbk][s] = __builtin_bit_cast(bf16x8, pack8t<F16>(p));
+                    }
                 }
             l_run += psum;
 
@@ -565,11 +574,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const bf16x8 vh = *reinterpret_cast<const bf16x8*>(rp + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
-                        ESME_LDS_CHECK(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
-                        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
-                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pf[0][kbk][s], oacc[i], 0, 0, 0);
-                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[1][kbk][s], oacc[i], 0, 0, 0);
-                        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pf[0][kbk][s], oacc[i], 0, 0, 0);
+                        if constexpr (!QKP) {
+                            ESME_LDS_CHECK(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4), 16, smem, 2 * BUF);
+                            const bf16x8 vl = *reinterpret_cast<const bf16x8*>(rp + V_BYTES + (((kbk * 4 + s * 2 + hi) ^ sw) << 4));
+                            oacc[i] = mfma_32x32x16<F16>(vl, pf[0][kbk][s], oacc[i]);
+                            oacc[i] = mfma_32x32x16<F16>(vh, pf[NPT - 1][kbk][s], oacc[i]);
+                        }
+                        oacc[i] = mfma_32x32x16<F16>(vh, pf[0][kbk][s], oacc[i]);
                     }
             }
         }
@@ -594,10 +605,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
                     float o4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o4[e] = oacc[i][4 * g + e] * inv;
-                    const u32x2 pk = {pack_bf16(o4[0], o4[1]), pack_bf16(o4[2], o4[3])};
+                    const u32x2 pk = {pack16<F16>(o4[0], o4[1]), pack16<F16>(o4[2], o4[3])};
                     *reinterpret_cast<u32x2*>(op + d) = pk;
-                    const u32x2 pl = {pack_bf16(o4[0] - bf_lo(pk[0]), o4[1] - bf_hi(pk[0])), pack_bf16(o4[2] - bf_lo(pk[1]), o4[3] - bf_hi(pk[1]))};
-                    *reinterpret_cast<u32x2*>(op + sa.lo_out + d) = pl;
+                    if constexpr (!QKP) {
+                        const u32x2 pl = {pack16<F16>(o4[0] - lo16<F16>(pk[0]), o4[1] - hi16<F16>(pk[0])), pack16<F16>(o4[2] - lo16<F16>(pk[1]), o4[3] - hi16<F16>(pk[1]))};
+                        *reinterpret_cast<u32x2*>(op + sa.lo_out + d) = pl;
+                    }
                 }
             }
     }
@@ -1551,10 +1564,10 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     return check_launch("attn_varlen_fwd");
 }
 
-template <int D>
+template <int D, bool F16 = false, bool QKP = false>
 static int launch_split(const AttnSplitArgs& sa, const dim3 grid, hipStream_t s) {
-    constexpr int smem = 2 * 2 * (KT * D * 2 + D * 128);
-    auto kern = attn_split_kernel<D>;
+    constexpr int smem = 2 * (2 * KT * D * 2 + (QKP ? 1 : 2) * D * 128);
+    auto kern = attn_split_kernel<D, F16, QKP>;
     if (smem >= 64 * 1024) {
         static std::atomic<unsigned long long> done{0ull};
         int dev = 0;
@@ -1589,6 +1602,27 @@ extern "C" int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, cons
         case 32: return launch_split<32>(sa, grid, s);
         case 64: return launch_split<64>(sa, grid, s);
         default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn_split: head dim must be 16, 32 or 64");
+    }
+}
+
+extern "C" int esme_hip_attn_varlen_fwd_qkpair_f16(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qk, void* o,
+                                                   int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                                   int max_len, float softmax_scale, const int32_t* seq_order, void* stream) {
+    ESME_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && d > 0 && max_len >= 0, "attn_qkpair: bad sizes");
+    if (T == 0 || B == 0) return ESME_OK;
+    ESME_CHECK_ARG(q && k && v && o && cu_lens, "attn_qkpair: null pointer");
+    ESME_CHECK_ARG(ld_qkv % 8 == 0 && lo_qk % 8 == 0 && lo_qk > 0 && ld_o % 4 == 0 && ld_o >= (int64_t)H * d, "attn_qkpair: bad row strides / pair offset");
+    ESME_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(o) & 7u) == 0, "attn_qkpair: misaligned");
+    ESME_CHECK_ARG(max_len > 0 && H <= 65535 && B <= 65535, "attn_qkpair: max_len must be > 0, H and B <= 65535");
+    AttnSplitArgs sa{{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H, softmax_scale * 1.4426950408889634f, 1, H * B,
+                      0.0f, 0, seq_order}, lo_qk, 0};
+    const dim3 grid((unsigned int)((max_len + QT - 1) / QT), (unsigned int)H, (unsigned int)B);
+    const hipStream_t s = (hipStream_t)stream;
+    switch (d) {
+        case 16: return launch_split<16, true, true>(sa, grid, s);
+        case 32: return launch_split<32, true, true>(sa, grid, s);
+        case 64: return launch_split<64, true, true>(sa, grid, s);
+        default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn_qkpair: head dim must be 16, 32 or 64");
     }
 }
 

@@ -132,10 +132,11 @@ struct WsHalf { char* xs; char* qkv; char* attn; char* mid; float* sums; float* 
 int64_t carve_half(const esme_model_desc_t* m, int64_t T, WsHalf* w, char* base) {
     const int64_t Ea = (int64_t)m->heads * m->head_pad, Ep = m->phys_dim;
     const int64_t nblk = esme_hip_gemm_stats_blocks(T, (int)Ep);
+    const int64_t ext = m->half_ext_n > 0 ? 64 : 0;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += align256(bytes); return base ? base + o : (char*)nullptr; };
-    char* xs = take(T * 2 * Ep * 2);
-    char* qkv = take(T * 3 * Ea * 2);
+    char* xs = take(T * (2 * Ep + ext) * 2);
+    char* qkv = take(T * (3 + (m->half_qk_pair ? 2 : 0)) * Ea * 2);        // [q k v | q_lo k_lo] when q / k travel as pairs
     char* attn = take(T * Ea * 2);
     char* mid = take(T * (int64_t)m->ffn_dim * 2);
     char* sums = take(T * 2 * 4);
@@ -162,6 +163,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
     ESME_CHECK_ARG(x32 && cu_lens && workspace && pair && m->layers && m->n_layers > 0, "forward_half: null pointer");
     ESME_CHECK_ARG(m->phys_dim % 64 == 0 && m->embed_dim > 0 && m->embed_dim <= m->phys_dim && ld32 >= m->phys_dim && ld_pair >= 2 * (int64_t)m->phys_dim,
                    "forward_half: the physical width must be a multiple of 64, ld_pair >= 2 * phys_dim");
+    ESME_CHECK_ARG(m->half_ext_n >= 0 && m->half_ext_n <= 64 && (m->half_ext_n == 0 || m->half_ext_sel), "forward_half: half_ext_n in [0, 64] with its channel list");
     ESME_CHECK_ARG(ws_bytes >= carve_half(m, T, nullptr, nullptr) && aligned16(workspace), "forward_half: workspace too small or misaligned");
     ESME_CHECK_ARG(!m->rotary || (m->cos && m->sin && pos), "forward_half: rotary models need cos, sin and pos");
     WsHalf w;
@@ -170,6 +172,17 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
     const int64_t Ea = (int64_t)H * dp;
     const int nblk = esme_hip_gemm_stats_blocks(T, Ep);
     const bool rot_fused = m->rotary && !m->qk_norm && (dp == 16 || dp == 32 || dp == 64) && Ea % 32 == 0;
+    const bool qk_pair = m->half_qk_pair != 0;
+    if (qk_pair && (m->qk_norm || !(dp == 16 || dp == 32 || dp == 64) || Ea % 128 != 0))
+        ESME_FAIL(ESME_ERR_UNSUPPORTED, "forward_half: q/k pairs cover blocks without q/k LayerNorm, head dim 16 / 32 / 64, heads * head_pad a multiple of 128");
+    // massive stream channels: the pair rows carry the extension K-tile [hi | ext | lo]; the LayerNorm-folded GEMMs read [hi | ext]
+    const int ext = m->half_ext_n > 0 ? 64 : 0;
+    const int64_t ldxs = 2 * (int64_t)Ep + ext, lo_off = (int64_t)Ep + ext;
+    const int Kf = Ep + ext;
+    auto stream_fields = [&](esme_gemm_fusion_t& f) {
+        f.f16 = 1; f.pair_off = lo_off;
+        if (ext) { f.ext_sel = m->half_ext_sel; f.ext_n = m->half_ext_n; f.ext_off = Ep; }
+    };
     int rc;
 #define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
     esme_attn_opts_t aopts{(int)sizeof(esme_attn_opts_t), 0, 0, 8.0f, 1, nullptr, 0, 1};
@@ -178,7 +191,8 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         aopts.seq_order = w.order;
     }
     // the stream as an fp16 pair [hi | lo] (scaled per column for the first LayerNorm-folded GEMM) + the statistics of the fp32 rows
-    ESME_TRY(esme_hip_stream_operand_scaled(x32, ld32, w.xs, 2 * (int64_t)Ep, Ep, 1, m->layers[0].ps_attn, w.sums, T, Ep, stream));
+    ESME_TRY(esme_hip_stream_operand_scaled(x32, ld32, w.xs, ldxs, lo_off, 1, m->layers[0].ps_attn, ext ? m->half_ext_sel : nullptr, m->half_ext_n,
+                                            ext ? Ep : 0, w.sums, T, Ep, stream));
     const float* stats = w.sums;
     int stats_nblk = 1;
     for (int i = 0; i < m->n_layers; ++i) {
@@ -186,35 +200,43 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         esme_gemm_fusion_t fu{};
         fu.f16 = 1;
         fu.ln_partial = stats; fu.ln_nblk = stats_nblk; fu.ln_dim = E; fu.ln_eps = m->ln_eps; fu.ln_c1 = L.qkv_c1; fu.ln_c2 = L.qkv_c2;
-        if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
-        ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, 2 * (int64_t)Ep, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Ep, ESME_EPI_NONE, 1.0f, &fu, stream));
         char* q = w.qkv; char* k = w.qkv + Ea * 2; char* v = w.qkv + 2 * Ea * 2;
-        if (m->qk_norm) {
-            ESME_TRY(esme_hip_qk_norm_rotary_f16(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
-        } else if (m->rotary && !rot_fused) {
-            ESME_TRY(esme_hip_rotary_varlen_f16(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+        if (qk_pair) {
+            // large attention scores: q / k as fp16 pairs [q k v | q_lo k_lo], rotated with fp32 tables, scores from three MFMA passes
+            fu.pair_off = 3 * Ea; fu.pair_cols = (int)(2 * Ea);
+            ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 5 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
+            if (m->rotary)
+                ESME_TRY(esme_hip_rotary_split_f16(w.qkv, 5 * Ea, 3 * Ea, (const float*)m->cos, (const float*)m->sin, pos, T, 2 * H, dp, m->table_len, stream));
+            ESME_TRY(esme_hip_attn_varlen_fwd_qkpair_f16(q, k, v, 5 * Ea, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, aopts.seq_order, stream));
+        } else {
+            if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
+            ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
+            if (m->qk_norm) {
+                ESME_TRY(esme_hip_qk_norm_rotary_f16(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+            } else if (m->rotary && !rot_fused) {
+                ESME_TRY(esme_hip_rotary_varlen_f16(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+            }
+            ESME_TRY(esme_hip_attn_varlen_fwd_opts(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, &aopts, stream));
         }
-        ESME_TRY(esme_hip_attn_varlen_fwd_opts(q, k, v, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, &aopts, stream));
         esme_gemm_fusion_t fo{};
-        fo.f16 = 1; fo.pair_off = Ep; fo.stats_out = w.part_b;
+        stream_fields(fo); fo.stats_out = w.part_b;
         fo.pair_scale_in = L.ps_attn_inv; fo.pair_scale_out = L.ps_ffn;               // the stream arrives scaled for this layer's attention LayerNorm, leaves scaled for its FFN LayerNorm
-        ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, 2 * (int64_t)Ep, w.xs, 2 * (int64_t)Ep, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, ldxs, w.xs, ldxs, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
         esme_gemm_fusion_t fup{};
         fup.f16 = 1;
         fup.ln_partial = w.part_b; fup.ln_nblk = nblk; fup.ln_dim = E; fup.ln_eps = m->ln_eps; fup.ln_c1 = L.up_c1; fup.ln_c2 = L.up_c2;
         const int up_rows = m->swiglu ? 2 * m->ffn_dim : m->ffn_dim;
-        ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, 2 * (int64_t)Ep, L.up_w, nullptr, nullptr, 0, w.mid, m->ffn_dim, T, up_rows, Ep,
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.up_w, nullptr, nullptr, 0, w.mid, m->ffn_dim, T, up_rows, Kf,
                                           m->swiglu ? ESME_EPI_SWIGLU : ESME_EPI_GELU, 1.0f, &fup, stream));
         esme_gemm_fusion_t fd{};
-        fd.f16 = 1; fd.pair_off = Ep; fd.stats_out = w.part_a;
+        stream_fields(fd); fd.stats_out = w.part_a;
         fd.pair_scale_in = L.ps_ffn_inv; fd.pair_scale_out = i + 1 < m->n_layers ? m->layers[i + 1].ps_attn : nullptr;    // (the final LayerNorm reads the stream unscaled)
-        ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, w.xs, 2 * (int64_t)Ep, w.xs, 2 * (int64_t)Ep, T, Ep, m->ffn_dim,
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, w.xs, ldxs, w.xs, ldxs, T, Ep, m->ffn_dim,
                                           ESME_EPI_RESIDUAL, m->alpha, &fd, stream));
         stats = w.part_a; stats_nblk = nblk;
     }
     // final LayerNorm over the logical width, from the fp16 pair, written as the bf16 pair the split-operand LM head reads (+ fp32)
-    ESME_TRY(esme_hip_layernorm_split(w.xs, 2 * (int64_t)Ep, 2, Ep, m->final_ln_w, m->final_ln_b, pair, ld_pair, Ep, rep32, ld_rep, T, E, m->ln_eps, stream));
+    ESME_TRY(esme_hip_layernorm_split(w.xs, ldxs, 2, lo_off, m->final_ln_w, m->final_ln_b, pair, ld_pair, Ep, rep32, ld_rep, T, E, m->ln_eps, stream));
 #undef ESME_TRY
     return ESME_OK;
 }
-

@@ -42,6 +42,8 @@ struct GemmArgs {
     int kt_wrap = 0; int64_t pair_off = 0; float* c32 = nullptr; int64_t ldc32 = 0;
     int f16 = 0;                 // precision 'half': A, W, rotary tables and C are IEEE fp16 (esme_gemm_fusion_t.f16)
     const float* ps_in = nullptr; const float* ps_out = nullptr;   // pair stream stored scaled per column (esme_gemm_fusion_t.pair_scale_in / _out); nullptr = 1
+    const int32_t* ext_sel = nullptr; int ext_n = 0; int64_t ext_off = 0;     // pair stream: lo of the selected columns also goes to C[m, ext_off + slot] (the extension K-tile)
+    int pair_cols = 0;           // PAIR output: only columns < pair_cols get their lo half (0 = all)
     int stream_out = 0;          // host side: the results are larger than the memory-side cache -> stored with the non-temporal hint (common.h store_stream)
 };
 

@@ -49,10 +49,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     static_assert(!RP || (F16 && EPI == ESME_EPI_RESIDUAL && !R32 && !PAIR && !LNF && ROTD == 0), "pair stream: fp16 residual epilogue");
     // F16 (precision 'half'): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (bias stays bf16, a checkpoint parameter); what
     // changes is the MFMA opcode, the table unpack and the output rounding -- the LDS image, the DMA path and the schedule do not.
-    static_assert(!F16 || (!PAIR && (EPI != ESME_EPI_RESIDUAL || R32 || RP)), "fp16 operands: plain / GELU / SwiGLU epilogues and the fp32- / pair-stream residual epilogues");
+    static_assert(!F16 || ((!PAIR || (LNF && EPI == ESME_EPI_NONE && ROTD == 0)) && (EPI != ESME_EPI_RESIDUAL || R32 || RP)),
+                  "fp16 operands: plain / GELU / SwiGLU epilogues, the fp32- / pair-stream residual epilogues, pair output of the LN-folded plain epilogue");
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
     static_assert(!R32 || EPI == ESME_EPI_RESIDUAL, "the fp32 residual stream belongs to the residual epilogue");
-    static_assert(!PAIR || (EPI != ESME_EPI_RESIDUAL && !LNF && !STATS && !PERSIST), "(hi, lo) pair output: plain / GELU / SwiGLU epilogues of the split-operand mode");
+    static_assert(!PAIR || (EPI != ESME_EPI_RESIDUAL && (!LNF || F16) && !STATS && !PERSIST), "(hi, lo) pair output: plain / GELU / SwiGLU epilogues of the split-operand mode; fp16: the LN-folded plain epilogue");
     static_assert(!STATS || (EPI == ESME_EPI_RESIDUAL && WTN_OK(BN, WN) && BN / WN == 64 && (WN == 2 || WN == 4)), "row statistics are emitted by the residual epilogue");
     static_assert(ROTD == 0 || (EPI == ESME_EPI_NONE && (ROTD == 16 || ROTD == 32 || ROTD == 64) && WTN_OK(BN, WN)),
                   "fused rotary: plain epilogue, head dim 16/32/64, 64-column wave tiles");
@@ -785,6 +786,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            // extension K-tile: the lo half of the (few) selected columns is stored a second time, side by side at C[m, ext_off + slot],
+            // where the next LayerNorm-folded GEMM finds it as one more K-tile (A = [hi | lo_sel], W = [W' | W'_sel]: those channels then
+            // enter the product at the pair's 22 bits).  Wave-uniform loop over the list; a wave whose 64 columns hold none skips it.
+            for (int sidx = 0; sidx < a.ext_n; ++sidx) {
+                const int c = a.ext_sel[sidx] - nw0;
+                if (c >= 0 && c < OUTC && lane < RPP) {
+                    const int64_t m = mw0 + pass * RPP + lane;
+                    const u16 lo = *reinterpret_cast<const u16*>(slab_lo + slab_off(lane, c & ~3) + (c & 3) * 2);
+                    if (m < a.M) a.C[m * a.ldc + a.ext_off + sidx] = lo;
+                }
+            }
             if constexpr (PERSIST) {                          // (after HALF the accumulators are dead: the registers the address set-up needs)
                 if (pass == NPASS / 2 - 1) {
                     __syncthreads();
@@ -893,8 +905,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 }
                 u32x2 pk = {pack16<F16>(o[0], o[1]), pack16<F16>(o[2], o[3])};
                 if (PAIR && half == 0) {
-                    acc[i][j][0] = o[0] - bf_lo(pk[0]); acc[i][j][1] = o[1] - bf_hi(pk[0]);
-                    acc[i][j][2] = o[2] - bf_lo(pk[1]); acc[i][j][3] = o[3] - bf_hi(pk[1]);
+                    acc[i][j][0] = o[0] - lo16<F16>(pk[0]); acc[i][j][1] = o[1] - hi16<F16>(pk[0]);
+                    acc[i][j][2] = o[2] - lo16<F16>(pk[1]); acc[i][j][3] = o[3] - hi16<F16>(pk[1]);
                 }
                 ESME_LDS_CHECK(slab + slab_off(r, cl), 8, smem, 2 * STAGE);
                 *reinterpret_cast<u32x2*>(slab + slab_off(r, cl)) = pk;
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         }
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
-        const bool col_ok = n < n_out;                    // n_out % 8 == 0 on this path
+        const bool col_ok = n < n_out && !(PAIR && half == 1 && a.pair_cols > 0 && en0 >= a.pair_cols);   // n_out % 8 == 0 on this path; (block-uniform) tiles right of pair_cols write no lo half
         if (col_ok || STATS) {
 #pragma unroll
             for (int it = 0; it < RPP / RPI; ++it) {
@@ -1117,6 +1129,8 @@ static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hip
         }
 #undef ESME_LP
     }
+    if (a.f16 && a.pair_off && epi == ESME_EPI_NONE)     // precision 'half', q / k as pairs: the LN-folded projection writes (hi, lo) (checked by the caller)
+        return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 0, true, false, false, false, true, true>(a, s);
     if (a.f16) {                                    // precision 'half': fp16 operands (checked by the caller: residual epilogue only on the fp32 stream)
 #define ESME_LH(E, R, L, S, R32) launch_one<BM, BN, WM, WN, E, R, L, S, false, R32, false, true>(a, s)
         switch (epi) {
@@ -1236,9 +1250,16 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     int rotd = 0;
     bool lnf = false, stats = false;
     if (r32) { a.resid32 = fu->resid32; a.ld32 = fu->ld32; }
-    ESME_CHECK_ARG(!fu || (!fu->pair_scale_in && !fu->pair_scale_out) || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_RESIDUAL),
-                   "gemm: pair_scale_in / pair_scale_out belong to the fp16 pair stream's residual epilogue");
-    if (fu && fu->f16 && fu->pair_off) {                             // precision 'half': the residual stream as an fp16 pair [hi | lo]
+    ESME_CHECK_ARG(!fu || (!fu->pair_scale_in && !fu->pair_scale_out && !fu->ext_off) || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_RESIDUAL),
+                   "gemm: pair_scale_in / pair_scale_out / ext_* belong to the fp16 pair stream's residual epilogue");
+    ESME_CHECK_ARG(!fu || !fu->pair_cols || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_NONE), "gemm: pair_cols belongs to the fp16 pair output");
+    if (fu && fu->f16 && fu->pair_off && epilogue == ESME_EPI_NONE) {   // precision 'half', q / k as pairs: pair output of the LN-folded plain projection
+        ESME_CHECK_ARG(fu->ln_partial && !fu->head_dim && !r32 && !fu->w_k && !fu->c32 && !fu->stats_out, "gemm: the fp16 pair output belongs to the LN-folded plain epilogue (no fused rotary)");
+        ESME_CHECK_ARG(fu->pair_off >= N && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + (fu->pair_cols > 0 ? fu->pair_cols : N) && fu->pair_cols >= 0 && fu->pair_cols % 256 == 0,
+                       "gemm: pair_off must be a multiple of 8 with N <= pair_off and room for the lo columns; pair_cols a multiple of 256");
+        if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: pair output needs a 16-byte addressable C and N % 8 == 0");
+        a.pair_off = fu->pair_off; a.pair_cols = fu->pair_cols;
+    } else if (fu && fu->f16 && fu->pair_off) {                      // precision 'half': the residual stream as an fp16 pair [hi | lo]
         ESME_CHECK_ARG(epilogue == ESME_EPI_RESIDUAL && !r32 && !fu->w_k && !fu->c32 && !fu->ln_partial, "gemm: the fp16 pair stream belongs to the residual epilogue");
         ESME_CHECK_ARG(fu->pair_off >= N && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + N && ldr >= fu->pair_off + N,
                        "gemm: pair_off must be a multiple of 8 with N <= pair_off <= ldc - N, ldr - N");
@@ -1247,6 +1268,11 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
         ESME_CHECK_ARG((!fu->pair_scale_in || aligned16(fu->pair_scale_in)) && (!fu->pair_scale_out || aligned16(fu->pair_scale_out)) && (N % 4 == 0),
                        "gemm: pair_scale_in / pair_scale_out must be 16-byte aligned float (N) vectors");
         a.ps_in = fu->pair_scale_in; a.ps_out = fu->pair_scale_out;
+        if (fu->ext_off) {
+            ESME_CHECK_ARG(fu->ext_off >= N && fu->ext_off + 64 <= fu->pair_off && fu->ext_n >= 0 && fu->ext_n <= 64 && (fu->ext_n == 0 || fu->ext_sel),
+                           "gemm: the extension tile is 64 columns between hi and lo (N <= ext_off, ext_off + 64 <= pair_off) with <= 64 selected columns");
+            a.ext_sel = fu->ext_sel; a.ext_n = fu->ext_n; a.ext_off = fu->ext_off;
+        }
     } else if (fu && (fu->w_k || fu->pair_off || fu->c32)) {        // split-operand ('exact') mode
         if (fu->w_k) {
             ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && K % fu->w_k == 0, "gemm: w_k (the K of W) must be a multiple of 64 that divides K");
@@ -1265,7 +1291,7 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
         }
     }
     if (fu && fu->f16) {                                             // precision 'half': fp16 A, W, tables, C
-        ESME_CHECK_ARG(!fu->w_k && !fu->c32 && (!fu->pair_off || epilogue == ESME_EPI_RESIDUAL), "gemm: fp16 operands do not combine with the split-operand fields");
+        ESME_CHECK_ARG(!fu->w_k && !fu->c32 && (!fu->pair_off || epilogue == ESME_EPI_RESIDUAL || epilogue == ESME_EPI_NONE), "gemm: fp16 operands do not combine with the split-operand fields");
         ESME_CHECK_ARG(epilogue != ESME_EPI_RESIDUAL || r32 || fu->pair_off, "gemm: fp16 operands run the residual epilogue on the fp32 stream or the fp16 pair stream");
         if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: fp16 operands need a 16-byte addressable C and N % 8 == 0");
         a.f16 = 1;

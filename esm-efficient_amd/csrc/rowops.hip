@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256) void rotary_kernel(u16* __restrict__ q, u16* _
 // `nheads` consecutive heads of width d (the q and k blocks of the projection's pair output): x = hi + lo in fp32,
 // x[j] <- x[j] cos - x[j + d/2] sin, x[j + d/2] <- x[j + d/2] cos + x[j] sin, written back as a pair.  One lane per 8-wide chunk
 // pair (j, j + d/2); HBM-bound: 16 B per element (hi and lo, read and written).
+template <bool F16>
 __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, int64_t ld, int64_t lo_off,
                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                            const int32_t* __restrict__ pos, int64_t T, int nheads, int d, int max_len) {
@@ -400,10 +401,10 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
         p = p < max_len ? p : max_len - 1;
         u16* xp = x + t * ld + h * d + c * 8;
         float lh[8], ll[8], uh[8], ul[8], cs[8], sn[8];
-        unpack8(*reinterpret_cast<const u32x4*>(xp), lh);
-        unpack8(*reinterpret_cast<const u32x4*>(xp + lo_off), ll);
-        unpack8(*reinterpret_cast<const u32x4*>(xp + (d >> 1)), uh);
-        unpack8(*reinterpret_cast<const u32x4*>(xp + (d >> 1) + lo_off), ul);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp), lh);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp + lo_off), ll);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp + (d >> 1)), uh);
+        unpack8t<F16>(*reinterpret_cast<const u32x4*>(xp + (d >> 1) + lo_off), ul);
         const float* cp = cosT + (int64_t)p * d + c * 8;
         const float* sp = sinT + (int64_t)p * d + c * 8;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
@@ -417,15 +418,15 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
             olo[j] = fmaf(lo, cs[j], -__fmul_rn(up, sn[j]));
             oup[j] = fmaf(up, cs[j], __fmul_rn(lo, sn[j]));
         }
-        const u32x4 plo = pack8(olo), pup = pack8(oup);
-        unpack8(plo, rl);
-        unpack8(pup, ru);
+        const u32x4 plo = pack8t<F16>(olo), pup = pack8t<F16>(oup);
+        unpack8t<F16>(plo, rl);
+        unpack8t<F16>(pup, ru);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { rl[j] = olo[j] - rl[j]; ru[j] = oup[j] - ru[j]; }
         *reinterpret_cast<u32x4*>(xp) = plo;
-        *reinterpret_cast<u32x4*>(xp + lo_off) = pack8(rl);
+        *reinterpret_cast<u32x4*>(xp + lo_off) = pack8t<F16>(rl);
         *reinterpret_cast<u32x4*>(xp + (d >> 1)) = pup;
-        *reinterpret_cast<u32x4*>(xp + (d >> 1) + lo_off) = pack8(ru);
+        *reinterpret_cast<u32x4*>(xp + (d >> 1) + lo_off) = pack8t<F16>(ru);
     }
 }
 
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(256) void rotary_split_kernel(u16* __restrict__ x, 
 template <int NCH, bool F16>
 __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __restrict__ x32, int64_t ld32, u16* __restrict__ x16,
                                                              int64_t ld16, int64_t lo_off, const float* __restrict__ scale,
+                                                             const int32_t* __restrict__ ext_sel, int ext_n, int64_t ext_off,
                                                              f32x2* __restrict__ sums, int64_t T, int E) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -472,6 +474,15 @@ __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __rest
                 for (int j = 0; j < 8; ++j) { s1 += r[j]; s2 = fmaf(r[j], r[j], s2); }
             }
         }
+    }
+    if (ext_off) {                                         // extension K-tile of the pair stream: lo of the selected channels, zeros behind them
+        u16 val = 0;
+        if (lane < ext_n) {
+            const int c = ext_sel[lane];
+            const float v = scale ? __fmul_rn(xr[c], scale[c]) : xr[c];
+            val = f2h<F16>(v - h2f<F16>(f2h<F16>(v)));
+        }
+        yr[ext_off + lane] = val;
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0 && sums) sums[row] = f32x2{s1, s2};
@@ -803,7 +814,7 @@ extern "C" int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, in
 }
 
 extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, const float* scale,
-                                              float* sums, int64_t T, int E, void* stream) {
+                                              const int32_t* ext_sel, int ext_n, int64_t ext_off, float* sums, int64_t T, int E, void* stream) {
     ESME_CHECK_ARG(T >= 0 && E > 0, "stream_operand: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(x32 && x16, "stream_operand: null pointer");
@@ -811,10 +822,12 @@ extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, vo
     ESME_CHECK_ARG(lo_off == 0 || (lo_off >= E && lo_off % 8 == 0 && ld16 >= lo_off + E), "stream_operand: lo_off must be a multiple of 8 with E <= lo_off <= ld16 - E");
     ESME_CHECK_ARG(aligned16(x32) && aligned16(x16) && (!sums || (reinterpret_cast<uintptr_t>(sums) & 7u) == 0), "stream_operand: misaligned");
     ESME_CHECK_ARG(!scale || (lo_off != 0 && aligned16(scale)), "stream_operand: a column scale belongs to the pair form (lo_off != 0) and must be 16-byte aligned");
+    ESME_CHECK_ARG(ext_off == 0 || (lo_off != 0 && ext_off >= E && ext_off + 64 <= lo_off && ext_n >= 0 && ext_n <= 64 && (ext_n == 0 || ext_sel)),
+                   "stream_operand: the extension tile is 64 columns between hi and lo (E <= ext_off, ext_off + 64 <= lo_off) with <= 64 selected channels");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, (f32x2*)sums, T, E); \
-                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, (f32x2*)sums, T, E); } while (0)
+#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, ext_sel, ext_n, ext_off, (f32x2*)sums, T, E); \
+                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, ext_sel, ext_n, ext_off, (f32x2*)sums, T, E); } while (0)
     if (E <= 512) ESME_SO(1);
     else if (E <= 1024) ESME_SO(2);
     else if (E <= 1536) ESME_SO(3);
@@ -827,7 +840,7 @@ extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, vo
 
 extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, float* sums,
                                        int64_t T, int E, void* stream) {
-    return esme_hip_stream_operand_scaled(x32, ld32, x16, ld16, lo_off, f16, nullptr, sums, T, E, stream);
+    return esme_hip_stream_operand_scaled(x32, ld32, x16, ld16, lo_off, f16, nullptr, nullptr, 0, 0, sums, T, E, stream);
 }
 
 extern "C" int esme_hip_pair_to_f32(const void* x, int64_t ld, int64_t lo_off, int f16, float* out, int64_t ld32, int64_t T, int E, void* stream) {
@@ -888,7 +901,7 @@ extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair,
     return check_launch("layernorm_split");
 }
 
-extern "C" int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const float* cosT, const float* sinT, const int32_t* pos,
+static int rotary_split_impl(const bool f16, void* x, int64_t ld, int64_t lo_off, const float* cosT, const float* sinT, const int32_t* pos,
                                      int64_t T, int nheads, int d, int max_len, void* stream) {
     ESME_CHECK_ARG(T >= 0 && nheads > 0 && d > 0 && max_len > 0, "rotary_split: bad sizes");
     if (T == 0) return ESME_OK;
@@ -897,9 +910,20 @@ extern "C" int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const 
     ESME_CHECK_ARG(ld % 8 == 0 && lo_off % 8 == 0 && lo_off >= (int64_t)nheads * d && ld >= lo_off + (int64_t)nheads * d, "rotary_split: bad row stride / pair offset");
     ESME_CHECK_ARG(aligned16(x) && aligned16(cosT) && aligned16(sinT), "rotary_split: misaligned");
     const int64_t items = T * nheads * (d / 16);
-    hipLaunchKernelGGL(rotary_split_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)x, ld, lo_off, cosT, sinT, pos,
+    if (f16) hipLaunchKernelGGL(rotary_split_kernel<true>, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)x, ld, lo_off, cosT, sinT, pos,
+                       T, nheads, d, max_len);
+    else hipLaunchKernelGGL(rotary_split_kernel<false>, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (u16*)x, ld, lo_off, cosT, sinT, pos,
                        T, nheads, d, max_len);
     return check_launch("rotary_split");
+}
+
+extern "C" int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const float* cosT, const float* sinT, const int32_t* pos,
+                                     int64_t T, int nheads, int d, int max_len, void* stream) {
+    return rotary_split_impl(false, x, ld, lo_off, cosT, sinT, pos, T, nheads, d, max_len, stream);
+}
+extern "C" int esme_hip_rotary_split_f16(void* x, int64_t ld, int64_t lo_off, const float* cosT, const float* sinT, const int32_t* pos,
+                                         int64_t T, int nheads, int d, int max_len, void* stream) {
+    return rotary_split_impl(true, x, ld, lo_off, cosT, sinT, pos, T, nheads, d, max_len, stream);
 }
 
 extern "C" int esme_hip_softmax_rows_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t T, int V, int log_flag, void* stream) {

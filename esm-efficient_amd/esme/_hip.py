@@ -28,7 +28,8 @@ class GemmFusion(Structure):
                 ('cos', c_void_p), ('sin', c_void_p), ('pos', c_void_p),
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int),
                 ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64), ('f16', c_int),
-                ('pair_scale_in', c_void_p), ('pair_scale_out', c_void_p)]
+                ('pair_scale_in', c_void_p), ('pair_scale_out', c_void_p),
+                ('ext_sel', c_void_p), ('ext_n', c_int), ('ext_off', c_int64), ('pair_cols', c_int)]
 
 
 class GemmOpts(Structure):
@@ -56,7 +57,8 @@ class ModelDesc(Structure):
                 + [('ln_eps', c_float), ('alpha', c_float), ('softmax_scale', c_float), ('attn_q_prescale', c_int),
                    ('layers', POINTER(LayerWeights))]
                 + [(n, c_void_p) for n in ('final_ln_w', 'final_ln_b', 'head_dense_w', 'head_dense_b', 'head_ln_w',
-                                           'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')])
+                                           'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')]
+                + [('half_ext_n', c_int), ('half_ext_sel', c_void_p), ('half_qk_pair', c_int)])
 
 
 # name -> (restype, argtypes); must list every symbol include/esme_hip.h declares
@@ -88,7 +90,11 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_pair_to_f32': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
-    'esme_hip_stream_operand_scaled': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_stream_operand_scaled': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int,
+                                               c_void_p]),
+    'esme_hip_rotary_split_f16': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_attn_varlen_fwd_qkpair_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int,
+                                                    c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_void_p]),
     'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
@@ -521,11 +527,13 @@ def residual_f32_(x32: torch.Tensor, o: torch.Tensor, alpha: float, x16: torch.T
 
 
 def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor], pair: bool = False,
-                   scale: Optional[torch.Tensor] = None) -> None:
+                   scale: Optional[torch.Tensor] = None, ext_sel: Optional[torch.Tensor] = None) -> None:
     """x16 <- round(x32) in x16's dtype (bfloat16, or float16 for precision 'half'); sums (1, T, 2) <- row {sum, sum sq} of the ROUNDED
     values: the operand and the statistics the LayerNorm-folded GEMMs read at the start of a forward on an fp32 stream.  `pair`: x16 is
     (T, W >= 2E) = [hi | ... | lo] (lo in the last E columns) with lo = round(v - hi), v = scale * x32 (`scale`: float32 (E) or None = 1):
-    the stream itself as a 16-bit pair (gemm_fused(resid_pair=, pair_scale=)); `sums` then describes the fp32 values x32 themselves."""
+    the stream itself as a 16-bit pair (gemm_fused(resid_pair=, pair_scale=)); `sums` then describes the fp32 values x32 themselves.
+    `ext_sel` (int32, <= 64 ascending column indices; the pair must be (T, 2E + 64) = [hi | ext | lo]): the extension K-tile receives lo of
+    those columns, zeros behind them (esme_gemm_fusion_t.ext_sel)."""
     if x16.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError('stream_operand: x16 must be bfloat16 or float16')
     xp, ld32 = _rows2d(x32, 'stream_operand x32', torch.float32)
@@ -535,9 +543,13 @@ def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Te
         raise ValueError('stream_operand: shape mismatch')
     if scale is not None and (not pair or scale.numel() != E):
         raise ValueError('stream_operand: `scale` is a float32 (E) vector of the pair form')
+    if ext_sel is not None and (not pair or x16.shape[1] != 2 * E + 64 or ext_sel.numel() > 64):
+        raise ValueError('stream_operand: `ext_sel` needs the (T, 2E + 64) pair layout and at most 64 columns')
     with _Traced('stream_operand', (T, E)):
         _check(load().esme_hip_stream_operand_scaled(xp, ld32, yp, ld16, x16.shape[1] - E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
                                                      _dev(scale, 'stream scale', torch.float32) if scale is not None else None,
+                                                     _dev(ext_sel, 'ext_sel', torch.int32) if ext_sel is not None else None,
+                                                     ext_sel.numel() if ext_sel is not None else 0, E if ext_sel is not None else 0,
                                                      _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
                'esme_hip_stream_operand_scaled')
 
@@ -602,10 +614,12 @@ def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 def rotary_split_(x: torch.Tensor, lo_off: int, cos32: torch.Tensor, sin32: torch.Tensor, pos: torch.Tensor, nheads: int, head_dim: int) -> None:
     """Split-operand ('exact') mode: in-place rotary on `nheads` consecutive heads of a pair buffer (hi at column c, lo at
     lo_off + c) with FP32 cos / sin tables (max_len, head_dim)."""
-    xp, ld = _rows2d(x, 'rotary_split x')
+    f16 = x.dtype == torch.float16                       # precision 'half' with q / k as pairs
+    xp, ld = _rows2d(x, 'rotary_split x', torch.float16 if f16 else torch.bfloat16)
     T = x.shape[0]
+    fn = load().esme_hip_rotary_split_f16 if f16 else load().esme_hip_rotary_split
     with _Traced('rotary_split', (T, nheads * head_dim)):
-        _check(load().esme_hip_rotary_split(xp, ld, int(lo_off), _dev(cos32, 'cos', torch.float32), _dev(sin32, 'sin', torch.float32),
+        _check(fn(xp, ld, int(lo_off), _dev(cos32, 'cos', torch.float32), _dev(sin32, 'sin', torch.float32),
                                             _dev(pos, 'pos', torch.int32), T, int(nheads), int(head_dim), int(cos32.shape[0]), _stream()),
                'esme_hip_rotary_split')
 
@@ -631,6 +645,30 @@ def attn_varlen_split(qkv: torch.Tensor, cu_lens: torch.Tensor, max_len: int, he
                                                      B, T, heads, head_dim, int(max_len), float(softmax_scale),
                                                      _dev(order, 'seq order', torch.int32) if order is not None else None, _stream()),
                'esme_hip_attn_varlen_fwd_split')
+    return out
+
+
+def attn_varlen_qkpair(qkv: torch.Tensor, cu_lens: torch.Tensor, max_len: int, heads: int, head_dim: int, softmax_scale: float,
+                       out: Optional[torch.Tensor] = None, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Precision 'half' with q / k as pairs: qkv (T, 5*E) float16 = [q k v | q_lo k_lo] (gemm_fused(pair_out=True, pair_cols=2E)) ->
+    (T, E) float16 attention output; scores from three MFMA passes (Qh Kh^T + Qh Kl^T + Ql Kh^T), exact row maxima."""
+    E = heads * head_dim
+    T = qkv.shape[0]
+    if qkv.shape[1] != 5 * E or qkv.dtype != torch.float16:
+        raise ValueError('attn_varlen_qkpair: qkv must be float16 (T, 5 * H * d)')
+    qp, ld = _rows2d(qkv, 'attn_qkpair qkv', torch.float16)
+    if out is None:
+        out = torch.empty(T, E, dtype=torch.float16, device=qkv.device)
+    op, ldo = _rows2d(out, 'attn_qkpair out', torch.float16)
+    cu = cu_lens if cu_lens.dtype == torch.int32 else cu_lens.to(torch.int32)
+    B = cu.numel() - 1
+    if order is not None and order.numel() != B:
+        raise ValueError('attn: `order` must be a permutation of the B sequence indices (seq_order(cu_lens))')
+    with _Traced('attn_qkpair', (T, heads, head_dim)):
+        _check(load().esme_hip_attn_varlen_fwd_qkpair_f16(qp, qp + 2 * E, qp + 4 * E, ld, 3 * E, op, ldo, _dev(cu, 'cu_lens', torch.int32),
+                                                          B, T, heads, head_dim, int(max_len), float(softmax_scale),
+                                                          _dev(order, 'seq order', torch.int32) if order is not None else None, _stream()),
+               'esme_hip_attn_varlen_fwd_qkpair_f16')
     return out
 
 
@@ -696,7 +734,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
                resid: Optional[torch.Tensor] = None, alpha: float = 1.0, out: Optional[torch.Tensor] = None,
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None,
                q_scale: float = 0.0, split_a: bool = False, pair_out: bool = False, out32: Optional[torch.Tensor] = None,
-               resid_pair: Optional[torch.Tensor] = None, pair_scale=None) -> torch.Tensor:
+               resid_pair: Optional[torch.Tensor] = None, pair_scale=None, pair_ext: Optional[torch.Tensor] = None,
+               pair_cols: int = 0) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
@@ -711,11 +750,14 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     epilogue needs `resid32` or `resid_pair`: the stream as a float16 pair (M, 2N) = [hi | lo], updated in place (x + alpha * (a W^T + b)
     formed in fp32, written back as a pair); returns its hi half, the next GEMM's operand (a view).  The pair may be wider than 2N (lo in
     the LAST N columns).  `pair_scale` = (scale_in, scale_out), float32 (N) or None each: the stream is stored scaled per column
-    (esme_gemm_fusion_t.pair_scale_in / _out: x = (hi + lo) * scale_in on entry, (x_new * scale_out) written back)."""
+    (esme_gemm_fusion_t.pair_scale_in / _out: x = (hi + lo) * scale_in on entry, (x_new * scale_out) written back).  `pair_ext` (int32, <= 64
+    ascending columns; the pair is then (M, 2N + 64) = [hi | ext | lo]): lo of those columns is also written to the extension K-tile.
+    float16 `pair_out` with `ln` (plain epilogue): the result leaves as a float16 (hi, lo) pair, lo only for the first `pair_cols` columns
+    (out is (M, N + pair_cols); 0 = all): q and k of a fused QKV projection as pairs."""
     f16 = a.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
-    if f16 and (split_a or pair_out or out32 is not None):
-        raise ValueError('gemm: float16 operands do not combine with the split-operand arguments')
+    if f16 and (split_a or out32 is not None or (pair_out and (ln is None or epilogue != EPI_NONE or rot is not None))):
+        raise ValueError('gemm: float16 operands do not combine with the split-operand arguments (pair_out: the LN-folded plain epilogue only)')
     ap, lda = _rows2d(a, 'gemm a', dt)
     if not w.is_contiguous():
         raise ValueError('gemm: weight must be contiguous (N, K)')
@@ -729,8 +771,9 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
                 or resid_pair.shape[1] < 2 * N or resid_pair.dtype != torch.float16):
             raise ValueError('gemm: resid_pair is the (M, >= 2N) float16 pair stream of the residual epilogue with float16 operands')
         resid = out = resid_pair[:, :N]
+    lo_cols = (int(pair_cols) if pair_cols else n_out) if pair_out else 0
     if out is None:
-        out = torch.empty(M, 2 * n_out if pair_out else n_out, dtype=dt, device=a.device) if out32 is None else out32
+        out = torch.empty(M, n_out + lo_cols, dtype=dt, device=a.device) if out32 is None else out32
     fu = GemmFusion()
     fu.f16 = 1 if f16 else 0
     if out32 is not None:
@@ -749,12 +792,17 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
                     raise ValueError('gemm: pair_scale vectors are float32 (N)')
             fu.pair_scale_in = _dev(sc_in, 'pair scale in', torch.float32) if sc_in is not None else None
             fu.pair_scale_out = _dev(sc_out, 'pair scale out', torch.float32) if sc_out is not None else None
-    elif pair_scale is not None:
-        raise ValueError('gemm: pair_scale belongs to resid_pair')
+        if pair_ext is not None:
+            if resid_pair.shape[1] != 2 * N + 64 or pair_ext.numel() > 64:
+                raise ValueError('gemm: pair_ext needs the (M, 2N + 64) pair layout and at most 64 columns')
+            fu.ext_sel, fu.ext_n, fu.ext_off = _dev(pair_ext, 'pair_ext', torch.int32), pair_ext.numel(), N
+    elif pair_scale is not None or pair_ext is not None:
+        raise ValueError('gemm: pair_scale / pair_ext belong to resid_pair')
     if pair_out:
-        if out.shape[1] != 2 * n_out:
-            raise ValueError('gemm: a pair output is (M, 2 * n_out)')
+        if out.shape[1] != n_out + lo_cols:
+            raise ValueError('gemm: a pair output is (M, n_out + pair_cols) (pair_cols = 0: 2 * n_out)')
         fu.pair_off = n_out
+        fu.pair_cols = int(pair_cols)
     rp, ldr = (None, 0)
     if resid32 is not None:
         if epilogue != EPI_RESIDUAL or resid32.shape != (M, N) or resid32.stride(1) != 1:

@@ -48,10 +48,12 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe')
 
-    def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False):
+    def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False, plan=None):
         self.pos, self.cos, self.sin = pos, cos, sin
+        self.plan = plan            # precision 'half': HalfPlan (which robustness measures this model needs) or None
+        self.probe = None           # calibration forward: list collecting a per-layer upper bound of |attention score|
         self.f16 = f16              # precision 'half': IEEE fp16 MFMA operands (weights converted once, activations rounded to fp16)
         self.fold = fold            # run the LN-folded fast path
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
@@ -127,6 +129,36 @@ def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.
     return wf, c1, c2.contiguous()
 
 
+class HalfPlan:
+    """What precision 'half' runs for ONE model, decided by a calibration forward (esme.esm.ESM2._calibrate_half):
+
+      ext_sel   int32 device tensor of <= 64 ascending stream channels whose rms is `ratio` times the median channel's at some LayerNorm
+                input ("massive" channels), or None.  Their lo half rides to the LayerNorm-folded GEMMs in an extension K-tile
+                (esme_gemm_fusion_t.ext_sel): a single fp16 rounding of such a channel is noise of the size of the other channels' signal.
+      qk_pair   q and k travel as fp16 (hi, lo) pairs, rotated with fp32 tables, and the scores come from three MFMA passes
+                (esme_hip_attn_varlen_fwd_qkpair_f16): needed once |score| reaches the hundreds (2^-12 |q||k| is then tenths of a score unit).
+      info      the measurements the decision was taken from (reported by tools / bench)."""
+    __slots__ = ('ext_sel', 'qk_pair', 'info')
+
+    def __init__(self, ext_sel=None, qk_pair=False, info=None):
+        self.ext_sel, self.qk_pair, self.info = ext_sel, bool(qk_pair), dict(info or {})
+
+    @property
+    def ext(self) -> int:
+        return 64 if self.ext_sel is not None else 0        # width of the extension tile in the pair row
+
+    def describe(self) -> str:
+        return f"ext channels {0 if self.ext_sel is None else self.ext_sel.numel()}, q/k pairs {'on' if self.qk_pair else 'off'}"
+
+
+def _extend_k(wf: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
+    """[W' | W'[:, sel] | 0] (N, K + 64): the weight of a LayerNorm-folded GEMM that reads [hi | ext] (HalfPlan.ext_sel)."""
+    out = torch.zeros(wf.shape[0], wf.shape[1] + 64, dtype=wf.dtype, device=wf.device)
+    out[:, :wf.shape[1]] = wf
+    out[:, wf.shape[1]:wf.shape[1] + sel.numel()] = wf[:, sel.long()]
+    return out
+
+
 def _fold_layernorm_pow2(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: Optional[torch.Tensor]):
     """The LN fold of precision 'half' (round 5): gamma = g2 * rho with g2 a signed power of two (0 where gamma is 0) and rho in
     [2^-1/2, 2^1/2].  W' = fp16(W * g2) is EXACT (a bf16 weight times a power of two; only values below fp16's normal range lose bits,
@@ -147,6 +179,15 @@ def _fold_layernorm_pow2(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: t
     if bias is not None:
         c2 += bias.float()
     return wf, c1, c2.contiguous(), rho, (1.0 / rho).contiguous()
+
+
+def _score_bound(q: torch.Tensor, k: torch.Tensor, heads: int, d: int, scale: float) -> torch.Tensor:
+    """Upper bound of |softmax_scale * q_i . k_j| over all rows and heads (max row norm of q times max row norm of k per head): what the
+    calibration forward of precision 'half' records per layer (a device scalar; no sync here)."""
+    T = q.shape[0]
+    qn = q.float().reshape(T, heads, d).norm(dim=-1).amax(dim=0)
+    kn = k.float().reshape(T, heads, d).norm(dim=-1).amax(dim=0)
+    return (qn * kn).amax() * scale
 
 
 class FlashMultiheadAttention(nn.Module):
@@ -187,6 +228,7 @@ class FlashMultiheadAttention(nn.Module):
         self._fold16 = None         # the same with W' = W * pow2(gamma) in float16 (precision 'half'), and the float16 out-projection weight
         self._fold16_key = None
         self._rho16 = None          # (rho, 1 / rho) float32 (phys_dim): the part of gamma that rides on the pair stream (_fold_layernorm_pow2)
+        self._fold16x = None        # (key, [W' | W'[:, sel] | 0]): the extension K-tile form (HalfPlan.ext_sel)
         self._out16 = None
         self._out16_key = None
         self._q4_qkv = None         # esme.quantization.Q4Matrix pair when the layer is 4-bit
@@ -262,13 +304,20 @@ class FlashMultiheadAttention(nn.Module):
         self._pack_fold(True)
         return self._rho16
 
-    def _weights_qkv(self, fold: bool, f16: bool = False):
+    def _weights_qkv(self, fold: bool, f16: bool = False, ext_sel: Optional[torch.Tensor] = None):
         """(W, bias, c1, c2) of the fused QKV projection: the LN-folded form when `fold`
-        (bias inside c2), else the plain one.  4-bit layers expand into the shared scratch."""
+        (bias inside c2), else the plain one.  4-bit layers expand into the shared scratch.  `ext_sel` (precision 'half' with massive
+        channels): the weight with the extension K-tile appended (_extend_k)."""
         if f16:
             if self._q4_qkv is not None or not fold:
                 raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
             wf, c1, c2 = self._pack_fold(True)
+            if ext_sel is not None:
+                key = (self._fold16_key, ext_sel.data_ptr())
+                if self._fold16x is None or self._fold16x[0] != key:
+                    with torch.no_grad():
+                        self._fold16x = (key, _extend_k(wf, ext_sel))
+                wf = self._fold16x[1]
             return wf, None, c1, c2
         if self._q4_qkv is not None:
             if fold:
@@ -331,7 +380,8 @@ class FlashMultiheadAttention(nn.Module):
                                 softmax_scale=self.head_dim ** -0.5, exact=exact, order=order, q_prescaled=q_prescaled)
 
     def forward(self, x, cu_lens, max_len, lora_names=None, ctx: Optional[ForwardContext] = None,
-                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None):
+                resid=None, alpha: float = 1.0, out=None, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None,
+                pair_ext=None):
         """Attention branch.  With `resid` given the out-projection epilogue returns
         resid + alpha * (attn @ W_o^T + b_o) (written to `out`, which may alias resid).
         `x_stats` ((nblk, T, 2) f32 partial row sums of x) selects the LN-folded projection;
@@ -349,8 +399,25 @@ class FlashMultiheadAttention(nn.Module):
         qp = bool(_ATTN_QP and (rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and x_stats is not None and not ctx.exact_attn and not f16)
         if f16 and (x_stats is None or (resid32 is None and resid_pair is None) or (self.pre_layernorm and not qk_pass)):
             raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 / pair stream (ESM-C: with the fused q/k pass)")
+        plan = ctx.plan if (f16 and ctx is not None) else None
+        qk_pair = bool(plan is not None and plan.qk_pair)
+        if qk_pair:
+            # precision 'half' on a model with large attention scores: q / k leave the LN-folded projection as fp16 (hi, lo) pairs, are rotated
+            # with FP32 tables (ctx.cos / ctx.sin are float32 then) and multiplied in three MFMA passes; v, P and the output stay single fp16
+            if self.pre_layernorm or d not in (16, 32, 64) or E % 128 != 0:
+                raise NotImplementedError("precision='half' with q/k pairs covers ESM-2 / ESM-1 blocks with head dim 16 / 32 / 64 and a 128-aligned width")
+            wf, _, c1, c2 = self._weights_qkv(True, True, pair_ext)
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), pair_out=True, pair_cols=2 * E)
+            if self.rot_emb is not None:
+                _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
+            if ctx.probe is not None:
+                ctx.probe.append(_score_bound(qkv[:, :E], qkv[:, E:2 * E], H, d, self.head_dim ** -0.5))
+            a = _hip.attn_varlen_qkpair(qkv, cu_lens, max_len, H, d, self.head_dim ** -0.5, order=ctx.order)
+            wo, bo = self._weights_out(True)
+            return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid_pair=resid_pair,
+                                   pair_scale=pair_scale, pair_ext=pair_ext)
         if x_stats is not None:
-            wf, _, c1, c2 = self._weights_qkv(True, f16)
+            wf, _, c1, c2 = self._weights_qkv(True, f16, pair_ext)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,
                                   q_scale=_q_scale(self.head_dim) if (qp and rot_fusable) else 0.0)
         else:
@@ -371,12 +438,14 @@ class FlashMultiheadAttention(nn.Module):
                     _hip.rotary_(q.view(T, E), k.view(T, E), ctx.cos, ctx.sin, ctx.pos, H)
                 else:
                     q, k = self.rot_emb(q, k, cu_lens, max_len, inplace=True)
+        if ctx is not None and ctx.probe is not None:
+            ctx.probe.append(_score_bound(q.reshape(T, E), k.reshape(T, E), H, d, self.head_dim ** -0.5))
         a = self._attn(q, k, v, cu_lens, max_len, exact=bool(ctx is not None and ctx.exact_attn),
                        order=ctx.order if ctx is not None else None, q_prescaled=qp)
         wo, bo = self._weights_out(f16)
         if resid is not None or resid32 is not None or resid_pair is not None:
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair,
-                                   pair_scale=pair_scale)
+                                   pair_scale=pair_scale, pair_ext=pair_ext)
         return _hip.gemm(a, wo, bo, out=out)
 
 
@@ -444,6 +513,7 @@ class FlashTransformerLayer(nn.Module):
         self._fold16 = None         # float16 forms (precision 'half'): folded up-projection (W * pow2(gamma)), down-projection weight
         self._fold16_key = None
         self._rho16 = None          # (rho, 1 / rho) of the FFN LayerNorm (see FlashMultiheadAttention._rho16)
+        self._fold16x = None        # (key, the up-projection weight with the extension K-tile)
         self._down16 = None
         self._down16_key = None
         self._q4_up = None          # esme.quantization.Q4Matrix pair when the layer is 4-bit
@@ -493,12 +563,18 @@ class FlashTransformerLayer(nn.Module):
         self._pack_fold(True)
         return self._rho16
 
-    def _weights_up(self, fold: bool, f16: bool = False):
-        """(W, bias, c1, c2) of the FFN up-projection (gate/fc interleaved for SwiGLU)."""
+    def _weights_up(self, fold: bool, f16: bool = False, ext_sel: Optional[torch.Tensor] = None):
+        """(W, bias, c1, c2) of the FFN up-projection (gate/fc interleaved for SwiGLU); `ext_sel`: with the extension K-tile (_extend_k)."""
         if f16:
             if self._q4_up is not None or not fold:
                 raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
             wf, c1, c2 = self._pack_fold(True)
+            if ext_sel is not None:
+                key = (self._fold16_key, ext_sel.data_ptr())
+                if self._fold16x is None or self._fold16x[0] != key:
+                    with torch.no_grad():
+                        self._fold16x = (key, _extend_k(wf, ext_sel))
+                wf = self._fold16x[1]
             return wf, None, c1, c2
         if self._q4_up is not None:
             if fold:
@@ -540,18 +616,18 @@ class FlashTransformerLayer(nn.Module):
             return self._down_pad
         return down.weight, down.bias
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None):
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None, pair_ext=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         f16 = x.dtype == torch.float16                       # precision 'half': the operand type travels with the tensors
         if x_stats is not None:
-            wf, _, c1, c2 = self._weights_up(True, f16)
+            wf, _, c1, c2 = self._weights_up(True, f16, pair_ext)
             u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, self.embed_dim, self.final[0].eps, c1, c2))
         else:
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
         wd, bd = self._weights_down(f16)
         return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair,
-                               pair_scale=pair_scale)
+                               pair_scale=pair_scale, pair_ext=pair_ext)
 
     def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext, next_scale=None):
         """One layer with the residual stream in fp32 (`ctx.x32`, updated in place).  `x16` = bf16(stream) is the MFMA
@@ -560,7 +636,7 @@ class FlashTransformerLayer(nn.Module):
         rounding back to x16 and emit its row statistics for the next folded LayerNorm -- the same four GEMM launches per
         layer as the fast mode, no extra pass.  Returns nothing: x16 / ctx.sums are refreshed in place."""
         alpha = 1.0 / self.residue_scaling
-        T, E = x16.shape
+        T, E = x16.shape[0], self.phys_dim                  # (x16 may carry the extension K-tile: (T, E + 64))
         if ctx.part_a is None:
             ctx.part_a = torch.empty(_hip.stats_blocks(T, E), T, 2, dtype=torch.float32, device=x16.device)
             ctx.part_b = torch.empty_like(ctx.part_a)
@@ -570,13 +646,14 @@ class FlashTransformerLayer(nn.Module):
         # scaled for this layer's attention LayerNorm, the out-projection hands it on scaled for the FFN LayerNorm, the down-projection
         # for the next layer's attention LayerNorm (`next_scale` = its rho; None after the last layer: the final LayerNorm reads x itself).
         r32, rp = (None, ctx.xs) if ctx.f16 else (ctx.x32, None)
-        sa = sf = None
+        sa = sf = ext = None
         if ctx.f16:
             (_, a_inv), (f_rho, f_inv) = self.self_attn.stream_scale(), self.stream_scale()
             sa, sf = (a_inv, f_rho), (f_inv, next_scale)
+            ext = ctx.plan.ext_sel if ctx.plan is not None else None      # massive channels: x16 is then [hi | ext] (K = E + 64), the pair (T, 2E + 64)
         self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
-                       resid32=r32, resid_pair=rp, pair_scale=sa)
-        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf)
+                       resid32=r32, resid_pair=rp, pair_scale=sa, pair_ext=ext)
+        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf, pair_ext=ext)
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):

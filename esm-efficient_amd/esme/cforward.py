@@ -34,10 +34,12 @@ _VERSION = operator.attrgetter('_version')
 class ModelDescriptor:
     """esme_model_desc_t of one model instance + the tensors it points to."""
 
-    def __init__(self, model, f16: bool = False):
-        """`f16`: the descriptor of esme_hip_forward_half -- the float16 derived copies (precision 'half')."""
+    def __init__(self, model, f16: bool = False, plan=None):
+        """`f16`: the descriptor of esme_hip_forward_half -- the float16 derived copies (precision 'half'); `plan`: its HalfPlan."""
         from esme.attention import _version_key
         self.key = self.signature(model)
+        self.plan = plan
+        ext_sel = plan.ext_sel if (f16 and plan is not None) else None
         layers = model.layers
         first = layers[0]
         att0 = first.self_attn
@@ -45,9 +47,9 @@ class ModelDescriptor:
         arr = (LayerWeights * len(layers))()
         for i, layer in enumerate(layers):
             att = layer.self_attn
-            wq, _, c1, c2 = att._weights_qkv(True, f16)
+            wq, _, c1, c2 = att._weights_qkv(True, f16, ext_sel) if f16 else att._weights_qkv(True)
             wo, bo = att._weights_out(f16)
-            wu, _, u1, u2 = layer._weights_up(True, f16)
+            wu, _, u1, u2 = layer._weights_up(True, f16, ext_sel) if f16 else layer._weights_up(True)
             wd, bd = layer._weights_down(f16)
             lw = arr[i]
             lw.qkv_w, lw.qkv_c1, lw.qkv_c2 = _ptr(wq), _ptr(c1), _ptr(c2)
@@ -77,6 +79,10 @@ class ModelDescriptor:
         d.layers = arr
         ln = model.emb_layer_norm_after
         d.final_ln_w, d.final_ln_b = _ptr(ln.weight), _ptr(ln.bias)
+        if ext_sel is not None:
+            d.half_ext_n, d.half_ext_sel = int(ext_sel.numel()), _ptr(ext_sel)
+            self.keep.append(ext_sel)
+        d.half_qk_pair = int(bool(f16 and plan is not None and plan.qk_pair))
         self.layer_array = arr
         self.desc = d
 
@@ -135,13 +141,14 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
 
 
 
-def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32):
+def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None):
     """precision 'half': fp32 stream at the start `x32` (T, phys_dim) -> all layers + final LayerNorm through ONE C call
-    (esme_hip_forward_half); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32."""
+    (esme_hip_forward_half); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32.
+    `plan`: the model's HalfPlan (cos / sin are float32 tables when it asks for q / k pairs)."""
     lib = _bind()
     md = getattr(model, '_cdesc16', None)
-    if md is None or md.key != ModelDescriptor.signature(model):
-        md = ModelDescriptor(model, f16=True)
+    if md is None or md.key != ModelDescriptor.signature(model) or md.plan is not plan:
+        md = ModelDescriptor(model, f16=True, plan=plan)
         model._cdesc16 = md
     d = md.desc
     d.cos, d.sin = _ptr(cos), _ptr(sin)

@@ -153,23 +153,91 @@ class ESM2(nn.Module):
         from esme.cforward import ModelDescriptor
         return ModelDescriptor.supported(self, precision)
 
-    def set_precision(self, mode: str):
-        """'fast' (default), 'high' (fp32 residual stream), 'half' (fp32 stream + fp16 MFMA operands: ~5e-4 of the fp32 forward, fp32
-        outputs, ~1.1x the time) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to ~1e-5, fp32 outputs, ~2.2x the
-        time); DESIGN.md section 4 has what each achieves."""
+    # precision 'half' on ill-conditioned checkpoints: 'auto' = a calibration forward on synthetic residues
+    # decides, once per model, whether massive stream channels get the extension K-tile and whether q / k travel as pairs
+    # (esme.attention.HalfPlan); False = the plain form; True = both measures on (the channel list still comes from the calibration).
+    half_robust = {'0': False, '1': True}.get(os.environ.get('ESME_HALF_ROBUST', 'auto'), 'auto')
+    HALF_CHANNEL_RATIO = 6.0       # a channel is "massive" when its rms over the calibration rows exceeds this multiple of the median channel's
+    HALF_SCORE_BOUND = 32.0        # q / k become pairs when max |q_i| max |k_j| / sqrt(d) reaches this (2^-12 relative x that = 1e-2 of a score unit)
+
+    def set_precision(self, mode: str, robust=None):
+        """'fast' (default), 'high' (fp32 residual stream), 'half' (fp16 MFMA operands, fp16-pair residual stream: ~4e-4 of the fp32
+        forward, fp32 outputs, ~1.1x the time) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to ~1e-5, fp32 outputs,
+        ~2.2x the time); DESIGN.md section 4 has what each achieves.  `robust` ('half' only): 'auto' (default; see `half_robust`), True,
+        False, or a ready esme.attention.HalfPlan."""
         assert mode in ('fast', 'high', 'half', 'exact'), mode
         self.precision = mode
+        from esme.attention import HalfPlan
+        self._half_plan = robust if isinstance(robust, HalfPlan) else None
+        if robust is not None and not isinstance(robust, HalfPlan):
+            assert robust in ('auto', True, False), robust
+            self.half_robust = robust
         self.invalidate_graphs()
         return self
+
+    def half_plan(self, device=None):
+        """The HalfPlan precision 'half' runs with on this model (calibrated on first use; see `half_robust`)."""
+        from esme.attention import HalfPlan
+        plan = getattr(self, '_half_plan', None)
+        if plan is None:
+            if self.half_robust is False or not len(self.layers):
+                plan = HalfPlan(info={'calibrated': False})
+            else:
+                plan = self._calibrate_half(device if device is not None else self.embed_tokens.weight.device)
+            self._half_plan = plan
+        return plan
+
+    def _calibrate_half(self, device):
+        """One forward of the plain 'half' form over synthetic residues (4 sequences, 1 024 tokens, numpy PCG64: the same on every
+        machine), measuring (a) the rms of every stream channel at every layer boundary relative to the median channel and (b) an upper
+        bound of |attention score| per layer.  Nothing in it depends on the caller's data; ~L x 5 small launches, once per model."""
+        import numpy as np
+        from esme.attention import HalfPlan
+        rng = np.random.Generator(np.random.PCG64(20250929))
+        lengths = [384, 320, 192, 128]
+        toks = []
+        for n in lengths:
+            body = rng.integers(4, 24, size=n - 2)
+            toks.append(np.concatenate(([self.alphabet.cls_idx], body, [self.alphabet.eos_idx])))
+        tokens = torch.from_numpy(np.concatenate(toks).astype(np.int64)).to(device)
+        cu = torch.tensor(np.concatenate(([0], np.cumsum(lengths))), dtype=torch.int32, device=device)
+        self._half_plan = HalfPlan(info={'calibrating': True})          # the plain form, and no recursion
+        probe = []
+        self._calib_probe = probe
+        try:
+            with torch.no_grad():
+                rep = self._forward_representation(tokens, (cu, max(lengths)), False, None, list(range(len(self.layers))))
+        finally:
+            self._calib_probe = None
+        Ep, L = self.phys_dim, len(self.layers)
+        taps = rep[:, Ep:].reshape(rep.shape[0], L, Ep)[:, :, :self.embed_dim].float()      # raw stream after every layer
+        x0 = self._embedding_phys(tokens, (cu, max(lengths)))[:, :self.embed_dim].float()
+        ratio = torch.zeros(self.embed_dim, device=device)
+        for site in [x0] + [taps[:, i] for i in range(L - 1)]:        # the inputs of the L attention LayerNorms
+            rms = site.pow(2).mean(dim=0).sqrt()
+            ratio = torch.maximum(ratio, rms / rms.median().clamp_min(1e-30))
+        bound = float(torch.stack(probe).max()) if probe else 0.0
+        mass = torch.nonzero(ratio > self.HALF_CHANNEL_RATIO).flatten()
+        if mass.numel() > 64:
+            mass = mass[torch.argsort(ratio[mass], descending=True)[:64]]
+        sel = torch.sort(mass).values.to(torch.int32).contiguous() if mass.numel() else None
+        att = self.layers[0].self_attn
+        pair_ok = (not att.pre_layernorm) and att.head_pad in (16, 32, 64) and att.attn_dim % 128 == 0
+        qk_pair = pair_ok and (bound >= self.HALF_SCORE_BOUND or self.half_robust is True)
+        info = {'calibrated': True, 'max_channel_ratio': float(ratio.max()), 'score_bound': bound, 'massive_channels': int(mass.numel()),
+                'qk_pair_supported': bool(pair_ok)}
+        return HalfPlan(sel, qk_pair, info)
 
     def _apply(self, fn, *a, **kw):
         """`.to()`, `.cuda()`, dtype casts: the parameters' storage moves -- drop everything derived from it."""
         out = super()._apply(fn, *a, **kw)
+        self._half_plan = None                # (its channel list lives on the old device; recalibrated on first use)
         self.invalidate_graphs()
         return out
 
     def load_state_dict(self, *a, **kw):
         out = super().load_state_dict(*a, **kw)
+        self._half_plan = None                # other weights, other plan
         self.invalidate_graphs()
         return out
 
@@ -178,10 +246,16 @@ class ESM2(nn.Module):
         pos, _ = _hip.seq_positions(cu_lens, total)
         rot = self.layers[0].self_attn.rot_emb if len(self.layers) else None
         cos = sin = None
+        plan = self.half_plan(device) if self.precision == 'half' else None
         if rot is not None:
-            cos, sin = rot.tables(int(max_len), device, {'exact': torch.float32, 'half': torch.float16}.get(self.precision, torch.bfloat16))
-        return ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high',
-                              f16=self.precision == 'half')
+            dt = {'exact': torch.float32, 'half': torch.float16}.get(self.precision, torch.bfloat16)
+            if plan is not None and plan.qk_pair:
+                dt = torch.float32                                # q / k pairs are rotated by a pass of their own with fp32 tables
+            cos, sin = rot.tables(int(max_len), device, dt)
+        ctx = ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high',
+                             f16=self.precision == 'half', plan=plan)
+        ctx.probe = getattr(self, '_calib_probe', None)
+        return ctx
 
     def _unpad(self, x, tokens):
         """Boolean-mask row gather: the `unpad_input` contract (esm.py:238)."""
@@ -272,32 +346,34 @@ class ESM2(nn.Module):
                 alloc = torch.zeros if self.padded else torch.empty
                 pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
                 x = alloc(T, Ep, dtype=torch.float32, device=x.device)
-                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x)
+                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan)
                 if want_pair:
                     x = pair
                 return self._finish_representation(x, [], pad_output, pad_args, pad_indices, cu_lens, pad_width)
             # the stream as a float16 PAIR [hi | lo] (x = hi + lo: 22 significant bits): hi is the operand of the LayerNorm-folded GEMMs,
             # the residual GEMMs read and write the pair in place (8 B per element in whole lines; an fp32 stream + operand copy is 10).
             # Padded layouts (ESM2-35M): everything at the physical width, pad columns zero as in the fast mode.
-            ctx.xs = torch.empty(T, 2 * Ep, dtype=torch.float16, device=x.device)
+            # With massive channels (ctx.plan.ext_sel) the row is [hi | ext (64) | lo]: the LayerNorm-folded GEMMs read [hi | ext] (K = Ep + 64).
+            ext = ctx.plan.ext
+            ctx.xs = torch.empty(T, 2 * Ep + ext, dtype=torch.float16, device=x.device)
             ctx.sums = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
             # (stored scaled per column by rho of the first attention LayerNorm: attention._fold_layernorm_pow2)
             scales = [layer.self_attn.stream_scale() for layer in self.layers]
-            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True, scale=scales[0][0])
+            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True, scale=scales[0][0], ext_sel=ctx.plan.ext_sel)
             del x32
-            x16 = ctx.xs[:, :Ep]
+            x16 = ctx.xs[:, :Ep + ext]
             ctx.order = _hip.seq_order(cu_lens)
             last = len(self.layers) - 1
             for i, layer in enumerate(self.layers):
                 layer.forward_high_precision(x16, cu_lens, max_len, ctx, next_scale=scales[i + 1][0] if i < last else None)
                 if i in layers:
-                    tap = _hip.pair_to_f32(ctx.xs)
+                    tap = _hip.pair_to_f32(ctx.xs, Ep)
                     taps.append(tap * scales[i + 1][1] if i < last else tap)          # the raw layer output: undo the stream's column scaling
             ln = self.emb_layer_norm_after
             alloc = torch.zeros if self.padded else torch.empty
             pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
             x = alloc(T, Ep, dtype=torch.float32, device=x.device)
-            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x, in_off=Ep, out_off=Ep)
+            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x, in_off=Ep + ext, out_off=Ep)
             if want_pair:
                 x, taps = pair, []
         elif self.precision == 'high' and len(self.layers):

@@ -104,9 +104,11 @@ int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t l
                             float* sums, int64_t T, int E, void* stream);
 /* The pair form (lo_off != 0) with the stream stored SCALED per column: [hi | lo] = split(scale[e] * x32[t, e]) (scale: float (E), 16-byte
  * aligned, or NULL = 1; see esme_gemm_fusion_t.pair_scale_in / _out).  In the pair form `sums` describes the fp32 values x32 themselves
- * (unscaled, unrounded), as the residual epilogues on the pair stream do afterwards. */
+ * (unscaled, unrounded), as the residual epilogues on the pair stream do afterwards.  ext_off != 0: the 64-column extension tile at
+ * x16[t, ext_off ..] receives lo of the ext_n selected columns (then zeros), see esme_gemm_fusion_t.ext_sel. */
 int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
-                                   const float* scale, float* sums, int64_t T, int E, void* stream);
+                                   const float* scale, const int32_t* ext_sel, int ext_n, int64_t ext_off,
+                                   float* sums, int64_t T, int E, void* stream);
 
 /* out[t, e] = x[t, e] + x[t, lo_off + e] in fp32 for a 16-bit pair stream (bf16, or IEEE fp16 when f16 != 0): the raw layer outputs that
  * forward_representation(layers=[...]) (esme/esm.py:225-227,249-264) returns when the stream is a pair (precision 'half'). */
@@ -236,6 +238,21 @@ int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, const void* v, 
 int esme_hip_rotary_split(void* x, int64_t ld, int64_t lo_off, const float* cos, const float* sin, const int32_t* pos,
                           int64_t T, int nheads, int d, int max_len, void* stream);
 
+/* esme_hip_rotary_split on IEEE fp16 pairs (precision 'half' with q / k as pairs: fp32 tables, because at |score| in the hundreds the
+ * 2^-12 of an fp16 table entry is tenths of a score unit). */
+int esme_hip_rotary_split_f16(void* x, int64_t ld, int64_t lo_off, const float* cos, const float* sin, const int32_t* pos,
+                              int64_t T, int nheads, int d, int max_len, void* stream);
+
+/* Varlen attention on IEEE fp16 operands with ONLY q and k as (hi, lo) pairs (lo lo_qk elements further right in the same row):
+ * S = Qh Kh^T + Qh Kl^T + Ql Kh^T (3 MFMA passes), classic online softmax with exact row maxima, P, v and o single fp16.
+ * Precision 'half' switches to it when a calibration forward finds attention scores large enough for the 2^-12 of an fp16 q / k to
+ * matter (massive residual-stream channels behind large LayerNorm gains); d in {16, 32, 64}.  Replaces flash_attn_varlen_func
+ * (esme/attention.py:115-123) of the reference's fp32 forward on such a model. */
+int esme_hip_attn_varlen_fwd_qkpair_f16(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qk,
+                                        void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
+                                        int H, int d, int max_len, float softmax_scale, const int32_t* seq_order,
+                                        void* stream);
+
 /* esme_hip_embed_positions with an fp32 result (contiguous (T, E)): token row + learned-position row summed exactly -- the embedding of
  * ESM-1b / ESM-1v in the reference's fp32 forward (esme/esm.py:634-652,694-711). */
 int esme_hip_embed_positions_f32(const int64_t* tokens, const void* table, const void* pos_table, const int32_t* pos_idx,
@@ -345,6 +362,19 @@ typedef struct esme_gemm_fusion {
      * pair (rho of the NEXT consumer).  float (N) each, 16-byte aligned; NULL = 1.  stats_out describes the UNSCALED fp32 x_new. */
     const float* pair_scale_in;
     const float* pair_scale_out;
+    /* fp16 pair stream only: the EXTENSION K-tile of precision 'half' for models with massive stream channels.  The pair row is laid out
+     * [hi (N) | ext (64) | lo (N)] (ext_off = N, pair_off = N + 64); for the ext_n <= 64 selected columns ext_sel[s] (int32, device, ascending) the
+     * epilogue stores lo a second time at C[m, ext_off + s].  The LayerNorm-folded GEMM that reads the stream next runs over K = N + 64 with
+     * A = [hi | ext] (contiguous) and W = [W' | W'[:, ext_sel] | 0]: the selected channels enter the product as hi + lo (22 bits) -- a
+     * single fp16 rounding of a channel 50x larger than the rest is noise of the size of the rest's signal.
+     * ext_off = 0: off.  The columns ext_off + ext_n .. ext_off + 63 must be zero (esme_hip_stream_operand_scaled writes them). */
+    const int32_t* ext_sel;
+    int ext_n;
+    int64_t ext_off;
+    /* f16 + pair_off with ESME_EPI_NONE and the LN fold (no fused rotary): the projection's result leaves as an fp16 (hi, lo) pair, lo at
+     * column pair_off + n -- only for the columns < pair_cols (0 = all; a multiple of 256): q and k of a fused QKV projection as pairs for
+     * esme_hip_attn_varlen_fwd_qkpair_f16, v single. */
+    int pair_cols;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
@@ -483,6 +513,14 @@ typedef struct esme_model_desc {
     const void* head_dense_w; const void* head_dense_b; const void* head_ln_w; const void* head_ln_b;
     const void* head_final_w; const void* head_final_b;
     const void* cos; const void* sin;
+    /* esme_hip_forward_half only (esme_hip_forward ignores them) -- the robustness measures a calibration decided for this model
+     * (esme.attention.HalfPlan):
+     *   half_ext_n > 0: the half_ext_n <= 64 "massive" stream channels half_ext_sel (int32, device, ascending) ride in an extension K-tile
+     *       (esme_gemm_fusion_t.ext_sel): the pair rows are [hi | ext (64) | lo], qkv_w / up_w are (N, phys_dim + 64) = [W' | W'[:, sel] | 0];
+     *   half_qk_pair != 0: q and k leave the QKV projection as fp16 pairs (esme_gemm_fusion_t.pair_cols), are rotated by
+     *       esme_hip_rotary_split_f16 -- cos / sin are then FP32 tables -- and multiplied by esme_hip_attn_varlen_fwd_qkpair_f16
+     *       (ESM-2 / ESM-1 blocks, head_pad in {16, 32, 64}, heads * head_pad a multiple of 128). */
+    int half_ext_n; const int32_t* half_ext_sel; int half_qk_pair;
 } esme_model_desc_t;
 
 int64_t esme_hip_forward_workspace_bytes(const esme_model_desc_t* model, int64_t T);

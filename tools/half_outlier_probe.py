@@ -30,7 +30,13 @@ for scale in (1.0, 10.0, 50.0, 200.0):
     model.to(DEV)
     ref = O.forward_logits(w, H, tokens, cu, max(lengths), torch.float32).float()
     out = {}
+    args = (tokens.to(DEV), (cu.to(DEV), max(lengths)))
     for mode in ('fast', 'half', 'exact'):
-        out[mode] = rel(model.set_precision(mode)(tokens.to(DEV), (cu.to(DEV), max(lengths))).float().cpu(), ref)
+        out[mode] = rel(model.set_precision(mode)(*args).float().cpu(), ref)
+    plan = model.set_precision('half').half_plan()
+    out['half-plain'] = rel(model.set_precision('half', robust=False)(*args).float().cpu(), ref)     # round 4's form + the power-of-two fold
+    model.half_robust = 'auto'
     x = O.forward_representation(w, H, tokens, cu, max(lengths), torch.float32)
-    print(f'outlier scale {scale:6.0f}: fast {out["fast"]:.2e}  half {out["half"]:.2e}  exact {out["exact"]:.2e}   (max |final-LN output| {float(x.abs().max()):.1f})', flush=True)
+    print(f'outlier scale {scale:6.0f}: fast {out["fast"]:.2e}  half {out["half"]:.2e} (plain form {out["half-plain"]:.2e})  exact {out["exact"]:.2e}   '
+          f'(max |final-LN output| {float(x.abs().max()):.1f}; plan: {plan.describe()}, score bound {plan.info.get("score_bound", 0):.0f}, '
+          f'max channel ratio {plan.info.get("max_channel_ratio", 0):.1f})', flush=True)
