@@ -41,14 +41,7 @@ def h16(x):
 def outlier_weights(L, E, scale, seed=2):
     """tools/half_outlier_probe.py's model: 4 embedding columns + the matching FFN-down biases x scale, two LN gains x min(scale, 10)."""
     from esme import synthetic as syn
-    w = syn.synthetic_state_dict('esm2', L, E, seed=seed)
-    g = torch.Generator().manual_seed(0)
-    cols = torch.randperm(E, generator=g)[:4]
-    w['embed_tokens.weight'][:, cols] *= scale
-    for i in range(L):
-        w[f'layers.{i}.final.3.bias'][cols] *= scale
-        w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= min(scale, 10.0)
-    return w, cols
+    return syn.massive_channel_state_dict(L, E, scale, seed=seed)
 
 
 def pow2_split(gamma):

@@ -18,13 +18,7 @@ lengths = [150, 61, 300]
 tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
 rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
 for scale in (1.0, 10.0, 50.0, 200.0):
-    w = syn.synthetic_state_dict('esm2', L, E, seed=2)
-    g = torch.Generator().manual_seed(0)
-    cols = torch.randperm(E, generator=g)[:4]
-    w['embed_tokens.weight'][:, cols] *= scale                       # massive stream channels from the start
-    for i in range(L):
-        w[f'layers.{i}.final.3.bias'][cols] *= scale                 # ... fed again by every FFN
-        w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= min(scale, 10.0)
+    w, cols = syn.massive_channel_state_dict(L, E, scale, seed=2)    # massive stream channels from the start, fed again by every FFN
     model = build('esm2', L, E, H, seed=2)
     model.load_state_dict({k: v.clone() for k, v in w.items()}, strict=False)
     model.to(DEV)
