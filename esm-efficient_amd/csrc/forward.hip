@@ -198,7 +198,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
     for (int i = 0; i < m->n_layers; ++i) {
         const esme_layer_weights_t& L = m->layers[i];
         esme_gemm_fusion_t fu{};
-        fu.f16 = 1;
+        fu.f16 = 1; fu.overflow_flag = m->half_overflow_flag;
         fu.ln_partial = stats; fu.ln_nblk = stats_nblk; fu.ln_dim = E; fu.ln_eps = m->ln_eps; fu.ln_c1 = L.qkv_c1; fu.ln_c2 = L.qkv_c2;
         char* q = w.qkv; char* k = w.qkv + Ea * 2; char* v = w.qkv + 2 * Ea * 2;
         if (qk_pair) {
@@ -223,7 +223,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         fo.pair_scale_in = L.ps_attn_inv; fo.pair_scale_out = L.ps_ffn;               // the stream arrives scaled for this layer's attention LayerNorm, leaves scaled for its FFN LayerNorm
         ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, ldxs, w.xs, ldxs, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
         esme_gemm_fusion_t fup{};
-        fup.f16 = 1;
+        fup.f16 = 1; fup.overflow_flag = m->half_overflow_flag;
         fup.ln_partial = w.part_b; fup.ln_nblk = nblk; fup.ln_dim = E; fup.ln_eps = m->ln_eps; fup.ln_c1 = L.up_c1; fup.ln_c2 = L.up_c2;
         const int up_rows = m->swiglu ? 2 * m->ffn_dim : m->ffn_dim;
         ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.up_w, nullptr, nullptr, 0, w.mid, m->ffn_dim, T, up_rows, Kf,
@@ -236,7 +236,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         stats = w.part_a; stats_nblk = nblk;
     }
     // final LayerNorm over the logical width, from the fp16 pair, written as the bf16 pair the split-operand LM head reads (+ fp32)
-    ESME_TRY(esme_hip_layernorm_split(w.xs, ldxs, 2, lo_off, m->final_ln_w, m->final_ln_b, pair, ld_pair, Ep, rep32, ld_rep, T, E, m->ln_eps, stream));
+    ESME_TRY(esme_hip_layernorm_split_checked(w.xs, ldxs, 2, lo_off, m->final_ln_w, m->final_ln_b, pair, ld_pair, Ep, rep32, ld_rep, T, E, m->ln_eps, m->half_overflow_flag, stream));
 #undef ESME_TRY
     return ESME_OK;
 }

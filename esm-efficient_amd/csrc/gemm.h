@@ -43,6 +43,7 @@ struct GemmArgs {
     int f16 = 0;                 // precision 'half': A, W, rotary tables and C are IEEE fp16 (esme_gemm_fusion_t.f16)
     const float* ps_in = nullptr; const float* ps_out = nullptr;   // pair stream stored scaled per column (esme_gemm_fusion_t.pair_scale_in / _out); nullptr = 1
     const int32_t* ext_sel = nullptr; int ext_n = 0; int64_t ext_off = 0;     // pair stream: lo of the selected columns also goes to C[m, ext_off + slot] (the extension K-tile)
+    int* ovf = nullptr;          // LN fold: set to 1 when a row's statistics are not finite (precision 'half': a stream value left fp16's range)
     int pair_cols = 0;           // PAIR output: only columns < pair_cols get their lo half (0 = all)
     int stream_out = 0;          // host side: the results are larger than the memory-side cache -> stored with the non-temporal hint (common.h store_stream)
 };

@@ -328,6 +328,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                         s1 += p[0]; s2 += p[1];
                     }
                 }
+                // range guard of precision 'half' (esme_gemm_fusion_t.overflow_flag): a stream value past fp16's 65 504 became inf in the pair, the
+                // branch that read it NaN, and the statistics of the stream it was added back into are not finite -- a sticky device flag says so
+                if (a.ovf && !(s2 < 3.0e38f)) atomicOr(a.ovf, 1);
                 const float inv = 1.0f / (float)a.ln_dim;
                 const float mean = s1 * inv;
                 const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + a.ln_eps);
@@ -1275,7 +1278,7 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
         }
     } else if (fu && (fu->w_k || fu->pair_off || fu->c32)) {        // split-operand ('exact') mode
         if (fu->w_k) {
-            ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && K % fu->w_k == 0, "gemm: w_k (the K of W) must be a multiple of 64 that divides K");
+            ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && (K == fu->w_k || K == 2 * fu->w_k), "gemm: w_k (the K of W) must be a multiple of 64 with K = w_k or K = 2 w_k (the K-tile index of W wraps once)");
             if (fu->w_k < K) a.kt_wrap = fu->w_k / BK;
         }
         if (fu->pair_off) {
@@ -1321,6 +1324,7 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
             if (N % 4 != 0 || !vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: LN fold needs N % 4 == 0 and 16-byte addressable C");
             a.ln_partial = fu->ln_partial; a.ln_nblk = fu->ln_nblk; a.ln_dim = fu->ln_dim; a.ln_eps = fu->ln_eps;
             a.ln_c1 = fu->ln_c1; a.ln_c2 = fu->ln_c2;
+            a.ovf = fu->overflow_flag;
             lnf = true;
         }
         if (fu->stats_out) {                                         // emit row statistics for the next LayerNorm

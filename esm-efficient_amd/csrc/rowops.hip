@@ -248,7 +248,8 @@ template <int NCH, int IN>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const void* __restrict__ xv, int64_t ldx, int64_t in_off,
                                                               const u16* __restrict__ w, const u16* __restrict__ b,
                                                               u16* __restrict__ y, int64_t ldy, int64_t out_off,
-                                                              float* __restrict__ y32, int64_t ld32, int64_t T, int E, float eps) {
+                                                              float* __restrict__ y32, int64_t ld32, int64_t T, int E, float eps,
+                                                              int* __restrict__ ovf) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -289,7 +290,10 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const void* __rest
             for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; ss += d * d; }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_e + eps);       // (correctly rounded forms: this mode is about accuracy)
+    const float var_e = wave_sum(ss);
+    // range guard of precision 'half': a stream value past fp16's 65 504 arrives here as inf / NaN (esme_gemm_fusion_t.overflow_flag)
+    if (ovf && lane == 0 && !(var_e < 3.0e38f)) atomicOr(ovf, 1);
+    const float rstd = 1.0f / sqrtf(var_e * inv_e + eps);       // (correctly rounded forms: this mode is about accuracy)
     u16* yr = y + row * ldy;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -876,8 +880,9 @@ extern "C" int esme_hip_layernorm_f32(const float* x, int64_t ldx, const void* w
     return check_launch("layernorm_f32");
 }
 
-extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b, void* y,
-                                        int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E, float eps, void* stream) {
+extern "C" int esme_hip_layernorm_split_checked(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b, void* y,
+                                        int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E, float eps, int* overflow_flag,
+                                        void* stream) {
     ESME_CHECK_ARG(T >= 0 && E > 0, "layernorm_split: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(x && w && y, "layernorm_split: null pointer");
@@ -888,9 +893,9 @@ extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair,
                    "layernorm_split: misaligned");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_LNS(N) do { if (in_pair == 2) hipLaunchKernelGGL((layernorm_split_kernel<N, 2>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); \
-                         else if (in_pair) hipLaunchKernelGGL((layernorm_split_kernel<N, 1>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); \
-                         else hipLaunchKernelGGL((layernorm_split_kernel<N, 0>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps); } while (0)
+#define ESME_LNS(N) do { if (in_pair == 2) hipLaunchKernelGGL((layernorm_split_kernel<N, 2>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps, overflow_flag); \
+                         else if (in_pair) hipLaunchKernelGGL((layernorm_split_kernel<N, 1>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps, overflow_flag); \
+                         else hipLaunchKernelGGL((layernorm_split_kernel<N, 0>), grid, block, 0, s, x, ldx, in_off, (const u16*)w, (const u16*)b, (u16*)y, ldy, out_off, y32, ld32, T, E, eps, overflow_flag); } while (0)
     if (E <= 512) ESME_LNS(1);
     else if (E <= 1024) ESME_LNS(2);
     else if (E <= 1536) ESME_LNS(3);
@@ -899,6 +904,11 @@ extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair,
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "layernorm_split: E > 5120 unsupported");
 #undef ESME_LNS
     return check_launch("layernorm_split");
+}
+
+extern "C" int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b, void* y,
+                                        int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E, float eps, void* stream) {
+    return esme_hip_layernorm_split_checked(x, ldx, in_pair, in_off, w, b, y, ldy, out_off, y32, ld32, T, E, eps, nullptr, stream);
 }
 
 static int rotary_split_impl(const bool f16, void* x, int64_t ld, int64_t lo_off, const float* cosT, const float* sinT, const int32_t* pos,

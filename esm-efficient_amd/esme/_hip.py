@@ -29,7 +29,7 @@ class GemmFusion(Structure):
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int),
                 ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64), ('f16', c_int),
                 ('pair_scale_in', c_void_p), ('pair_scale_out', c_void_p),
-                ('ext_sel', c_void_p), ('ext_n', c_int), ('ext_off', c_int64), ('pair_cols', c_int)]
+                ('ext_sel', c_void_p), ('ext_n', c_int), ('ext_off', c_int64), ('pair_cols', c_int), ('overflow_flag', c_void_p)]
 
 
 class GemmOpts(Structure):
@@ -58,7 +58,7 @@ class ModelDesc(Structure):
                    ('layers', POINTER(LayerWeights))]
                 + [(n, c_void_p) for n in ('final_ln_w', 'final_ln_b', 'head_dense_w', 'head_dense_b', 'head_ln_w',
                                            'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')]
-                + [('half_ext_n', c_int), ('half_ext_sel', c_void_p), ('half_qk_pair', c_int)])
+                + [('half_ext_n', c_int), ('half_ext_sel', c_void_p), ('half_qk_pair', c_int), ('half_overflow_flag', c_void_p)])
 
 
 # name -> (restype, argtypes); must list every symbol include/esme_hip.h declares
@@ -101,6 +101,8 @@ SIGNATURES = {
                                        c_float, c_void_p]),
     'esme_hip_layernorm_split': (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                          c_int64, c_int64, c_int, c_float, c_void_p]),
+    'esme_hip_layernorm_split_checked': (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                         c_int64, c_int64, c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_attn_varlen_fwd_split': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                                c_int, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_rotary_split': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
@@ -581,7 +583,7 @@ def layernorm_f32(x32: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
 
 def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float, dim: int,
                     out: Optional[torch.Tensor] = None, out32: Optional[torch.Tensor] = None, in_off: Optional[int] = None,
-                    out_off: Optional[int] = None) -> torch.Tensor:
+                    out_off: Optional[int] = None, overflow_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Split-operand ('exact') mode: LayerNorm over `dim` features in fp32 -> (T, 2*dim) bf16 pair [hi | lo] (+ fp32 copy in
     `out32`).  x: fp32 (T, dim), or a bf16 pair (T, 2*dim) read as hi + lo.  `in_off` / `out_off` (elements; default `dim`): where
     the lo half sits relative to the hi half when x / out are the hi views of a wider pair buffer (the q block of a (T, 6E)
@@ -603,10 +605,11 @@ def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     if out32 is not None:
         zp, ldz = _rows2d(out32, 'layernorm_split out32', torch.float32)
     with _Traced('layernorm_split', (T, dim)):
-        _check(load().esme_hip_layernorm_split(xp, ldx, pair_in, dim if in_off is None else int(in_off),
-                                               _dev(weight, 'layernorm weight', torch.bfloat16),
-                                               _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
-                                               yp, ldy, dim if out_off is None else int(out_off), zp, ldz, T, dim, float(eps), _stream()),
+        _check(load().esme_hip_layernorm_split_checked(xp, ldx, pair_in, dim if in_off is None else int(in_off),
+                                                       _dev(weight, 'layernorm weight', torch.bfloat16),
+                                                       _dev(bias, 'layernorm bias', torch.bfloat16) if bias is not None else None,
+                                                       yp, ldy, dim if out_off is None else int(out_off), zp, ldz, T, dim, float(eps),
+                                                       _dev(overflow_flag, 'overflow flag', torch.int32) if overflow_flag is not None else None, _stream()),
                'esme_hip_layernorm_split')
     return out
 
@@ -812,7 +815,9 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         rp, ldr = _rows2d(resid, 'gemm resid', dt if resid_pair is not None else torch.bfloat16)
     tag = epilogue
     if ln is not None:
-        part, dim, eps, c1, c2 = ln
+        part, dim, eps, c1, c2 = ln[:5]
+        if len(ln) > 5 and ln[5] is not None:             # the range guard of precision 'half' (esme_gemm_fusion_t.overflow_flag)
+            fu.overflow_flag = _dev(ln[5], 'overflow flag', torch.int32)
         if part.dim() != 3 or part.shape[1] != M or part.shape[2] != 2 or c1.numel() != N or c2.numel() != N or not part.is_contiguous():
             raise ValueError('gemm: LN-fold tensors have the wrong shape')
         fu.ln_partial, fu.ln_nblk, fu.ln_dim, fu.ln_eps = _dev(part, 'ln partial', torch.float32), part.shape[0], int(dim), float(eps)

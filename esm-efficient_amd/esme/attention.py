@@ -48,12 +48,13 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe', 'ovf')
 
     def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False, plan=None):
         self.pos, self.cos, self.sin = pos, cos, sin
         self.plan = plan            # precision 'half': HalfPlan (which robustness measures this model needs) or None
         self.probe = None           # calibration forward: list collecting a per-layer upper bound of |attention score|
+        self.ovf = None             # precision 'half': int32 device flag of the run-time range guard (esme_gemm_fusion_t.overflow_flag)
         self.f16 = f16              # precision 'half': IEEE fp16 MFMA operands (weights converted once, activations rounded to fp16)
         self.fold = fold            # run the LN-folded fast path
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
@@ -407,7 +408,7 @@ class FlashMultiheadAttention(nn.Module):
             if self.pre_layernorm or d not in (16, 32, 64) or E % 128 != 0:
                 raise NotImplementedError("precision='half' with q/k pairs covers ESM-2 / ESM-1 blocks with head dim 16 / 32 / 64 and a 128-aligned width")
             wf, _, c1, c2 = self._weights_qkv(True, True, pair_ext)
-            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), pair_out=True, pair_cols=2 * E)
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2, ctx.ovf), pair_out=True, pair_cols=2 * E)
             if self.rot_emb is not None:
                 _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
             if ctx.probe is not None:
@@ -418,7 +419,7 @@ class FlashMultiheadAttention(nn.Module):
                                    pair_scale=pair_scale, pair_ext=pair_ext)
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True, f16, pair_ext)
-            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2), rot=rot,
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2, ctx.ovf if ctx is not None else None), rot=rot,
                                   q_scale=_q_scale(self.head_dim) if (qp and rot_fusable) else 0.0)
         else:
             if self.padded:
@@ -616,12 +617,12 @@ class FlashTransformerLayer(nn.Module):
             return self._down_pad
         return down.weight, down.bias
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None, pair_ext=None):
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None, pair_ext=None, ovf=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         f16 = x.dtype == torch.float16                       # precision 'half': the operand type travels with the tensors
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_up(True, f16, pair_ext)
-            u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, self.embed_dim, self.final[0].eps, c1, c2))
+            u = _hip.gemm_fused(x, wf, None, epi, ln=(x_stats, self.embed_dim, self.final[0].eps, c1, c2, ovf))
         else:
             w, b, _, _ = self._weights_up(False)
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
@@ -653,7 +654,8 @@ class FlashTransformerLayer(nn.Module):
             ext = ctx.plan.ext_sel if ctx.plan is not None else None      # massive channels: x16 is then [hi | ext] (K = E + 64), the pair (T, 2E + 64)
         self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
                        resid32=r32, resid_pair=rp, pair_scale=sa, pair_ext=ext)
-        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf, pair_ext=ext)
+        self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf, pair_ext=ext,
+                  ovf=ctx.ovf)
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):

@@ -114,6 +114,22 @@ class ModelDescriptor:
         return True
 
 
+def _workspace(model, key, nbytes, device):
+    """The C entry's scratch: one buffer per (device, stream[, mode]), kept on the model and grown on demand (two streams never share
+    one).  While a hipGraph is being CAPTURED the buffer is allocated per call instead: it then lives in the capturing graph's private
+    pool and is owned by that graph -- a cached buffer would be baked into every graph captured on the (always identical) capture stream
+    while belonging to the first one's pool, and be freed under the others when that graph is evicted."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    pool = model.__dict__.setdefault('_cws', {})
+    ws = pool.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(pool) >= 8:                 # short-lived streams must not pile buffers up: start over (the allocator recycles them)
+            pool.clear()
+        ws = pool[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    return ws
+
+
 def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
     """In place on x (T, phys_dim): all layers + final LayerNorm through ONE C call."""
     lib = _bind()
@@ -127,13 +143,7 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
     T = x.shape[0]
     nbytes = int(lib.esme_hip_forward_workspace_bytes(ctypes.byref(d), T))
     # workspace: one buffer per (device, stream), kept on the model and grown on demand (two streams never share one)
-    key = (x.device.index, _hip._stream())
-    pool = model.__dict__.setdefault('_cws', {})
-    ws = pool.get(key)
-    if ws is None or ws.numel() < nbytes:
-        if len(pool) >= 8:                 # short-lived streams must not pile buffers up: start over (the allocator recycles them)
-            pool.clear()
-        ws = pool[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    ws = _workspace(model, (x.device.index, _hip._stream()), nbytes, x.device)
     _hip._check(lib.esme_hip_forward(ctypes.byref(d), _hip._dev(x, 'forward x', torch.bfloat16), x.stride(0),
                                      _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
                                      _ptr(pos), ws.data_ptr(), ws.numel(), None, 0, _hip._stream()), 'esme_hip_forward')
@@ -141,7 +151,7 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
 
 
 
-def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None):
+def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None, ovf=None):
     """precision 'half': fp32 stream at the start `x32` (T, phys_dim) -> all layers + final LayerNorm through ONE C call
     (esme_hip_forward_half); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32.
     `plan`: the model's HalfPlan (cos / sin are float32 tables when it asks for q / k pairs)."""
@@ -153,15 +163,10 @@ def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32
     d = md.desc
     d.cos, d.sin = _ptr(cos), _ptr(sin)
     d.table_len = int(cos.shape[0]) if cos is not None else 0
+    d.half_overflow_flag = _ptr(ovf)                  # the run-time range guard (model.check_overflow reads it)
     T = x32.shape[0]
     nbytes = int(lib.esme_hip_forward_half_workspace_bytes(ctypes.byref(d), T))
-    key = (x32.device.index, _hip._stream(), 'half')
-    pool = model.__dict__.setdefault('_cws', {})
-    ws = pool.get(key)
-    if ws is None or ws.numel() < nbytes:
-        if len(pool) >= 8:
-            pool.clear()
-        ws = pool[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x32.device)
+    ws = _workspace(model, (x32.device.index, _hip._stream(), 'half'), nbytes, x32.device)
     _hip._check(lib.esme_hip_forward_half(ctypes.byref(d), _hip._dev(x32, 'forward x32', torch.float32), x32.stride(0),
                                           _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
                                           _ptr(pos), ws.data_ptr(), ws.numel(), _hip._dev(pair, 'forward pair', torch.bfloat16), pair.stride(0),

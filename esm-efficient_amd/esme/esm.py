@@ -255,7 +255,32 @@ class ESM2(nn.Module):
         ctx = ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high',
                              f16=self.precision == 'half', plan=plan)
         ctx.probe = getattr(self, '_calib_probe', None)
+        if self.precision == 'half':
+            ctx.ovf = self._overflow_flag(device)
         return ctx
+
+    # -- run-time range guard of precision 'half' --------------------------------------------------------------------
+    def _overflow_flag(self, device):
+        """int32 device flag the LayerNorm-folded GEMMs / the final LayerNorm set when a row's statistics are not finite."""
+        f = getattr(self, '_half_ovf', None)
+        if f is None or f.device != torch.device(device):
+            f = self._half_ovf = torch.zeros(1, dtype=torch.int32, device=device)
+        return f
+
+    def check_overflow(self):
+        """Raise OverflowError if a forward in precision 'half' since the last call saw a value leave IEEE fp16's range (|x| >= 65 504 in the
+        residual stream, q / k / v or the FFN intermediate: it becomes inf, the result NaN).  Synchronises with the device; the flag is
+        cleared.  predict_log_prob / predict_prob call it (their result is about to be read anyway); `model(...)` / `forward_representation`
+        do not synchronise -- call it yourself before trusting their output, or read NaNs.  The bf16 modes ('fast', 'high', 'exact') have
+        bf16's range (= fp32's) and nothing to check."""
+        f = getattr(self, '_half_ovf', None)
+        if f is None or torch.cuda.is_current_stream_capturing():
+            return self
+        if int(f.item()) != 0:
+            f.zero_()
+            raise OverflowError("precision='half': an activation left IEEE fp16's range (|x| >= 65 504) during a forward; the result holds "
+                                "inf / NaN.  Use precision 'exact' (bf16 pairs, fp32's range) for this checkpoint / input.")
+        return self
 
     def _unpad(self, x, tokens):
         """Boolean-mask row gather: the `unpad_input` contract (esm.py:238)."""
@@ -346,7 +371,7 @@ class ESM2(nn.Module):
                 alloc = torch.zeros if self.padded else torch.empty
                 pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
                 x = alloc(T, Ep, dtype=torch.float32, device=x.device)
-                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan)
+                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan, ctx.ovf)
                 if want_pair:
                     x = pair
                 return self._finish_representation(x, [], pad_output, pad_args, pad_indices, cu_lens, pad_width)
@@ -373,7 +398,7 @@ class ESM2(nn.Module):
             alloc = torch.zeros if self.padded else torch.empty
             pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
             x = alloc(T, Ep, dtype=torch.float32, device=x.device)
-            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x, in_off=Ep + ext, out_off=Ep)
+            _hip.layernorm_split(ctx.xs, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x, in_off=Ep + ext, out_off=Ep, overflow_flag=ctx.ovf)
             if want_pair:
                 x, taps = pair, []
         elif self.precision == 'high' and len(self.layers):
@@ -420,12 +445,18 @@ class ESM2(nn.Module):
 
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
+            y = _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
+            if self.precision == 'half':
+                self.check_overflow()
+            return y
 
     def predict_prob(self, tokens, log=False, pad_args=None, pad_output=False, pad_indices=None,
                      lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            return _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
+            y = _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
+            if self.precision == 'half':
+                self.check_overflow()
+            return y
 
     def graphed(self, tokens, pad_args, what: str = 'forward', clone: bool = True):
         """`getattr(self, what)(tokens, pad_args)` replayed from a hipGraph captured on first use of this

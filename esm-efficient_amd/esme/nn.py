@@ -34,6 +34,13 @@ class _TrackedModule(nn.Module):
             bump_epoch()
         super().__setattr__(name, value)
 
+    def _apply(self, fn, *a, **kw):
+        """`.to()` / `.cuda()` / dtype casts on a SUBMODULE move its storage without going through ESM2._apply: bump the epoch here too, so
+        that descriptors holding raw pointers to copies derived from the old storage are rebuilt."""
+        out = super()._apply(fn, *a, **kw)
+        bump_epoch()
+        return out
+
 
 class Linear(_TrackedModule):
     """y = x W^T + b on the bf16 MFMA GEMM (replaces nn.Linear on the path)."""

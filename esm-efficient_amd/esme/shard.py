@@ -68,12 +68,29 @@ def gather_rows_all_ranks(local: torch.Tensor, counts: Sequence[int], group=None
     return torch.cat([recv[r * tmax:r * tmax + counts[r]] for r in range(world)])
 
 
-def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], torch.Tensor],
-                    tokens: torch.Tensor, cu_lens: torch.Tensor, device, group=None) -> torch.Tensor:
-    """Run `forward(tokens_r, (cu_lens_r, max_len_r))` on this rank's share of the packed
-    batch and return the logits of the WHOLE batch, in input order, on every rank.
+def _output_spec(forward, out_width, out_dtype):
+    """(width, dtype) of `forward`'s rows for a rank that has no sequence to run.  Both are known locally -- from the arguments, or from
+    the model when `forward` is a model or a bound method of one (vocab_size; fp32 logits in precision 'exact' / 'half', bf16
+    otherwise) -- so no collective is spent on them."""
+    model = forward if hasattr(forward, 'vocab_size') else getattr(forward, '__self__', None)
+    if model is not None and hasattr(model, 'vocab_size'):
+        if out_width is None:
+            out_width = model.vocab_size
+        if out_dtype is None:
+            out_dtype = torch.float32 if getattr(model, 'precision', 'fast') in ('exact', 'half') else torch.bfloat16
+    if out_width is None or out_dtype is None:
+        raise ValueError('sharded_forward: a rank without sequences needs out_width / out_dtype (pass them, or pass the model / a bound model method)')
+    return int(out_width), out_dtype
 
-    `tokens` / `cu_lens` are the full (host) batch, identical on all ranks.
+
+def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], torch.Tensor],
+                    tokens: torch.Tensor, cu_lens: torch.Tensor, device, group=None,
+                    out_width: int = None, out_dtype=None) -> torch.Tensor:
+    """Run `forward(tokens_r, (cu_lens_r, max_len_r))` on this rank's share of the packed
+    batch and return the logits of the WHOLE batch, in input order, on every rank.  ONE collective: the logits all-gather.
+
+    `tokens` / `cu_lens` are the full (host) batch, identical on all ranks.  `out_width` / `out_dtype`: shape of `forward`'s rows,
+    needed only by a rank that receives no sequence (fewer sequences than ranks) when `forward` is not a model / bound model method.
     """
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -86,11 +103,9 @@ def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], 
         out_r = forward(tok_r.to(device), (cu_r.to(device), max_r))
     else:
         out_r = None
-    # (width, 1 if the logits are fp32 -- precision 'exact' -- else 0): a rank without sequences learns both from the others
-    meta = torch.tensor([0, 0] if out_r is None else [out_r.shape[1], int(out_r.dtype == torch.float32)], device=device)
-    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
-    if out_r is None:
-        out_r = torch.zeros(0, int(meta[0].item()), dtype=torch.float32 if int(meta[1].item()) else torch.bfloat16, device=device)
+    if out_r is None:                                     # width and dtype are known locally: no second collective
+        width, dtype = _output_spec(forward, out_width, out_dtype)
+        out_r = torch.zeros(0, width, dtype=dtype, device=device)
     gathered = gather_rows_all_ranks(out_r, counts, group)
     # gathered holds rank 0's sequences, then rank 1's, ...: build the inverse permutation
     src = np.concatenate([np.arange(cu[i], cu[i + 1]) for p in plan for i in p]) if len(lengths) else np.zeros(0, int)

@@ -221,6 +221,11 @@ int esme_hip_attn_varlen_fwd_exact(const void* q, const void* k, const void* v, 
 int esme_hip_layernorm_split(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b,
                              void* y, int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E,
                              float eps, void* stream);
+/* The same with the range guard of precision 'half': *overflow_flag (int32, device; NULL = off) is set to 1 when a row's variance is not
+ * finite (see esme_gemm_fusion_t.overflow_flag). */
+int esme_hip_layernorm_split_checked(const void* x, int64_t ldx, int in_pair, int64_t in_off, const void* w, const void* b,
+                                     void* y, int64_t ldy, int64_t out_off, float* y32, int64_t ld32, int64_t T, int E,
+                                     float eps, int* overflow_flag, void* stream);
 
 /* esme_hip_attn_varlen_fwd with every MFMA operand as a (hi, lo) pair: S = Qh Kh^T + Qh Kl^T + Ql Kh^T, P split in registers,
  * O = Ph Vh + Ph Vl + Pl Vh, classic online softmax with exact row maxima, fp32 row sums; q / k / v: hi at the pointer, lo
@@ -349,7 +354,7 @@ typedef struct esme_gemm_fusion {
     float q_scale;               /* see above: fused rotary only; 0 = off */
     int q_cols;
     /* split-operand ('exact') mode -- see below */
-    int w_k;                     /* K of W when A = [hi | lo | ...] repeats it: W is (N, w_k), K a multiple of w_k; 0 = K */
+    int w_k;                     /* K of W when A = [hi | lo] repeats it: W is (N, w_k), K = 2 w_k (or w_k); 0 = K */
     int64_t pair_off;            /* != 0: C receives the result as a (hi, lo) bf16 pair, lo at column pair_off + n of the same row */
     float* c32;                  /* != NULL: the result is written in fp32 to c32 (M, N), row stride ldc32, instead of C */
     int64_t ldc32;
@@ -375,6 +380,13 @@ typedef struct esme_gemm_fusion {
      * column pair_off + n -- only for the columns < pair_cols (0 = all; a multiple of 256): q and k of a fused QKV projection as pairs for
      * esme_hip_attn_varlen_fwd_qkpair_f16, v single. */
     int pair_cols;
+    /* LN fold only: int32 on the device (or NULL).  Set to 1 (atomic OR; never cleared by the library) when a row's statistics are not
+     * finite.  The run-time range guard of precision 'half': a residual-stream, q / k / v or FFN-mid value past fp16's 65 504 becomes inf, the
+     * branch that consumes it NaN, and at the latest the next LayerNorm-folded GEMM (or esme_hip_layernorm_split_checked at the end of the
+     * stack) sees non-finite statistics.  Sticky and free on the hot path; the caller reads it at its next natural synchronisation
+     * (the Python package: model.check_overflow(), predict_log_prob / predict_prob).  The reference's bf16 forward has no such hazard
+     * (bf16 has fp32's range: esme/esm.py:268-298). */
+    int* overflow_flag;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
@@ -521,6 +533,7 @@ typedef struct esme_model_desc {
      *       esme_hip_rotary_split_f16 -- cos / sin are then FP32 tables -- and multiplied by esme_hip_attn_varlen_fwd_qkpair_f16
      *       (ESM-2 / ESM-1 blocks, head_pad in {16, 32, 64}, heads * head_pad a multiple of 128). */
     int half_ext_n; const int32_t* half_ext_sel; int half_qk_pair;
+    int* half_overflow_flag;     /* esme_hip_forward_half: the run-time range guard (esme_gemm_fusion_t.overflow_flag), int32 on the device or NULL */
 } esme_model_desc_t;
 
 int64_t esme_hip_forward_workspace_bytes(const esme_model_desc_t* model, int64_t T);

@@ -222,3 +222,35 @@ def test_half_plan_on_benign_weights_is_the_plain_form():
     assert model.half_plan().qk_pair and rel_fro(forced.cpu(), ref) <= 1e-3 and rel_fro(auto.cpu(), ref) <= 1e-3
     g = model.graphed(*args, 'forward')                    # the q/k-pair form replays from a hipGraph like the plain one
     assert torch.equal(g, forced)
+
+
+def test_half_mode_range_guard_raises_on_fp16_overflow():
+    """A checkpoint whose FFN-down bias pushes a residual-stream value past fp16's 65 504: the forward itself stays asynchronous (its
+    logits hold NaN), model.check_overflow() and predict_log_prob raise OverflowError instead of handing inf / NaN on, the flag clears, and a
+    healthy forward afterwards is clean.  'exact' (bf16 pairs: fp32's range) runs the same checkpoint."""
+    lengths = [40, 130]
+    tokens, cu = syn.random_tokens(lengths, seed=3).to(DEV), syn.cu_lens_of(lengths).to(DEV)
+    args = (tokens, (cu, max(lengths)))
+    model = build('esm2', 3, 320, 20, seed=4)
+    good = model.set_precision('half', robust=False)(*args)
+    model.check_overflow()                                              # nothing to report
+    with torch.no_grad():
+        model.layers[1].final[3].bias.data[7] = 9.0e4                   # x[7] += 90 000 in layer 1 -> hi = inf
+    model.invalidate_graphs()
+    for c_forward in (True, False):                                     # the C entry and the module-by-module path carry the same flag
+        model.c_forward = c_forward
+        bad = model(*args)
+        assert not torch.isfinite(bad).all()
+        with pytest.raises(OverflowError):
+            model.check_overflow()
+        model.check_overflow()                                          # cleared
+        with pytest.raises(OverflowError):
+            model.predict_log_prob(*args)
+    model.c_forward = True
+    ok = model.set_precision('exact')(*args)
+    assert torch.isfinite(ok).all()
+    with torch.no_grad():
+        model.layers[1].final[3].bias.data[7] = 0.0
+    model.invalidate_graphs()
+    assert torch.isfinite(model.set_precision('half', robust=False)(*args)).all()
+    model.check_overflow()

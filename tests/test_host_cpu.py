@@ -192,7 +192,7 @@ def _worker(rank, world, port, lengths, out_path, dtype=torch.bfloat16):
         out[:, 0] = pos.to(torch.bfloat16)             # position inside its own sequence
         return out.to(dtype)
 
-    full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu')
+    full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu', out_width=8, out_dtype=dtype)     # (known locally: no second collective)
     if rank == 0:
         torch.save(full, out_path)
     dist.barrier()
@@ -218,7 +218,8 @@ def test_sharded_forward_gloo_world2(lengths):
 
 def test_sharded_forward_gloo_world2_fp32_logits_and_an_empty_rank():
     """precision='exact' returns fp32 logits: the gather keeps the dtype, and a rank that received no sequence (one sequence, two
-    ranks) learns width AND dtype from the others instead of contributing bf16 zeros to an fp32 all-gather."""
+    ranks) contributes an empty fp32 block of the right width -- both known locally (the model's vocab_size / precision, or the arguments),
+    not learned through a second collective."""
     from esme import synthetic as syn
     lengths = [11]
     with tempfile.TemporaryDirectory() as td:

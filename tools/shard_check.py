@@ -46,7 +46,7 @@ def main():
     for mode in ('fast', 'half', 'exact'):              # bf16 logits, then the two fp32-logit modes through the same gather
         model.set_precision(mode)
         with torch.no_grad():
-            full = shard.sharded_forward(lambda t, pa: model(t, pa), tokens, cu, dev)
+            full = shard.sharded_forward(model, tokens, cu, dev)
             single = model(tokens.to(dev), (cu.to(dev), max(lengths)))
             graphed = model.graphed(tokens.to(dev), (cu.to(dev), max(lengths)), 'forward')
         torch.cuda.synchronize()
