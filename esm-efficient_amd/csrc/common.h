@@ -156,10 +156,17 @@ __device__ __forceinline__ float gelu_poly(const float z) {
         return fmaf(z, p, -1.0005322694778442f);
     }
 }
+// NaN: v_min / v_max return their non-NaN operand, so the formula maps NaN to 0.  The degree-7 sites (LM head, split-operand mode: not hot)
+// hand a NaN on as torch does -- a NaN representation must not come out of the LM head as finite logits (found by the range-guard test of
+// precision 'half': an overflowed stream gave identical, finite rows); the degree-5 site (the LayerNorm-folded FFN up-projection, where
+// every VALU instruction costs 0.2 ms per step) keeps the bare formula: a NaN there comes from a non-finite residual stream, which the
+// run-time range guard reports (esme_gemm_fusion_t.overflow_flag) and which reaches the output through the attention branch anyway.
 template <int DEG = ESME_GELU_DEG>
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fminf(fabsf(x), 64.0f);
-    return fmaf(-z, __builtin_amdgcn_exp2f(gelu_poly<DEG>(z)), fmaxf(x, 0.0f));
+    const float g = fmaf(-z, __builtin_amdgcn_exp2f(gelu_poly<DEG>(z)), fmaxf(x, 0.0f));
+    if constexpr (DEG == 7) return x != x ? x : g;
+    else return g;
 }
 
 // Two elements at a time on the packed fp32 pipe (v_pk_fma_f32: the same IEEE fma per half, so every result bit equals
@@ -193,7 +200,9 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
     f32x2_t m;                                                      // plain v_max: fmaxf() would add a canonicalising v_max per element
     asm("v_max_f32 %0, 0, %1" : "=v"(m[0]) : "v"(x[0]));
     asm("v_max_f32 %0, 0, %1" : "=v"(m[1]) : "v"(x[1]));
-    return __builtin_elementwise_fma(-z, e, m);
+    f32x2_t g = __builtin_elementwise_fma(-z, e, m);
+    if constexpr (DEG == 7) { g[0] = x[0] != x[0] ? x[0] : g[0]; g[1] = x[1] != x[1] ? x[1] : g[1]; }      // (NaN in, NaN out: see gelu_erf)
+    return g;
 }
 
 // Observed dispatcher policy: block b runs on XCD b % 8.  Remap so each XCD (own L2)

@@ -141,10 +141,9 @@ def test_fuzz_gemm_f16_pair_stream(seed):
     assert err <= 1e-6, f'pair stream M={M} N={N} K={K} tile={tile}: {err:.2e}'
     assert torch.equal(out.cpu(), xs[:, :N].cpu()) and bool((xs[:, 2 * N:] == 7.0).all())
     assert float((xs[:, :N].cpu().double() - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max()) + 1e-6
-    if stats is not None:
-        r = xs[:, :N].cpu().double()
+    if stats is not None:                                # statistics of the fp32 value x = hi + lo (round 5; round 4: of hi)
         st = stats.sum(dim=0).cpu().double()
-        assert torch.allclose(st[:, 0], r.sum(dim=1), atol=5e-3, rtol=1e-5) and torch.allclose(st[:, 1], (r * r).sum(dim=1), rtol=1e-5)
+        assert torch.allclose(st[:, 0], got.sum(dim=1), atol=5e-3, rtol=1e-5) and torch.allclose(st[:, 1], (got * got).sum(dim=1), rtol=1e-5)
 
 
 @pytest.mark.parametrize('seed', range(12))
