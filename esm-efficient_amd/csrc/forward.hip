@@ -204,9 +204,8 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         if (qk_pair) {
             // large attention scores: q / k as fp16 pairs [q k v | q_lo k_lo], rotated with fp32 tables, scores from three MFMA passes
             fu.pair_off = 3 * Ea; fu.pair_cols = (int)(2 * Ea);
+            if (m->rotary) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }     // (fp32 tables)
             ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 5 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
-            if (m->rotary)
-                ESME_TRY(esme_hip_rotary_split_f16(w.qkv, 5 * Ea, 3 * Ea, (const float*)m->cos, (const float*)m->sin, pos, T, 2 * H, dp, m->table_len, stream));
             ESME_TRY(esme_hip_attn_varlen_fwd_qkpair_f16(q, k, v, 5 * Ea, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, aopts.seq_order, stream));
         } else {
             if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     static_assert(!RP || (F16 && EPI == ESME_EPI_RESIDUAL && !R32 && !PAIR && !LNF && ROTD == 0), "pair stream: fp16 residual epilogue");
     // F16 (precision 'half'): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (bias stays bf16, a checkpoint parameter); what
     // changes is the MFMA opcode, the table unpack and the output rounding -- the LDS image, the DMA path and the schedule do not.
-    static_assert(!F16 || ((!PAIR || (LNF && EPI == ESME_EPI_NONE && ROTD == 0)) && (EPI != ESME_EPI_RESIDUAL || R32 || RP)),
+    static_assert(!F16 || ((!PAIR || (LNF && EPI == ESME_EPI_NONE)) && (EPI != ESME_EPI_RESIDUAL || R32 || RP)),
                   "fp16 operands: plain / GELU / SwiGLU epilogues, the fp32- / pair-stream residual epilogues, pair output of the LN-folded plain epilogue");
     static_assert(!LNF || EPI != ESME_EPI_RESIDUAL, "LN fold applies to the consumers of a LayerNorm");
     static_assert(!R32 || EPI == ESME_EPI_RESIDUAL, "the fp32 residual stream belongs to the residual epilogue");
@@ -223,8 +223,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
     // into the stage buffer that is no longer being refilled, once per row group (the WN waves that share the
     // rows split the instructions), so the epilogue finds them in LDS instead of waiting ~2 us for them.
     // Layout per row group: [row][cos half | sin half], TB = 2*ROTD bytes per row, 16-B chunks XOR-swizzled.
-    constexpr int CPRW = ROTD > 0 ? ROTD / 8 : 1;            // 16-B chunks per table row
-    constexpr int TB = 2 * ROTD;                             // bytes per table row
+    // ROT32: a PAIR output is rotated with FP32 tables (the pair carries 16-22 bits; a 16-bit table entry would cap it at 8-11:
+    // esme_hip_rotary_split's reason) -- twice the table bytes, the same prefetch.
+    constexpr bool ROT32 = PAIR && ROTD > 0;
+    constexpr int CPRW = ROTD > 0 ? (ROT32 ? ROTD / 4 : ROTD / 8) : 1;      // 16-B chunks per table row
+    constexpr int TB = (ROT32 ? 4 : 2) * ROTD;                             // bytes per table row
     constexpr int TAB_INSTR = WTM * CPRW / 64;               // DMA instructions per row group
     constexpr int TAB_PER_WAVE = (TAB_INSTR + WN - 1) / WN;
     auto rot_prefetch = [&](int fb, int h) {
@@ -241,8 +244,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 const int r = idx / CPRW;
                 const int c = (idx % CPRW) ^ (r & (CPRW - 1));
                 const int p = lpos[wm * WTM + r];
-                const u16* src = (c < CPRW / 2) ? a.cosT + (int64_t)p * ROTD + c * 8
-                                                : a.sinT + (int64_t)p * ROTD + (c - CPRW / 2) * 8;
+                const void* src;
+                if constexpr (ROT32) src = (c < CPRW / 2) ? reinterpret_cast<const float*>(a.cosT) + (int64_t)p * ROTD + c * 4
+                                                          : reinterpret_cast<const float*>(a.sinT) + (int64_t)p * ROTD + (c - CPRW / 2) * 4;
+                else src = (c < CPRW / 2) ? a.cosT + (int64_t)p * ROTD + c * 8
+                                          : a.sinT + (int64_t)p * ROTD + (c - CPRW / 2) * 8;
                 ESME_LDS_CHECK(tab + g * 1024, 1024, smem, 2 * STAGE);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tab + g * 1024), 16, 0, 0);
             }
@@ -608,13 +614,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
                 const int r = j * 16 + l15;
-                const char* trow = tab + r * TB + (lq & 1) * 8;          // this lane's 4 columns are half (lq & 1) of a 16-B table chunk
+                const char* trow = tab + r * TB + (ROT32 ? 0 : (lq & 1) * 8);          // 16-bit tables: this lane's 4 columns are half (lq & 1) of a 16-B chunk; fp32: a whole chunk
                 if constexpr (ROTD == 16) {
                     // one fragment = one head: column 4 lq + e pairs with 4 (lq ^ 2) + e, i.e. the same register of lane ^ 32
-                    const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((0 ^ (r & 1)) << 4));
-                    const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + ((1 ^ (r & 1)) << 4));
-                    const float cv[4] = {lo16<F16>(cw[0]), hi16<F16>(cw[0]), lo16<F16>(cw[1]), hi16<F16>(cw[1])};
-                    const float sv[4] = {lo16<F16>(sw[0]), hi16<F16>(sw[0]), lo16<F16>(sw[1]), hi16<F16>(sw[1])};
+                    float cv[4], sv[4];
+                    if constexpr (ROT32) {
+                        const f32x4 cq = *reinterpret_cast<const f32x4*>(trow + (((lq & 1) ^ (r & 3)) << 4));
+                        const f32x4 sq = *reinterpret_cast<const f32x4*>(trow + (((2 + (lq & 1)) ^ (r & 3)) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { cv[e] = cq[e]; sv[e] = sq[e]; }
+                    } else {
+                        const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((0 ^ (r & 1)) << 4));
+                        const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + ((1 ^ (r & 1)) << 4));
+                        cv[0] = lo16<F16>(cw[0]); cv[1] = hi16<F16>(cw[0]); cv[2] = lo16<F16>(cw[1]); cv[3] = hi16<F16>(cw[1]);
+                        sv[0] = lo16<F16>(sw[0]); sv[1] = hi16<F16>(sw[0]); sv[2] = lo16<F16>(sw[1]); sv[3] = hi16<F16>(sw[1]);
+                    }
 #pragma unroll
                     for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -632,11 +646,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     const int hc = (i * 16) % ROTD;           // first column of the fragment inside its head
                     if (hc >= HALF) continue;                 // upper half of a head: handled with its partner
                     const int i2 = i + HALF / 16;             // partner fragment (same lane, same column quad)
-                    const int cc = (hc >> 3) + (lq >> 1);     // cos chunk of the lane's quad; the sin chunk sits CPRW/2 further
-                    const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((cc ^ (r & (CPRW - 1))) << 4));
-                    const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + (((cc + CPRW / 2) ^ (r & (CPRW - 1))) << 4));
-                    const float cv[4] = {lo16<F16>(cw[0]), hi16<F16>(cw[0]), lo16<F16>(cw[1]), hi16<F16>(cw[1])};
-                    const float sv[4] = {lo16<F16>(sw[0]), hi16<F16>(sw[0]), lo16<F16>(sw[1]), hi16<F16>(sw[1])};
+                    const int cc = ROT32 ? (hc >> 2) + lq : (hc >> 3) + (lq >> 1);     // cos chunk of the lane's quad; the sin chunk sits CPRW/2 further
+                    float cv[4], sv[4];
+                    if constexpr (ROT32) {
+                        const f32x4 cq = *reinterpret_cast<const f32x4*>(trow + ((cc ^ (r & (CPRW - 1))) << 4));
+                        const f32x4 sq = *reinterpret_cast<const f32x4*>(trow + (((cc + CPRW / 2) ^ (r & (CPRW - 1))) << 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { cv[e] = cq[e]; sv[e] = sq[e]; }
+                    } else {
+                        const u32x2 cw = *reinterpret_cast<const u32x2*>(trow + ((cc ^ (r & (CPRW - 1))) << 4));
+                        const u32x2 sw = *reinterpret_cast<const u32x2*>(trow + (((cc + CPRW / 2) ^ (r & (CPRW - 1))) << 4));
+                        cv[0] = lo16<F16>(cw[0]); cv[1] = hi16<F16>(cw[0]); cv[2] = lo16<F16>(cw[1]); cv[3] = hi16<F16>(cw[1]);
+                        sv[0] = lo16<F16>(sw[0]); sv[1] = hi16<F16>(sw[0]); sv[2] = lo16<F16>(sw[1]); sv[3] = hi16<F16>(sw[1]);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = acc[i][j][e], up = acc[i2][j][e];
@@ -1132,8 +1154,15 @@ static int launch_gemm(GemmArgs& a, int epi, int rotd, bool lnf, bool stats, hip
         }
 #undef ESME_LP
     }
-    if (a.f16 && a.pair_off && epi == ESME_EPI_NONE)     // precision 'half', q / k as pairs: the LN-folded projection writes (hi, lo) (checked by the caller)
-        return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 0, true, false, false, false, true, true>(a, s);
+    if (a.f16 && a.pair_off && epi == ESME_EPI_NONE) {   // precision 'half', q / k as pairs: the LN-folded projection writes (hi, lo), rotated with fp32 tables (checked by the caller)
+        switch (rotd) {
+            case 0: return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 0, true, false, false, false, true, true>(a, s);
+            case 16: return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 16, true, false, false, false, true, true>(a, s);
+            case 32: return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 32, true, false, false, false, true, true>(a, s);
+            case 64: return launch_one<BM, BN, WM, WN, ESME_EPI_NONE, 64, true, false, false, false, true, true>(a, s);
+            default: return fail(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs head dim 16, 32 or 64");
+        }
+    }
     if (a.f16) {                                    // precision 'half': fp16 operands (checked by the caller: residual epilogue only on the fp32 stream)
 #define ESME_LH(E, R, L, S, R32) launch_one<BM, BN, WM, WN, E, R, L, S, false, R32, false, true>(a, s)
         switch (epi) {
@@ -1257,7 +1286,7 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
                    "gemm: pair_scale_in / pair_scale_out / ext_* belong to the fp16 pair stream's residual epilogue");
     ESME_CHECK_ARG(!fu || !fu->pair_cols || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_NONE), "gemm: pair_cols belongs to the fp16 pair output");
     if (fu && fu->f16 && fu->pair_off && epilogue == ESME_EPI_NONE) {   // precision 'half', q / k as pairs: pair output of the LN-folded plain projection
-        ESME_CHECK_ARG(fu->ln_partial && !fu->head_dim && !r32 && !fu->w_k && !fu->c32 && !fu->stats_out, "gemm: the fp16 pair output belongs to the LN-folded plain epilogue (no fused rotary)");
+        ESME_CHECK_ARG(fu->ln_partial && !r32 && !fu->w_k && !fu->c32 && !fu->stats_out, "gemm: the fp16 pair output belongs to the LN-folded plain epilogue");
         ESME_CHECK_ARG(fu->pair_off >= N && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + (fu->pair_cols > 0 ? fu->pair_cols : N) && fu->pair_cols >= 0 && fu->pair_cols % 256 == 0,
                        "gemm: pair_off must be a multiple of 8 with N <= pair_off and room for the lo columns; pair_cols a multiple of 256");
         if (!vec_ok) ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: pair output needs a 16-byte addressable C and N % 8 == 0");
@@ -1308,6 +1337,7 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
             if (N % 64 != 0 || fu->rot_cols % 64 != 0 || fu->rot_cols < 0 || fu->rot_cols > N || !vec_ok)
                 ESME_FAIL(ESME_ERR_UNSUPPORTED, "gemm: fused rotary needs N, rot_cols multiples of 64, rot_cols <= N, 16-byte addressable C");
             ESME_CHECK_ARG(aligned16(fu->cos) && aligned16(fu->sin), "gemm: misaligned rotary tables");
+            ESME_CHECK_ARG(!fu->pair_off || fu->q_scale == 0.f, "gemm: q_scale does not combine with a pair output");      // (a pair output is rotated with FP32 tables)
             a.cosT = (const u16*)fu->cos; a.sinT = (const u16*)fu->sin; a.pos = fu->pos;
             a.max_len = fu->max_len; a.rot_cols = fu->rot_cols;
             rotd = fu->head_dim;

@@ -759,7 +759,7 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     (out is (M, N + pair_cols); 0 = all): q and k of a fused QKV projection as pairs."""
     f16 = a.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
-    if f16 and (split_a or out32 is not None or (pair_out and (ln is None or epilogue != EPI_NONE or rot is not None))):
+    if f16 and (split_a or out32 is not None or (pair_out and (ln is None or epilogue != EPI_NONE))):
         raise ValueError('gemm: float16 operands do not combine with the split-operand arguments (pair_out: the LN-folded plain epilogue only)')
     ap, lda = _rows2d(a, 'gemm a', dt)
     if not w.is_contiguous():
@@ -828,7 +828,8 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         fu.stats_out = _dev(stats_out, 'stats_out', torch.float32)
     if rot is not None:
         cos, sin, pos, head_dim, rot_cols = rot
-        fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', dt), _dev(sin, 'sin', dt), _dev(pos, 'pos', torch.int32)
+        tdt = torch.float32 if pair_out else dt                   # a pair output is rotated with fp32 tables
+        fu.cos, fu.sin, fu.pos = _dev(cos, 'cos', tdt), _dev(sin, 'sin', tdt), _dev(pos, 'pos', torch.int32)
         fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
         if q_scale:
             fu.q_scale, fu.q_cols = float(q_scale), int(rot_cols) // 2

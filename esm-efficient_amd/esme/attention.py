@@ -408,9 +408,8 @@ class FlashMultiheadAttention(nn.Module):
             if self.pre_layernorm or d not in (16, 32, 64) or E % 128 != 0:
                 raise NotImplementedError("precision='half' with q/k pairs covers ESM-2 / ESM-1 blocks with head dim 16 / 32 / 64 and a 128-aligned width")
             wf, _, c1, c2 = self._weights_qkv(True, True, pair_ext)
-            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2, ctx.ovf), pair_out=True, pair_cols=2 * E)
-            if self.rot_emb is not None:
-                _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
+            qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2, ctx.ovf), pair_out=True, pair_cols=2 * E,
+                                  rot=(ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if self.rot_emb is not None else None)     # (fp32 tables, in the epilogue)
             if ctx.probe is not None:
                 ctx.probe.append(_score_bound(qkv[:, :E], qkv[:, E:2 * E], H, d, self.head_dim ** -0.5))
             a = _hip.attn_varlen_qkpair(qkv, cu_lens, max_len, H, d, self.head_dim ** -0.5, order=ctx.order)
@@ -690,11 +689,13 @@ class FlashTransformerLayer(nn.Module):
         # ---- attention branch
         _hip.layernorm_split(x32, att.norm.weight, att.norm.bias, att.norm.eps, E, out=h)
         w, b, _, _ = att._weights_qkv(False)
-        _hip.gemm_fused(h, w, b, out=qkv, split_a=True, pair_out=True)
+        rot_fused = att.rot_emb is not None and not att.pre_layernorm and d in (16, 32, 64) and E % 64 == 0
+        # rotary with fp32 tables (the reference's fp32 forward has them) in the projection's pair epilogue (round 5; rounds 3-4: a pass of its own)
+        _hip.gemm_fused(h, w, b, out=qkv, split_a=True, pair_out=True, rot=(ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fused else None)
         if att.pre_layernorm:             # ESM-C: q / k LayerNorm over the full width, pair in -> pair out, in place (attention.py:104-105)
             for blk, ln in ((qkv[:, :E], att.layernorm_q), (qkv[:, E:2 * E], att.layernorm_k)):
                 _hip.layernorm_split(blk, ln.weight, ln.bias, ln.eps, E, out=blk, in_off=3 * E, out_off=3 * E)
-        if att.rot_emb is not None:       # fp32 tables (the reference's fp32 forward has them): a pass of its own, not the bf16-table epilogue
+        if att.rot_emb is not None and not rot_fused:       # ESM-C (the q / k LayerNorm sits between projection and rotation): a pass of its own
             _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
         _hip.attn_varlen_split(qkv, cu_lens, max_len, H, d, att.head_dim ** -0.5, out=h, order=ctx.order)
         wo, bo = att._weights_out()

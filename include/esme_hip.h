@@ -290,7 +290,9 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
                              int rot_cols, void* stream);
 
 /* Optional fusions of esme_hip_gemm_bf16_fused (any subset; zero-initialise the struct):
- *  - rotary:   head_dim in {16,32,64} != 0 -> as esme_hip_gemm_qkv_rotary (ESME_EPI_NONE only);
+ *  - rotary:   head_dim in {16,32,64} != 0 -> as esme_hip_gemm_qkv_rotary (ESME_EPI_NONE only).  With a PAIR output (pair_off != 0: the
+ *              split-operand mode, or precision 'half' with q / k as pairs) cos / sin are FP32 tables, float (max_len, head_dim): the pair
+ *              carries 16-22 bits, a 16-bit table entry would cap it at 8-11 (what esme_hip_rotary_split does as a pass of its own);
  *  - LN fold:  ln_partial != NULL -> the GEMM consumes the RAW residual stream x with gamma-scaled
  *              weights W' = W*diag(gamma) and finishes LayerNorm(x) W^T + b in its epilogue:
  *              y[m,n] = rstd[m]*acc[m,n] - (rstd*mean)[m]*c1[n] + c2[n],
@@ -376,7 +378,7 @@ typedef struct esme_gemm_fusion {
     const int32_t* ext_sel;
     int ext_n;
     int64_t ext_off;
-    /* f16 + pair_off with ESME_EPI_NONE and the LN fold (no fused rotary): the projection's result leaves as an fp16 (hi, lo) pair, lo at
+    /* f16 + pair_off with ESME_EPI_NONE and the LN fold (+ fused rotary with fp32 tables): the projection's result leaves as an fp16 (hi, lo) pair, lo at
      * column pair_off + n -- only for the columns < pair_cols (0 = all; a multiple of 256): q and k of a fused QKV projection as pairs for
      * esme_hip_attn_varlen_fwd_qkpair_f16, v single. */
     int pair_cols;
@@ -529,8 +531,8 @@ typedef struct esme_model_desc {
      * (esme.attention.HalfPlan):
      *   half_ext_n > 0: the half_ext_n <= 64 "massive" stream channels half_ext_sel (int32, device, ascending) ride in an extension K-tile
      *       (esme_gemm_fusion_t.ext_sel): the pair rows are [hi | ext (64) | lo], qkv_w / up_w are (N, phys_dim + 64) = [W' | W'[:, sel] | 0];
-     *   half_qk_pair != 0: q and k leave the QKV projection as fp16 pairs (esme_gemm_fusion_t.pair_cols), are rotated by
-     *       esme_hip_rotary_split_f16 -- cos / sin are then FP32 tables -- and multiplied by esme_hip_attn_varlen_fwd_qkpair_f16
+     *   half_qk_pair != 0: q and k leave the QKV projection as fp16 pairs (esme_gemm_fusion_t.pair_cols), rotated in its epilogue
+     *       -- cos / sin are then FP32 tables -- and are multiplied by esme_hip_attn_varlen_fwd_qkpair_f16
      *       (ESM-2 / ESM-1 blocks, head_pad in {16, 32, 64}, heads * head_pad a multiple of 128). */
     int half_ext_n; const int32_t* half_ext_sel; int half_qk_pair;
     int* half_overflow_flag;     /* esme_hip_forward_half: the run-time range guard (esme_gemm_fusion_t.overflow_flag), int32 on the device or NULL */

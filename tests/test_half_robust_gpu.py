@@ -129,6 +129,51 @@ def test_layernorm_folded_gemm_pair_output(tile):
     assert rel(full, y[:, :2 * E]) <= 5e-6 and rel(out[:, :2 * E].double().cpu(), y[:, :2 * E]) >= 5e-5
 
 
+@pytest.mark.parametrize('d', [16, 32, 64])
+@pytest.mark.parametrize('tile', [1, 2])
+def test_pair_output_with_fused_fp32_rotary(d, tile):
+    """The QKV launch of the q/k-pair form: LN-folded projection, q and k rotated with FP32 tables in the epilogue and written as fp16
+    (hi, lo) pairs, v single.  hi + lo against the float64 rotation of the float64 projection of the same operands: the pair's own
+    resolution (2^-21), where a rotation with fp16 tables or of a single fp16 q would stop at 2^-12."""
+    from esme.attention import _fold_layernorm_pow2
+    H, lengths = 8, [70, 300, 141]
+    E, T = H * d, sum(lengths)
+    if E % 128:
+        E = 128 * ((E + 127) // 128)
+        H = E // d
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(T, E, generator=g) * 1.5 + 0.2
+    gamma = (1 + 0.1 * torch.randn(E, generator=g)).to(torch.bfloat16)
+    beta = (0.05 * torch.randn(E, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(3 * E, E, generator=g) * E ** -0.5 * 4).to(torch.bfloat16)
+    b = (0.1 * torch.randn(3 * E, generator=g)).to(torch.bfloat16)
+    wf, c1, c2, rho, _ = _fold_layernorm_pow2(w, b, gamma, beta)
+    cu = syn.cu_lens_of(lengths)
+    pos, _ = _hip.seq_positions(cu.to(DEV), T)
+    cos, sin = O.rotary_tables(max(lengths), d, torch.float32)
+    xs = torch.empty(T, 2 * E, dtype=H16, device=DEV)
+    sums = torch.empty(1, T, 2, dtype=torch.float32, device=DEV)
+    _hip.stream_operand(x.to(DEV), xs, sums, pair=True, scale=rho.to(DEV))
+    ln = (sums, E, 1e-5, c1.to(DEV), c2.to(DEV))
+    with _hip.gemm_options(tile=tile):
+        out = torch.zeros(T, 5 * E, dtype=H16, device=DEV)
+        _hip.gemm_fused(xs[:, :E], wf.to(DEV), None, ln=ln, pair_out=True, pair_cols=2 * E, out=out,
+                        rot=(cos.to(DEV), sin.to(DEV), pos, d, 2 * E))
+        plain = torch.zeros(T, 5 * E, dtype=H16, device=DEV)
+        _hip.gemm_fused(xs[:, :E], wf.to(DEV), None, ln=ln, pair_out=True, pair_cols=2 * E, out=plain)
+    acc = xs[:, :E].double().cpu() @ wf.double().T
+    st = sums[0].cpu().double()
+    mean = st[:, 0] / E
+    rstd = torch.rsqrt((st[:, 1] / E - mean * mean).clamp_min(0) + 1e-5)
+    y = rstd[:, None] * (acc - mean[:, None] * c1.double()[None]) + c2.double()[None]
+    p64 = O.culen_positions(cu)
+    ref = torch.cat([O.apply_rotary(y[:, i * E:(i + 1) * E].reshape(T, H, d), cos.double(), sin.double(), p64).reshape(T, E) for i in range(2)], dim=1)
+    got = out[:, :2 * E].double().cpu() + out[:, 3 * E:].double().cpu()
+    assert rel(got, ref) <= 4e-6, rel(got, ref)
+    assert rel(out[:, :2 * E].double().cpu(), ref) >= 5e-5                     # hi alone: the fp16 rounding
+    assert torch.equal(out[:, 2 * E:3 * E], plain[:, 2 * E:3 * E])              # v: not rotated, no lo half
+
+
 def test_rotary_split_f16():
     H, d, lengths = 6, 64, [70, 300, 141]
     T = sum(lengths)
