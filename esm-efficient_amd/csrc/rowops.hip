@@ -558,6 +558,9 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
         u16* xr = (is_k ? k : q) + row * ld;
         int p = pos[row];
         p = p < max_len ? p : max_len - 1;
+        // (round 5 A/B: ONE partial vector load of the row's 2 * d/16 distinct table chunks + ds_bpermute instead of these two full-wave
+        // loads changes nothing -- 66.6 / 67.5 / 68.1 us against 66.1 / 65.7 / 69.3 on one box at the ESMC-600M shape: the pass is no longer
+        // bound by vector-memory instructions; profiles/r05_qk_norm_ab.txt)
         const u32x4 craw = *reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc);
         const u32x4 sraw = *reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc);
         float v[NCH][8];
