@@ -28,6 +28,9 @@
 #include "launch.h"
 #include "gemm.h"
 
+#ifndef ESME_ATTN_ABL           // lab builds only (timing ablations of attn_pp64_kernel, WRONG results; profiles/r05_attn_rowsum_ablation.txt):
+#define ESME_ATTN_ABL 0         // 1 = the two row-sum v_add per score pair dropped; 3 = ... and 4 MFMAs per phase on a ones fragment issued instead
+#endif                          // (what "row sums on the matrix pipe" would execute: VERDICT r4 item 3b)
 #ifndef ESME_ATTN_DMA0          // MFMA slots of a phase behind which this wave's two LDS-DMA pieces are issued (A/B builds)
 #define ESME_ATTN_DMA0 3
 #define ESME_ATTN_DMA1 11
@@ -803,6 +806,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     };
 
     f32x16 oacc[2][DB], sacc[2][2];
+#if ESME_ATTN_ABL & 2
+    f32x16 abl_l = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // ONE set for both blocks (a real kernel needs two: +32 registers)
+#endif
     u32x4 pw[2][2][2];                 // P of block bb as packed bf16: [bb][32-key block][16-key step]
     float mc[2], lrun[2];
     const float c = a.scale_log2, thr = a.thr;
@@ -840,6 +846,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 const int db = m % DB, ks = m / DB;
                 oacc[bm][db] = mfma_32x32x16<F16>(
                     fr[m % 3], __builtin_bit_cast(bf16x8, pw[bm][ks >> 1][ks & 1]), oacc[bm][db]);
+#if ESME_ATTN_ABL & 2
+                if (db == DB - 1) {          // the row-sum MFMA of this 16-key step: ones (32 x 16) times P^T
+                    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                    abl_l = mfma_32x32x16<F16>(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pw[bm][ks >> 1][ks & 1]), abl_l);
+                }
+#endif
             }
         };
         // P, packed to bf16, and four partial row sums of block bs against the reference maximum -nm.  Pair p covers
@@ -859,7 +871,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         auto pair_sum_pack = [&](const int p, const float q0, const float q1) {
             const int kbk = p >> 3, r = (2 * p) & 15;
             pw[bs][kbk][r >> 3][(r & 7) >> 1] = pack16<F16>(q0, q1);
+#if !(ESME_ATTN_ABL & 1)
             if (p & 1) { ps2 += q0; ps3 += q1; } else { ps0 += q0; ps1 += q1; }
+#endif
         };
         auto softmax_slot = [&](const int m, const float nm) {      // pair step m = 0..15 (one per MFMA slot at head dim 64, two at 32)
             const float q0 = pa0, q1 = pa1;                  // P of pair m - 1
@@ -944,7 +958,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         // overflow (inf / NaN included): the work item is redone exactly.  fp16 P ends at 65 504: a lane's partial sum below 3e4 bounds each of
         // its P values (the pack would have produced inf otherwise; those MFMAs are discarded with the redo)
         if (__any(!(psum < (F16 ? 3.0e4f : 1e30f)))) ovf = 1;
+#if ESME_ATTN_ABL
+        lrun[bs] += 1.0f;
+#if ESME_ATTN_ABL & 2
+        asm volatile("" : "+v"(abl_l));
+#endif
+#else
         lrun[bs] += psum;
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
