@@ -239,3 +239,91 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
 #undef ESME_TRY
     return ESME_OK;
 }
+
+
+// ---- split-operand ('exact') mode: the same layer stack with every activation operand as a (hi, lo) bf16 pair on an fp32
+// residual stream, through one call.  Mirrors esme/attention.py FlashTransformerLayer.forward_exact launch for launch.
+namespace {
+
+struct WsExact { char* h; char* attn; char* qkv; char* mid; char* x16; int32_t* order; };
+
+int64_t carve_exact(const esme_model_desc_t* m, int64_t T, WsExact* w, char* base) {
+    const int64_t Ea = (int64_t)m->heads * m->head_pad, Ep = m->phys_dim, F = m->ffn_dim;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off += align256(bytes); return base ? base + o : (char*)nullptr; };
+    char* h = take(T * 2 * Ep * 2);                       // LayerNorm output pair
+    char* attn = Ea == Ep ? h : take(T * 2 * Ea * 2);     // attention output pair (shares the LayerNorm pair's buffer when the widths agree)
+    char* qkv = take(T * 6 * Ea * 2);                     // [q k v hi | q k v lo]
+    char* mid = take(T * 2 * F * 2);
+    char* x16 = take(T * Ep * 2);                         // bf16 rounding of the stream (written by the residual epilogue, unused)
+    char* ord = take(1024 * 4);
+    if (w) *w = WsExact{h, attn, qkv, mid, x16, (int32_t*)ord};
+    return off;
+}
+
+}  // namespace
+
+extern "C" int64_t esme_hip_forward_exact_workspace_bytes(const esme_model_desc_t* m, int64_t T) {
+    if (!m || T < 0) return -1;
+    return carve_exact(m, T, nullptr, nullptr);
+}
+
+extern "C" int esme_hip_forward_exact(const esme_model_desc_t* m, float* x32, int64_t ld32, const int32_t* cu_lens, int B, int64_t T,
+                                      int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes, void* pair, int64_t ld_pair,
+                                      float* rep32, int64_t ld_rep, void* stream) {
+    ESME_CHECK_ARG(m && m->struct_bytes == (int)sizeof(esme_model_desc_t), "forward_exact: descriptor missing or of another ABI");
+    ESME_CHECK_ARG(T >= 0 && B >= 0 && max_len >= 0, "forward_exact: bad sizes");
+    if (T == 0) return ESME_OK;
+    ESME_CHECK_ARG(x32 && cu_lens && workspace && pair && m->layers && m->n_layers > 0, "forward_exact: null pointer");
+    ESME_CHECK_ARG(m->phys_dim % 64 == 0 && m->embed_dim > 0 && m->embed_dim <= m->phys_dim && ld32 >= m->phys_dim && ld_pair >= 2 * (int64_t)m->phys_dim,
+                   "forward_exact: the physical width must be a multiple of 64, ld_pair >= 2 * phys_dim");
+    ESME_CHECK_ARG(ws_bytes >= carve_exact(m, T, nullptr, nullptr) && aligned16(workspace), "forward_exact: workspace too small or misaligned");
+    ESME_CHECK_ARG(!m->rotary || (m->cos && m->sin && pos), "forward_exact: rotary models need (fp32) cos, sin and pos");
+    const int Ep = m->phys_dim, E = m->embed_dim, H = m->heads, dp = m->head_pad, F = m->ffn_dim;
+    const int64_t Ea = (int64_t)H * dp;
+    if (dp != 16 && dp != 32 && dp != 64) ESME_FAIL(ESME_ERR_UNSUPPORTED, "forward_exact: head dims 16, 32 and 64");
+    WsExact w;
+    carve_exact(m, T, &w, (char*)workspace);
+    const bool rot_fused = m->rotary && !m->qk_norm && Ea % 64 == 0;
+    const int32_t* order = nullptr;
+    int rc;
+#define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
+    if (B > 1 && B <= 1024) {
+        ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));
+        order = w.order;
+    }
+    for (int i = 0; i < m->n_layers; ++i) {
+        const esme_layer_weights_t& L = m->layers[i];
+        ESME_CHECK_ARG(L.ln1_w && L.ln2_w && L.qkv_w && L.out_w && L.up_w && L.down_w, "forward_exact: the descriptor needs the plain weights and the LayerNorm parameters");
+        // ---- attention branch
+        ESME_TRY(esme_hip_layernorm_split(x32, ld32, 0, 0, L.ln1_w, L.ln1_b, w.h, 2 * (int64_t)Ep, Ep, nullptr, 0, T, E, m->ln_eps, stream));
+        esme_gemm_fusion_t fq{};
+        fq.w_k = Ep; fq.pair_off = 3 * Ea;
+        if (rot_fused) { fq.cos = m->cos; fq.sin = m->sin; fq.pos = pos; fq.head_dim = dp; fq.max_len = m->table_len; fq.rot_cols = (int)(2 * Ea); }
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.h, 2 * (int64_t)Ep, L.qkv_w, L.qkv_b, nullptr, 0, w.qkv, 6 * Ea, T, (int)(3 * Ea), 2 * Ep, ESME_EPI_NONE, 1.0f, &fq, stream));
+        if (m->qk_norm) {                    // ESM-C: q / k LayerNorm over the full width, pair in -> pair out, in place
+            ESME_TRY(esme_hip_layernorm_split(w.qkv, 6 * Ea, 1, 3 * Ea, L.lnq_w, L.lnq_b, w.qkv, 6 * Ea, 3 * Ea, nullptr, 0, T, (int)Ea, m->ln_eps, stream));
+            ESME_TRY(esme_hip_layernorm_split(w.qkv + Ea * 2, 6 * Ea, 1, 3 * Ea, L.lnk_w, L.lnk_b, w.qkv + Ea * 2, 6 * Ea, 3 * Ea, nullptr, 0, T, (int)Ea, m->ln_eps, stream));
+        }
+        if (m->rotary && !rot_fused)
+            ESME_TRY(esme_hip_rotary_split(w.qkv, 6 * Ea, 3 * Ea, (const float*)m->cos, (const float*)m->sin, pos, T, 2 * H, dp, m->table_len, stream));
+        ESME_TRY(esme_hip_attn_varlen_fwd_split(w.qkv, w.qkv + Ea * 2, w.qkv + 2 * Ea * 2, 6 * Ea, 3 * Ea, w.attn, 2 * Ea, Ea, cu_lens, B, T, H, dp, max_len,
+                                                m->softmax_scale, order, stream));
+        esme_gemm_fusion_t fo{};
+        fo.w_k = (int)Ea; fo.resid32 = x32; fo.ld32 = ld32;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, 2 * Ea, L.out_w, L.out_b, nullptr, 0, w.x16, Ep, T, Ep, (int)(2 * Ea), ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
+        // ---- FFN branch
+        ESME_TRY(esme_hip_layernorm_split(x32, ld32, 0, 0, L.ln2_w, L.ln2_b, w.h, 2 * (int64_t)Ep, Ep, nullptr, 0, T, E, m->ln_eps, stream));
+        esme_gemm_fusion_t fu{};
+        fu.w_k = Ep; fu.pair_off = F;
+        const int up_rows = m->swiglu ? 2 * F : F;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.h, 2 * (int64_t)Ep, L.up_w, L.up_b, nullptr, 0, w.mid, 2 * (int64_t)F, T, up_rows, 2 * Ep,
+                                          m->swiglu ? ESME_EPI_SWIGLU : ESME_EPI_GELU, 1.0f, &fu, stream));
+        esme_gemm_fusion_t fd{};
+        fd.w_k = F; fd.resid32 = x32; fd.ld32 = ld32;
+        ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, 2 * (int64_t)F, L.down_w, L.down_b, nullptr, 0, w.x16, Ep, T, Ep, 2 * F, ESME_EPI_RESIDUAL, m->alpha, &fd, stream));
+    }
+    ESME_TRY(esme_hip_layernorm_split(x32, ld32, 0, 0, m->final_ln_w, m->final_ln_b, pair, ld_pair, Ep, rep32, ld_rep, T, E, m->ln_eps, stream));
+#undef ESME_TRY
+    return ESME_OK;
+}

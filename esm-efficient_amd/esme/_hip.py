@@ -47,7 +47,8 @@ class LayerWeights(Structure):
     """esme_layer_weights_t (include/esme_hip.h)."""
     _fields_ = [(n, c_void_p) for n in ('qkv_w', 'qkv_c1', 'qkv_c2', 'out_w', 'out_b', 'up_w', 'up_c1', 'up_c2',
                                         'down_w', 'down_b', 'lnq_w', 'lnk_w', 'lnq_b', 'lnk_b',
-                                        'ps_attn', 'ps_attn_inv', 'ps_ffn', 'ps_ffn_inv')]
+                                        'ps_attn', 'ps_attn_inv', 'ps_ffn', 'ps_ffn_inv',
+                                        'ln1_w', 'ln1_b', 'ln2_w', 'ln2_b', 'qkv_b', 'up_b')]
 
 
 class ModelDesc(Structure):
@@ -92,6 +93,9 @@ SIGNATURES = {
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand_scaled': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int,
                                                c_void_p]),
+    'esme_hip_forward_exact_workspace_bytes': (c_int64, [c_void_p, c_int64]),
+    'esme_hip_forward_exact': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                       c_void_p, c_int64, c_void_p]),
     'esme_hip_rotary_split_f16': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_attn_varlen_fwd_qkpair_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int,
                                                     c_int, c_float, c_void_p, c_void_p]),
@@ -596,8 +600,8 @@ def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
             raise ValueError('layernorm_split: a pair input is (T, 2 * dim)')
     else:
         xp, ldx = _rows2d(x, 'layernorm_split x', torch.float32)
-        if x.shape[1] != dim:
-            raise ValueError('layernorm_split: an fp32 input is (T, dim)')
+        if x.shape[1] < dim:
+            raise ValueError('layernorm_split: an fp32 input is (T, >= dim) (the first `dim` columns are normalised: a padded layout is wider)')
     if out is None:
         out = torch.empty(T, 2 * dim, dtype=torch.bfloat16, device=x.device)
     yp, ldy = _rows2d(out, 'layernorm_split out')

@@ -495,6 +495,7 @@ class FlashTransformerLayer(nn.Module):
         self.padded = self.self_attn.padded
         self._down_pad = None
         self._down_key = None
+        self._up_pad = None         # (key, up-projection weight with zero pad columns): precision 'exact' on padded layouts
         if final_activation == 'swiglu':
             width = int(((expand_dim * embed_dim) + 255) // 256 * 256)
             self.final = nn.Sequential(LayerNorm(embed_dim, dtype=dtype),
@@ -584,8 +585,15 @@ class FlashTransformerLayer(nn.Module):
         if fold:
             wf, c1, c2 = self._pack_fold()
             return wf, None, c1, c2
-        if self.padded:
-            raise NotImplementedError('padded layouts run the LayerNorm-folded path only')
+        if self.padded:                                     # (precision 'exact' on a padded layout: the up weight with zero pad columns)
+            if self.final_activation != 'gelu':
+                raise NotImplementedError('padded layouts are implemented for the ESM-2 block')
+            up = self.final[1]
+            key = _version_key(up.weight)
+            if self._up_pad is None or self._up_pad[0] != key:
+                with torch.no_grad():
+                    self._up_pad = (key, _pad_last(up.weight.data, self.phys_dim))
+            return self._up_pad[1], up.bias, None, None
         if self.final_activation == 'gelu':
             return self.final[1].weight, self.final[1].bias, None, None
         self.final[1]._pack()
@@ -667,13 +675,13 @@ class FlashTransformerLayer(nn.Module):
         fp32 forward (`dtype=torch.float32`, esme/esm.py:132-141) to ~1e-5 relative instead of bf16's ~1e-2; ~2.3x the time
         of the fast mode."""
         att = self.self_attn
-        if self.padded or att.head_pad not in (16, 32, 64):
-            raise NotImplementedError("precision='exact' needs a 64-aligned embedding width and head dim 16 / 32 / 64 "
-                                      "(ESM2-35M's padded layout and ESM2-15B's head dim 128 are not covered)")
+        if att.head_pad not in (16, 32, 64):
+            raise NotImplementedError("precision='exact' covers head dims 16 / 32 / 64 (ESM2-15B's head dim 128 is not covered)")
         if any(q is not None for q in (att._q4_qkv, att._q4_out, self._q4_up, self._q4_down)):
             raise NotImplementedError("precision='exact' needs unquantised weights")
         x32 = ctx.x32
-        T, E = x32.shape
+        T, Ep = x32.shape                                                                  # physical width of the stream (padded layouts: > embed_dim)
+        E, Ea = self.embed_dim, att.attn_dim                                               # LayerNorm width; width of each of q, k, v (heads x padded head dim)
         H, d = att.num_heads, att.head_pad
         alpha = 1.0 / self.residue_scaling
         gelu = self.final_activation == 'gelu'
@@ -681,28 +689,30 @@ class FlashTransformerLayer(nn.Module):
         sc = ctx.scratch
         if 'h' not in sc:
             dev = x32.device
-            sc['h'] = torch.empty(T, 2 * E, dtype=torch.bfloat16, device=dev)          # LayerNorm output pair / attention output pair
-            sc['qkv'] = torch.empty(T, 6 * E, dtype=torch.bfloat16, device=dev)        # [q k v hi | q k v lo]
+            alloc = torch.zeros if self.padded else torch.empty                            # (pad columns of the LayerNorm pair stay zero: the kernels write the logical width)
+            sc['h'] = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=dev)                  # LayerNorm output pair
+            sc['attn'] = sc['h'] if Ea == Ep else torch.empty(T, 2 * Ea, dtype=torch.bfloat16, device=dev)      # attention output pair
+            sc['qkv'] = torch.empty(T, 6 * Ea, dtype=torch.bfloat16, device=dev)       # [q k v hi | q k v lo]
             sc['mid'] = torch.empty(T, 2 * F, dtype=torch.bfloat16, device=dev)
-            sc['x16'] = torch.empty(T, E, dtype=torch.bfloat16, device=dev)            # bf16 rounding of the stream (written by the residual epilogue, unused)
-        h, qkv, mid, x16 = sc['h'], sc['qkv'], sc['mid'], sc['x16']
+            sc['x16'] = torch.empty(T, Ep, dtype=torch.bfloat16, device=dev)           # bf16 rounding of the stream (written by the residual epilogue, unused)
+        h, ao, qkv, mid, x16 = sc['h'], sc['attn'], sc['qkv'], sc['mid'], sc['x16']
         # ---- attention branch
-        _hip.layernorm_split(x32, att.norm.weight, att.norm.bias, att.norm.eps, E, out=h)
+        _hip.layernorm_split(x32, att.norm.weight, att.norm.bias, att.norm.eps, E, out=h, out_off=Ep)
         w, b, _, _ = att._weights_qkv(False)
-        rot_fused = att.rot_emb is not None and not att.pre_layernorm and d in (16, 32, 64) and E % 64 == 0
+        rot_fused = att.rot_emb is not None and not att.pre_layernorm and d in (16, 32, 64) and Ea % 64 == 0
         # rotary with fp32 tables (the reference's fp32 forward has them) in the projection's pair epilogue (round 5; rounds 3-4: a pass of its own)
-        _hip.gemm_fused(h, w, b, out=qkv, split_a=True, pair_out=True, rot=(ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if rot_fused else None)
+        _hip.gemm_fused(h, w, b, out=qkv, split_a=True, pair_out=True, rot=(ctx.cos, ctx.sin, ctx.pos, d, 2 * Ea) if rot_fused else None)
         if att.pre_layernorm:             # ESM-C: q / k LayerNorm over the full width, pair in -> pair out, in place (attention.py:104-105)
-            for blk, ln in ((qkv[:, :E], att.layernorm_q), (qkv[:, E:2 * E], att.layernorm_k)):
-                _hip.layernorm_split(blk, ln.weight, ln.bias, ln.eps, E, out=blk, in_off=3 * E, out_off=3 * E)
+            for blk, ln in ((qkv[:, :Ea], att.layernorm_q), (qkv[:, Ea:2 * Ea], att.layernorm_k)):
+                _hip.layernorm_split(blk, ln.weight, ln.bias, ln.eps, Ea, out=blk, in_off=3 * Ea, out_off=3 * Ea)
         if att.rot_emb is not None and not rot_fused:       # ESM-C (the q / k LayerNorm sits between projection and rotation): a pass of its own
-            _hip.rotary_split_(qkv, 3 * E, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
-        _hip.attn_varlen_split(qkv, cu_lens, max_len, H, d, att.head_dim ** -0.5, out=h, order=ctx.order)
+            _hip.rotary_split_(qkv, 3 * Ea, ctx.cos, ctx.sin, ctx.pos, 2 * H, d)
+        _hip.attn_varlen_split(qkv, cu_lens, max_len, H, d, att.head_dim ** -0.5, out=ao, order=ctx.order)
         wo, bo = att._weights_out()
-        _hip.gemm_fused(h, wo, bo, _hip.EPI_RESIDUAL, None, alpha, x16, resid32=x32, split_a=True)
+        _hip.gemm_fused(ao, wo, bo, _hip.EPI_RESIDUAL, None, alpha, x16, resid32=x32, split_a=True)
         # ---- FFN branch
         ln = self.final[0]
-        _hip.layernorm_split(x32, ln.weight, ln.bias, ln.eps, E, out=h)
+        _hip.layernorm_split(x32, ln.weight, ln.bias, ln.eps, E, out=h, out_off=Ep)
         wu, bu, _, _ = self._weights_up(False)
         _hip.gemm_fused(h, wu, bu, _hip.EPI_GELU if gelu else _hip.EPI_SWIGLU, out=mid, split_a=True, pair_out=True)
         wd, bd = self._weights_down()

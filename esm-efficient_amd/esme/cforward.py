@@ -34,12 +34,15 @@ _VERSION = operator.attrgetter('_version')
 class ModelDescriptor:
     """esme_model_desc_t of one model instance + the tensors it points to."""
 
-    def __init__(self, model, f16: bool = False, plan=None):
-        """`f16`: the descriptor of esme_hip_forward_half -- the float16 derived copies (precision 'half'); `plan`: its HalfPlan."""
+    def __init__(self, model, f16: bool = False, plan=None, exact: bool = False):
+        """`f16`: the descriptor of esme_hip_forward_half -- the float16 derived copies (precision 'half'); `plan`: its HalfPlan.
+        `exact`: the descriptor of esme_hip_forward_exact -- the plain bf16 weights + the LayerNorm parameters (nothing folded)."""
         from esme.attention import _version_key
         self.key = self.signature(model)
         self.plan = plan
         ext_sel = plan.ext_sel if (f16 and plan is not None) else None
+        if exact:
+            return self._init_exact(model)
         layers = model.layers
         first = layers[0]
         att0 = first.self_attn
@@ -86,6 +89,41 @@ class ModelDescriptor:
         self.layer_array = arr
         self.desc = d
 
+    def _init_exact(self, model):
+        layers = model.layers
+        first, att0 = layers[0], layers[0].self_attn
+        self.keep = []
+        arr = (LayerWeights * len(layers))()
+        for i, layer in enumerate(layers):
+            att = layer.self_attn
+            wq, bq, _, _ = att._weights_qkv(False)
+            wo, bo = att._weights_out()
+            wu, bu, _, _ = layer._weights_up(False)
+            wd, bd = layer._weights_down()
+            ln2 = layer.final[0]
+            lw = arr[i]
+            lw.qkv_w, lw.qkv_b, lw.out_w, lw.out_b = _ptr(wq), _ptr(bq), _ptr(wo), _ptr(bo)
+            lw.up_w, lw.up_b, lw.down_w, lw.down_b = _ptr(wu), _ptr(bu), _ptr(wd), _ptr(bd)
+            lw.ln1_w, lw.ln1_b, lw.ln2_w, lw.ln2_b = _ptr(att.norm.weight), _ptr(att.norm.bias), _ptr(ln2.weight), _ptr(ln2.bias)
+            if att.pre_layernorm:
+                lw.lnq_w, lw.lnk_w = _ptr(att.layernorm_q.weight), _ptr(att.layernorm_k.weight)
+                lw.lnq_b, lw.lnk_b = _ptr(att.layernorm_q.bias), _ptr(att.layernorm_k.bias)
+            self.keep += [wq, bq, wo, bo, wu, bu, wd, bd]
+        d = ModelDesc()
+        d.struct_bytes = ctypes.sizeof(ModelDesc)
+        d.n_layers, d.embed_dim, d.phys_dim = len(layers), model.embed_dim, model.phys_dim
+        d.heads, d.head_dim, d.head_pad = att0.num_heads, att0.head_dim, att0.head_pad
+        d.ffn_dim = first.final[1].out_features
+        d.vocab = model.vocab_size
+        d.swiglu, d.rotary, d.qk_norm = int(first.final_activation == 'swiglu'), int(att0.rot_emb is not None), int(att0.pre_layernorm)
+        d.ln_eps, d.alpha = float(att0.norm.eps), 1.0 / float(first.residue_scaling)
+        d.softmax_scale = att0.head_dim ** -0.5
+        d.layers = arr
+        ln = model.emb_layer_norm_after
+        d.final_ln_w, d.final_ln_b = _ptr(ln.weight), _ptr(ln.bias)
+        self.layer_array = arr
+        self.desc = d
+
     @staticmethod
     def signature(model):
         """What the descriptor (raw pointers to DERIVED copies: fused q/k/v, LayerNorm-folded weights) depends on, cheap enough
@@ -103,7 +141,13 @@ class ModelDescriptor:
 
     @staticmethod
     def supported(model, precision: str = 'fast') -> bool:
-        if not len(model.layers) or not model.fold_layernorm or model.precision != precision or model.phys_dim % 64:
+        if not len(model.layers) or model.precision != precision or model.phys_dim % 64:
+            return False
+        if precision == 'exact':                    # nothing is folded in this mode; the split-operand kernels cover head dims 16 / 32 / 64
+            att = model.layers[0].self_attn
+            return att.head_pad in (16, 32, 64) and not any(q is not None for layer in model.layers for q in
+                                                            (layer.self_attn._q4_qkv, layer.self_attn._q4_out, layer._q4_up, layer._q4_down))
+        if not model.fold_layernorm:
             return False
         for layer in model.layers:
             att = layer.self_attn
@@ -172,3 +216,28 @@ def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32
                                           _ptr(pos), ws.data_ptr(), ws.numel(), _hip._dev(pair, 'forward pair', torch.bfloat16), pair.stride(0),
                                           _hip._dev(rep32, 'forward rep32', torch.float32), rep32.stride(0), _hip._stream()),
                 'esme_hip_forward_half')
+
+
+def forward_layers_exact(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32):
+    """precision 'exact': fp32 stream `x32` (T, phys_dim), updated in place -> all layers + final LayerNorm through ONE C call
+    (esme_hip_forward_exact); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32.
+    cos / sin: FLOAT32 tables."""
+    lib = _bind()
+    md = getattr(model, '_cdesc_exact', None)
+    if md is None or md.key != ModelDescriptor.signature(model):
+        md = ModelDescriptor(model, exact=True)
+        model._cdesc_exact = md
+    d = md.desc
+    d.cos, d.sin = _ptr(cos), _ptr(sin)
+    d.table_len = int(cos.shape[0]) if cos is not None else 0
+    T = x32.shape[0]
+    nbytes = int(lib.esme_hip_forward_exact_workspace_bytes(ctypes.byref(d), T))
+    key = (x32.device.index, _hip._stream(), 'exact')
+    ws = _workspace(model, key, nbytes, x32.device)
+    if model.padded:
+        ws.zero_()                                    # pad columns of the LayerNorm pairs are never written and must read as zero (the carve-up moves with T)
+    _hip._check(lib.esme_hip_forward_exact(ctypes.byref(d), _hip._dev(x32, 'forward x32', torch.float32), x32.stride(0),
+                                           _hip._dev(cu_lens, 'cu_lens', torch.int32), cu_lens.numel() - 1, T, int(max_len),
+                                           _ptr(pos), ws.data_ptr(), ws.numel(), _hip._dev(pair, 'forward pair', torch.bfloat16), pair.stride(0),
+                                           _hip._dev(rep32, 'forward rep32', torch.float32), rep32.stride(0), _hip._stream()),
+                'esme_hip_forward_exact')

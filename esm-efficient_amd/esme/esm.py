@@ -344,20 +344,31 @@ class ESM2(nn.Module):
         taps = []
         E = self.embed_dim
         if self.precision == 'exact':
-            # split-operand mode: fp32 residual stream, activation pairs, fp32 results (esme.attention.FlashTransformerLayer.forward_exact)
-            assert not self.padded, "precision='exact' needs a 64-aligned embedding width and a supported head dim"
-            T = x.shape[0]
+            # split-operand mode: fp32 residual stream, activation pairs, fp32 results (esme.attention.FlashTransformerLayer.forward_exact).
+            # Padded layouts (ESM2-35M): everything at the physical width, pad columns zero as in the other modes.
+            T, Ep = x.shape
             ctx.x32 = self._embedding_exact(x, tokens, pad_args, pad_indices)
+            if self.c_forward and not layers and _hip.TRACE is None and self._c_forward_ok('exact'):
+                # all layers + the final LayerNorm through ONE C call (esme_hip_forward_exact: the launches below, bit-identical)
+                from esme import cforward
+                alloc = torch.zeros if self.padded else torch.empty
+                pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
+                x = alloc(T, Ep, dtype=torch.float32, device=x.device)
+                cforward.forward_layers_exact(self, ctx.x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x)
+                if want_pair:
+                    x = pair
+                return self._finish_representation(x, [], pad_output, pad_args, pad_indices, cu_lens, pad_width)
             ctx.order = _hip.seq_order(cu_lens)
             for i, layer in enumerate(self.layers):
                 layer.forward_exact(cu_lens, max_len, ctx)
                 if i in layers:
                     taps.append(ctx.x32.clone())
             ln = self.emb_layer_norm_after
+            alloc = torch.zeros if self.padded else torch.empty
             pair = ctx.scratch.get('h')
-            pair = pair if pair is not None else torch.empty(T, 2 * E, dtype=torch.bfloat16, device=x.device)
-            x = torch.empty(T, E, dtype=torch.float32, device=x.device)
-            _hip.layernorm_split(ctx.x32, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x)
+            pair = pair if pair is not None else alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
+            x = alloc(T, Ep, dtype=torch.float32, device=x.device)
+            _hip.layernorm_split(ctx.x32, ln.weight, ln.bias, ln.eps, E, out=pair, out32=x, out_off=Ep)
             if want_pair:
                 x, taps = pair, []
         elif self.precision == 'half':
@@ -476,6 +487,7 @@ class ESM2(nn.Module):
             self._graph_cache.clear()
         self.__dict__.pop('_cdesc', None)
         self.__dict__.pop('_cdesc16', None)
+        self.__dict__.pop('_cdesc_exact', None)
         self.__dict__.pop('_cparams', None)
         self.__dict__.pop('_cws', None)
         from esme.nn import bump_epoch

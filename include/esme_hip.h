@@ -507,6 +507,11 @@ typedef struct esme_layer_weights {
      * W * pow2(gamma), exact in fp16, and qkv_c1 = sum_k gamma_k W[n, k] in fp32), ps_ffn = rho of the FFN LayerNorm (up_w likewise),
      * *_inv their reciprocals (1 / rho in fp32).  See esme_gemm_fusion_t.pair_scale_in / _out. */
     const float* ps_attn; const float* ps_attn_inv; const float* ps_ffn; const float* ps_ffn_inv;
+    /* esme_hip_forward_exact only: the split-operand mode does NOT fold the LayerNorms (their gain would have to be rounded into the weight),
+     * so its descriptor carries the plain bf16 weights -- qkv_w (3 H head_pad, phys_dim), up_w (F or 2 F interleaved, phys_dim), out_w,
+     * down_w as above -- plus the two LayerNorms' parameters (bf16 (embed_dim); biases may be NULL) and the projection biases (bf16 or NULL);
+     * qkv_c1 / c2, up_c1 / c2 and ps_* are ignored. */
+    const void* ln1_w; const void* ln1_b; const void* ln2_w; const void* ln2_b; const void* qkv_b; const void* up_b;
 } esme_layer_weights_t;
 
 typedef struct esme_model_desc {
@@ -559,6 +564,22 @@ int64_t esme_hip_forward_half_workspace_bytes(const esme_model_desc_t* model, in
 int esme_hip_forward_half(const esme_model_desc_t* model, const float* x32, int64_t ld32, const int32_t* cu_lens, int B,
                           int64_t T, int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes,
                           void* pair, int64_t ld_pair, float* rep32, int64_t ld_rep, void* stream);
+
+/* The layer stack in the split-operand ('exact') mode through ONE call (model.set_precision('exact')): fp32 residual
+ * stream, every activation that feeds a matrix product as a (hi, lo) bf16 pair, LayerNorms in fp32 (not folded), rotary with FP32 tables in
+ * the QKV projection's pair epilogue (ESM-C: after its q / k LayerNorm, esme_hip_rotary_split), three-pass attention, fp32 accumulators
+ * added straight into the stream.  The descriptor carries the PLAIN bf16 weights (esme_layer_weights_t.ln1_w ...); cos / sin are FP32 tables.
+ *  x32:   fp32 (T, phys_dim), row stride ld32: the stream at the start (embedding rows), updated IN PLACE (on exit: the last layer's output);
+ *  pair:  bf16 (T, 2 * phys_dim) = [hi | lo], row stride ld_pair: the final LayerNorm's output as the split-operand LM head reads it (pad
+ *         columns, if any, are left as they are: pass zeros); rep32: the same in fp32 (T, phys_dim), row stride ld_rep, or NULL;
+ *  workspace: esme_hip_forward_exact_workspace_bytes(desc, T) bytes, 16-byte aligned and ZEROED when phys_dim != embed_dim (the pad
+ *         columns of the LayerNorm pairs are never written).
+ * Issues the launches of the module-by-module path (esme/attention.py forward_exact): bit-identical results.  Reference counterpart: the
+ * fp32 forward, `dtype=torch.float32` (esme/esm.py:132-141, 243-252).  Head dims 16 / 32 / 64. */
+int64_t esme_hip_forward_exact_workspace_bytes(const esme_model_desc_t* model, int64_t T);
+int esme_hip_forward_exact(const esme_model_desc_t* model, float* x32, int64_t ld32, const int32_t* cu_lens, int B,
+                           int64_t T, int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes,
+                           void* pair, int64_t ld_pair, float* rep32, int64_t ld_rep, void* stream);
 
 #ifdef __cplusplus
 }

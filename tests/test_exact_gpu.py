@@ -246,12 +246,48 @@ def test_exact_mode_esm1_vs_reference_fp32_golden(kind):
 
 
 def test_exact_mode_rejects_what_it_does_not_cover():
-    """Padded layouts (ESM2-35M: E = 480, head dim 24) have no split-operand form: a loud NotImplementedError / AssertionError, never
-    a silent bf16 answer."""
-    m = build('esm2', 2, 480, 20, seed=0).set_precision('exact')
+    """Head dim 128 (ESM2-15B's) has no split-operand attention kernel: a loud NotImplementedError, never a silent bf16 answer."""
+    m = build('esm2', 2, 256, 2, seed=0).set_precision('exact')
     tokens, cu = syn.random_tokens([40], seed=0), syn.cu_lens_of([40])
     with pytest.raises((NotImplementedError, AssertionError)):
         m(tokens.to(DEV), (cu.to(DEV), 40))
+
+
+def test_exact_mode_padded_layout_esm2_35m_geometry():
+    """ESM2-35M's geometry (E = 480 -> a 512-wide stream, head dim 24 -> 32-wide heads) in the split-operand mode (round 5): LayerNorm pairs,
+    weights and the fp32 stream at the physical width with zero pad columns, attention pairs at heads x 32; logical-width fp32 outputs."""
+    model = build('esm2', 3, 480, 20, seed=4).set_precision('exact')
+    w = syn.synthetic_state_dict('esm2', 3, 480, seed=4)
+    lengths = [40, 131, 7]
+    tokens, cu = syn.random_tokens(lengths, seed=3), syn.cu_lens_of(lengths)
+    args = (tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    out = model(*args)
+    ref = O.forward_logits(w, 20, tokens, cu, max(lengths), dtype=torch.float32)
+    e = rel(out.cpu(), ref)
+    rep = model.forward_representation(*args, layers=[0])
+    ref_rep = O.forward_representation(w, 20, tokens, cu, max(lengths), torch.float32, layers=[0])
+    e_rep = rel(rep.cpu(), ref_rep)
+    print(f'\n[exact] padded layout (E = 480, d = 24): logits {e:.2e}, representation + layer-0 tap {e_rep:.2e} vs the fp32 oracle')
+    assert out.dtype == torch.float32 and out.shape == (sum(lengths), 33) and rep.shape == (sum(lengths), 960)
+    assert e <= 1e-4 and e_rep <= 1e-4
+
+
+@pytest.mark.parametrize('kind,L,E,H', [('esm2', 3, 640, 20), ('esm2', 2, 480, 20), ('esmc', 2, 960, 15), ('esm1b', 2, 320, 20)])
+def test_exact_mode_c_forward_entry_equals_module_path(kind, L, E, H):
+    """esme_hip_forward_exact (ONE C call for the layer stack + final LayerNorm) issues the launches of the module-by-module path: logits and
+    representations are bit-identical (ESM-2, the padded 24 -> 32 layout, ESM-C with its q / k LayerNorm + rotary pass, ESM-1b)."""
+    lengths = [70, 9, 200, 33]
+    tokens, cu = syn.random_tokens(lengths, seed=4).to(DEV), syn.cu_lens_of(lengths).to(DEV)
+    model = build(kind, L, E, H, seed=9).set_precision('exact')
+    assert model.c_forward and model._c_forward_ok('exact')
+    out_c = model(tokens, (cu, max(lengths)))
+    rep_c = model.forward_representation(tokens, (cu, max(lengths)))
+    model.c_forward = False
+    out_m = model(tokens, (cu, max(lengths)))
+    rep_m = model.forward_representation(tokens, (cu, max(lengths)))
+    model.c_forward = True
+    assert out_c.dtype == torch.float32 and torch.equal(out_c, out_m) and torch.equal(rep_c, rep_m)
+    assert torch.equal(model(tokens, (cu, max(lengths))), out_c)          # (descriptor and workspace reused)
 
 
 def test_exact_mode_mask_margin_scores():
