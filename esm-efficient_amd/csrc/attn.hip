@@ -364,12 +364,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
     constexpr int KCH = KT * CPR;
     constexpr int KI = (KCH + 255) / 256;
     constexpr int DQ = D / 4;
-    constexpr int DQ_HI_BITS = (D == 16 ? 0 : D == 32 ? 1 : 2);
+    constexpr int DQ_HI_BITS = (D == 16 ? 0 : D == 32 ? 1 : D == 64 ? 2 : 3);
     constexpr int VI = (16 * DQ + 255) / 256;
     constexpr int K_BYTES = KT * D * 2;
     constexpr int V_BYTES = D * 128;
     constexpr int BUF = 2 * K_BYTES + NPT * V_BYTES;   // [K hi | K lo | V^T hi | V^T lo]  (QKP: one V^T)
-    static_assert(D == 16 || D == 32 || D == 64, "split-operand attention: head dims 16, 32, 64");
+    static_assert(D == 16 || D == 32 || D == 64 || D == 128, "split-operand attention: head dims 16, 32, 64, 128");
 
     extern __shared__ __attribute__((aligned(16))) char smem_split[];
     char* smem = smem_split;
@@ -1622,7 +1622,8 @@ extern "C" int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, cons
         case 16: return launch_split<16>(sa, grid, s);
         case 32: return launch_split<32>(sa, grid, s);
         case 64: return launch_split<64>(sa, grid, s);
-        default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn_split: head dim must be 16, 32 or 64");
+        case 128: return launch_split<128>(sa, grid, s);
+        default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn_split: head dim must be 16, 32, 64 or 128");
     }
 }
 

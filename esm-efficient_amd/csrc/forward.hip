@@ -281,10 +281,10 @@ extern "C" int esme_hip_forward_exact(const esme_model_desc_t* m, float* x32, in
     ESME_CHECK_ARG(!m->rotary || (m->cos && m->sin && pos), "forward_exact: rotary models need (fp32) cos, sin and pos");
     const int Ep = m->phys_dim, E = m->embed_dim, H = m->heads, dp = m->head_pad, F = m->ffn_dim;
     const int64_t Ea = (int64_t)H * dp;
-    if (dp != 16 && dp != 32 && dp != 64) ESME_FAIL(ESME_ERR_UNSUPPORTED, "forward_exact: head dims 16, 32 and 64");
+    if (dp != 16 && dp != 32 && dp != 64 && dp != 128) ESME_FAIL(ESME_ERR_UNSUPPORTED, "forward_exact: head dims 16, 32, 64 and 128");
     WsExact w;
     carve_exact(m, T, &w, (char*)workspace);
-    const bool rot_fused = m->rotary && !m->qk_norm && Ea % 64 == 0;
+    const bool rot_fused = m->rotary && !m->qk_norm && dp <= 64 && Ea % 64 == 0;      // (head dim 128: esme_hip_rotary_split)
     const int32_t* order = nullptr;
     int rc;
 #define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)

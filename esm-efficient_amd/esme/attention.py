@@ -675,8 +675,8 @@ class FlashTransformerLayer(nn.Module):
         fp32 forward (`dtype=torch.float32`, esme/esm.py:132-141) to ~1e-5 relative instead of bf16's ~1e-2; ~2.3x the time
         of the fast mode."""
         att = self.self_attn
-        if att.head_pad not in (16, 32, 64):
-            raise NotImplementedError("precision='exact' covers head dims 16 / 32 / 64 (ESM2-15B's head dim 128 is not covered)")
+        if att.head_pad not in (16, 32, 64, 128):
+            raise NotImplementedError("precision='exact' covers head dims 16 / 32 / 64 / 128")
         if any(q is not None for q in (att._q4_qkv, att._q4_out, self._q4_up, self._q4_down)):
             raise NotImplementedError("precision='exact' needs unquantised weights")
         x32 = ctx.x32

@@ -143,9 +143,9 @@ class ModelDescriptor:
     def supported(model, precision: str = 'fast') -> bool:
         if not len(model.layers) or model.precision != precision or model.phys_dim % 64:
             return False
-        if precision == 'exact':                    # nothing is folded in this mode; the split-operand kernels cover head dims 16 / 32 / 64
+        if precision == 'exact':                    # nothing is folded in this mode; the split-operand kernels cover head dims 16 / 32 / 64 / 128
             att = model.layers[0].self_attn
-            return att.head_pad in (16, 32, 64) and not any(q is not None for layer in model.layers for q in
+            return att.head_pad in (16, 32, 64, 128) and not any(q is not None for layer in model.layers for q in
                                                             (layer.self_attn._q4_qkv, layer.self_attn._q4_out, layer._q4_up, layer._q4_down))
         if not model.fold_layernorm:
             return False

@@ -229,7 +229,7 @@ int esme_hip_layernorm_split_checked(const void* x, int64_t ldx, int in_pair, in
 
 /* esme_hip_attn_varlen_fwd with every MFMA operand as a (hi, lo) pair: S = Qh Kh^T + Qh Kl^T + Ql Kh^T, P split in registers,
  * O = Ph Vh + Ph Vl + Pl Vh, classic online softmax with exact row maxima, fp32 row sums; q / k / v: hi at the pointer, lo
- * lo_qkv elements further right in the same row; o receives a pair likewise (lo at lo_o).  d in {16, 32, 64}.  seq_order as in
+ * lo_qkv elements further right in the same row; o receives a pair likewise (lo at lo_o).  d in {16, 32, 64, 128}.  seq_order as in
  * esme_attn_opts_t (NULL = identity).  Replaces flash_attn_varlen_func (esme/attention.py:115-123) of the fp32 forward. */
 int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qkv,
                                    void* o, int64_t ld_o, int64_t lo_o, const int32_t* cu_lens, int B, int64_t T,
@@ -575,7 +575,7 @@ int esme_hip_forward_half(const esme_model_desc_t* model, const float* x32, int6
  *  workspace: esme_hip_forward_exact_workspace_bytes(desc, T) bytes, 16-byte aligned and ZEROED when phys_dim != embed_dim (the pad
  *         columns of the LayerNorm pairs are never written).
  * Issues the launches of the module-by-module path (esme/attention.py forward_exact): bit-identical results.  Reference counterpart: the
- * fp32 forward, `dtype=torch.float32` (esme/esm.py:132-141, 243-252).  Head dims 16 / 32 / 64. */
+ * fp32 forward, `dtype=torch.float32` (esme/esm.py:132-141, 243-252).  Head dims 16 / 32 / 64 / 128 (128: rotary as a pass of its own). */
 int64_t esme_hip_forward_exact_workspace_bytes(const esme_model_desc_t* model, int64_t T);
 int esme_hip_forward_exact(const esme_model_desc_t* model, float* x32, int64_t ld32, const int32_t* cu_lens, int B,
                            int64_t T, int max_len, const int32_t* pos, void* workspace, int64_t ws_bytes,

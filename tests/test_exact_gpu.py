@@ -122,7 +122,7 @@ def test_rotary_split_fp32_tables(d):
     assert torch.equal(dev.cpu()[:, 2 * E:3 * E], pair[:, 2 * E:3 * E])          # v untouched
 
 
-@pytest.mark.parametrize('d,H', [(16, 20), (32, 20), (64, 8)])
+@pytest.mark.parametrize('d,H', [(16, 20), (32, 20), (64, 8), (128, 3)])
 def test_attention_split(d, H):
     lengths = [1, 7, 64, 65, 130, 300, 517]
     cu = syn.cu_lens_of(lengths)
@@ -246,11 +246,33 @@ def test_exact_mode_esm1_vs_reference_fp32_golden(kind):
 
 
 def test_exact_mode_rejects_what_it_does_not_cover():
-    """Head dim 128 (ESM2-15B's) has no split-operand attention kernel: a loud NotImplementedError, never a silent bf16 answer."""
-    m = build('esm2', 2, 256, 2, seed=0).set_precision('exact')
+    """4-bit weights have no split-operand form: a loud NotImplementedError, never a silent bf16 answer."""
+    import os, tempfile
+    from esme import ESM
+    with tempfile.TemporaryDirectory() as td:
+        path = syn.write_checkpoint(os.path.join(td, 'm.safetensors'), 'esm2_q', 2, 320, 20, seed=0)
+        m = ESM.from_pretrained(path, quantization='4bit', device=DEV).set_precision('exact')
     tokens, cu = syn.random_tokens([40], seed=0), syn.cu_lens_of([40])
     with pytest.raises((NotImplementedError, AssertionError)):
         m(tokens.to(DEV), (cu.to(DEV), 40))
+
+
+def test_exact_mode_head_dim_128():
+    """ESM2-15B's head dim (round 5): the split-operand attention kernel at d = 128, rotary as a pass of its own (the projection epilogue
+    rotates head dims <= 64)."""
+    model = build('esm2', 2, 256, 2, seed=6).set_precision('exact')
+    w = syn.synthetic_state_dict('esm2', 2, 256, seed=6)
+    lengths = [70, 9, 200]
+    tokens, cu = syn.random_tokens(lengths, seed=4), syn.cu_lens_of(lengths)
+    args = (tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    out = model(*args)
+    ref = O.forward_logits(w, 2, tokens, cu, max(lengths), dtype=torch.float32)
+    e = rel(out.cpu(), ref)
+    model.c_forward = False
+    out_m = model(*args)
+    model.c_forward = True
+    print(f'\n[exact] head dim 128: logits {e:.2e} vs the fp32 oracle')
+    assert out.dtype == torch.float32 and e <= 1e-4 and torch.equal(out, out_m)
 
 
 def test_exact_mode_padded_layout_esm2_35m_geometry():
@@ -321,9 +343,9 @@ def test_split_entry_points_reject_bad_arguments():
     cu = torch.tensor([0, 16], dtype=torch.int32, device=DEV)
     o = torch.zeros(16, 2 * 128, dtype=torch.bfloat16, device=DEV)
     s = torch.cuda.current_stream().cuda_stream
-    # head dim 128 is not a split-attention head dim
+    # head dim 48 is not a split-attention head dim (16 / 32 / 64 / 128 are)
     rc = lib.esme_hip_attn_varlen_fwd_split(x.data_ptr(), x.data_ptr() + 256, x.data_ptr() + 512, 768, 384, o.data_ptr(), 256, 128, cu.data_ptr(),
-                                            1, 16, 1, 128, 16, 0.1, None, s)
+                                            1, 16, 1, 48, 16, 0.1, None, s)
     assert rc == -2 and b'head dim' in lib.esme_hip_last_error()
     # lo offset of the output overlapping the hi block
     rc = lib.esme_hip_attn_varlen_fwd_split(x.data_ptr(), x.data_ptr() + 256, x.data_ptr() + 512, 768, 384, o.data_ptr(), 256, 64, cu.data_ptr(),
