@@ -91,7 +91,7 @@ def pmc_traffic():
     profiles/rNN_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  Counters cannot be read
     from inside the process, so this is the last PROFILED value -- a static file, not an observation of this run -- valid
     for the default workload only; (None, None) otherwise."""
-    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
+    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:
