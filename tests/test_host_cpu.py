@@ -88,6 +88,55 @@ def test_argument_validation_without_gpu():
     assert lib.esme_hip_gemm_bf16(None, 0, None, None, None, 0, None, 0, 0, 64, 64, 0, 1.0, None) == 0   # M = 0: no-op
 
 
+def test_round5_entry_points_validate_without_gpu():
+    """The round-5 entries (precision 'half' made robust, the one-call 'exact' stack) reject bad arguments on the host, before any launch:
+    runs without a GPU and under the host-side AddressSanitizer build (tools/asan_host_check.sh)."""
+    from esme import _hip
+    lib = _hip.load()
+    # stream_operand_scaled: a scale / an extension tile belongs to the pair form; the tile sits between hi and lo
+    assert lib.esme_hip_stream_operand_scaled(16, 64, 16, 64, 0, 1, 16, None, 0, 0, None, 4, 64, None) == -1
+    assert b'pair form' in lib.esme_hip_last_error()
+    assert lib.esme_hip_stream_operand_scaled(16, 64, 16, 192, 128, 1, None, 16, 4, 96, None, 4, 64, None) == -1      # ext_off + 64 > lo_off
+    assert b'extension tile' in lib.esme_hip_last_error()
+    assert lib.esme_hip_stream_operand_scaled(16, 64, 16, 192, 128, 1, None, None, 65, 64, None, 4, 64, None) == -1    # > 64 channels
+    # q/k-pair attention: head dims 16 / 32 / 64, a positive lo offset
+    assert lib.esme_hip_attn_varlen_fwd_qkpair_f16(16, 16, 16, 640, 384, 16, 128, 16, 1, 8, 1, 128, 8, 0.1, None, None) == -2
+    assert b'head dim' in lib.esme_hip_last_error()
+    assert lib.esme_hip_attn_varlen_fwd_qkpair_f16(16, 16, 16, 640, 0, 16, 128, 16, 1, 8, 2, 64, 8, 0.1, None, None) == -1
+    # rotary on fp16 pairs: the lo block must not overlap the heads
+    assert lib.esme_hip_rotary_split_f16(16, 256, 64, 16, 16, 16, 4, 2, 64, 8, None) == -1
+    # the checked LayerNorm: same layout rules as esme_hip_layernorm_split
+    assert lib.esme_hip_layernorm_split_checked(16, 128, 2, 32, 16, None, 16, 128, 64, None, 0, 4, 64, 1e-5, None, None) == -1
+    # fused GEMM: pair scales / extension tile / overflow flag only where they belong
+    fu = _hip.GemmFusion()
+    fu.pair_scale_in = 16
+    assert lib.esme_hip_gemm_bf16_fused(16, 64, 16, None, 16, 64, 16, 64, 8, 64, 64, 2, 1.0, ctypes.byref(fu), None) == -1
+    assert b'pair stream' in lib.esme_hip_last_error()
+    fu = _hip.GemmFusion()
+    fu.pair_cols = 256
+    assert lib.esme_hip_gemm_bf16_fused(16, 64, 16, None, None, 0, 16, 64, 8, 64, 64, 0, 1.0, ctypes.byref(fu), None) == -1
+    fu = _hip.GemmFusion()
+    fu.f16, fu.pair_off, fu.ext_off, fu.ext_n = 1, 128, 64, 65            # 65 channels in a 64-wide tile
+    assert lib.esme_hip_gemm_bf16_fused(16, 64, 16, None, 16, 192, 16, 192, 8, 64, 64, 2, 1.0, ctypes.byref(fu), None) == -1
+    assert b'extension tile' in lib.esme_hip_last_error()
+    # whole-stack entries: descriptor of another ABI, workspace, head dim
+    d = _hip.ModelDesc()
+    assert lib.esme_hip_forward_exact_workspace_bytes(None, 8) == -1
+    assert lib.esme_hip_forward_exact(ctypes.byref(d), 16, 64, 16, 1, 8, 8, 16, 16, 1 << 20, 16, 128, None, 0, None) == -1
+    assert b'ABI' in lib.esme_hip_last_error()
+    lw = (_hip.LayerWeights * 1)()
+    d.struct_bytes, d.n_layers, d.embed_dim, d.phys_dim, d.heads, d.head_dim, d.head_pad, d.ffn_dim = ctypes.sizeof(_hip.ModelDesc), 1, 64, 64, 1, 48, 48, 256
+    d.layers = lw
+    need = lib.esme_hip_forward_exact_workspace_bytes(ctypes.byref(d), 8)
+    assert need > 0
+    assert lib.esme_hip_forward_exact(ctypes.byref(d), 16, 64, 16, 1, 8, 8, 16, 16, need, 16, 128, None, 0, None) == -2
+    assert b'head dims' in lib.esme_hip_last_error()
+    assert lib.esme_hip_forward_exact(ctypes.byref(d), 16, 64, 16, 1, 8, 8, 16, 16, need - 1, 16, 128, None, 0, None) == -1
+    d.half_ext_n = 65
+    assert lib.esme_hip_forward_half(ctypes.byref(d), 16, 64, 16, 1, 8, 8, 16, 16, 1 << 24, 16, 128, None, 0, None) == -1
+    assert b'half_ext_n' in lib.esme_hip_last_error()
+
+
 def test_no_cpu_fallback_and_missing_library(monkeypatch):
     from esme import _hip, ESM2
     x = torch.zeros(4, 64, dtype=torch.bfloat16)
