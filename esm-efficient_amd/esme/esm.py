@@ -224,6 +224,10 @@ class ESM2(nn.Module):
         att = self.layers[0].self_attn
         pair_ok = (not att.pre_layernorm) and att.head_pad in (16, 32, 64) and att.attn_dim % 128 == 0
         qk_pair = pair_ok and (bound >= self.HALF_SCORE_BOUND or self.half_robust is True)
+        if bound >= self.HALF_SCORE_BOUND and not pair_ok:
+            import warnings
+            warnings.warn(f"precision='half': attention scores of this model can reach |s| ~ {bound:.0f}, where fp16 q / k cost more than 1e-3, and its block "
+                          "(q/k LayerNorm, head dim 128 or a width that is not a multiple of 128) has no q/k-pair form; use precision 'exact' if 1e-3 must hold")
         info = {'calibrated': True, 'max_channel_ratio': float(ratio.max()), 'score_bound': bound, 'massive_channels': int(mass.numel()),
                 'qk_pair_supported': bool(pair_ok)}
         return HalfPlan(sel, qk_pair, info)
