@@ -299,3 +299,56 @@ def test_half_mode_range_guard_raises_on_fp16_overflow():
     model.invalidate_graphs()
     assert torch.isfinite(model.set_precision('half', robust=False)(*args)).all()
     model.check_overflow()
+
+
+@pytest.mark.parametrize('d,H', [(64, 4), (32, 6), (16, 8)])
+def test_attention_qk_pairs_ragged_lengths_and_dispatch_order(d, H):
+    """The three-pass score kernel on the edge lengths the other attention kernels are tested on (1, 7, 64, 65, 130, 300, 517 residues:
+    single-row sequences, tiles with a ragged tail, exactly one tile, one key past a tile) -- against float64 on the same pairs; the dispatch
+    order changes no bit; rows of other sequences are untouched by construction (every row is written exactly once)."""
+    lengths = [1, 7, 64, 65, 130, 300, 517]
+    E, T = H * d, sum(lengths)
+    g = torch.Generator().manual_seed(100 + d)
+    q, k, v = (torch.randn(T, E, generator=g) * s for s in (2.0, 2.0, 1.0))
+    qkv = torch.zeros(T, 5 * E, dtype=H16, device=DEV)
+    qh, kh = q.to(H16), k.to(H16)
+    qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:3 * E] = qh.to(DEV), kh.to(DEV), v.to(H16).to(DEV)
+    qkv[:, 3 * E:4 * E], qkv[:, 4 * E:] = (q - qh.float()).to(H16).to(DEV), (k - kh.float()).to(H16).to(DEV)
+    cu = syn.cu_lens_of(lengths)
+    out = torch.full((T, E), 9.0, dtype=H16, device=DEV)
+    _hip.attn_varlen_qkpair(qkv, cu.to(DEV), max(lengths), H, d, d ** -0.5, out=out)
+    out2 = _hip.attn_varlen_qkpair(qkv, cu.to(DEV), max(lengths), H, d, d ** -0.5, order=_hip.seq_order(cu.to(DEV)))
+    qd = qkv[:, :E].double().cpu() + qkv[:, 3 * E:4 * E].double().cpu()
+    kd = qkv[:, E:2 * E].double().cpu() + qkv[:, 4 * E:].double().cpu()
+    ref = O.varlen_attention(qd.view(T, H, d), kd.view(T, H, d), qkv[:, 2 * E:3 * E].double().cpu().view(T, H, d), cu).reshape(T, E)
+    assert torch.isfinite(out.float()).all() and rel(out.float().cpu(), ref) <= 6e-4
+    assert torch.equal(out, out2)
+
+
+def test_half_robust_plan_2d_input_taps_and_alone_vs_packed():
+    """The calibrated form (extension tile + q/k pairs) through the rest of the API: 2-D padded input, `layers=` taps (un-scaled raw stream),
+    and a sequence's logits bit-identical alone and packed."""
+    L, E, H = 4, 640, 20
+    model, w = _probe_model(L, E, H, 50.0)
+    model.set_precision('half', robust='auto')
+    lengths = [37, 250, 5, 128]
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    out = model(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    plan = model.half_plan()
+    assert plan.ext_sel is not None and plan.qk_pair
+    ref = O.forward_logits(w, H, tokens, cu, max(lengths), dtype=torch.float32)
+    assert rel_fro(out.cpu(), ref) <= 1e-3
+    cul = cu.tolist()
+    for i, n in enumerate(lengths):
+        alone = model(tokens[cul[i]:cul[i + 1]].to(DEV), (syn.cu_lens_of([n]).to(DEV), n))
+        assert torch.equal(alone, out[cul[i]:cul[i + 1]]), f'sequence {i}'
+    pad, S = model.alphabet.padding_idx, max(lengths)
+    t2 = torch.full((len(lengths), S), pad, dtype=torch.int64)
+    for i, n in enumerate(lengths):
+        t2[i, :n] = tokens[cul[i]:cul[i + 1]]
+    out2 = model(t2.to(DEV))
+    for i, n in enumerate(lengths):
+        assert torch.equal(out2[i, :n], out[cul[i]:cul[i + 1]])
+    taps = model.forward_representation(tokens.to(DEV), (cu.to(DEV), max(lengths)), layers=[0, 3])
+    ref_taps = O.forward_representation(w, H, tokens, cu, max(lengths), torch.float32, layers=[0, 3])
+    assert taps.shape == ref_taps.shape and rel_fro(taps.cpu(), ref_taps) <= 1e-3
