@@ -257,11 +257,10 @@ def test_exact_mode_esmc_600m_full_depth():
 
 def test_half_mode_esmc_600m_full_depth():
     """precision 'half' on BASELINE config 5's model at its real depth: ESMC-600M (36 layers, E = 1152, q/k LayerNorm, SwiGLU) on
-    32 x 1 002 residues, one whole sequence vs the fp32-math oracle.  ESM-C is the harder geometry for a single-pass mode: the CPU
-    emulation of "fp32 math, every matrix operand rounded to fp16" sits at 9.2e-4 here (bf16: 7.4e-3; ESM2-650M: 4.7e-4 / 3.8e-3), and
-    the kernel path adds the fp16 rounding of the LayerNorm-folded weights: measured 1.2e-3 -- eight times closer than the fast mode,
-    but NOT inside north_star's 1e-3, which is quoted on ESM2-650M (test_half_mode_full_depth).  The bar here is 2e-3 and a quarter of the
-    fast mode's error; precision 'exact' is the mode that meets 1e-3 on ESM-C (test_exact_mode_esmc_600m_full_depth: 1e-5)."""
+    32 x 1 002 residues, one whole sequence vs the fp32-math oracle.  ESM-C is the harder geometry for a single-pass mode: round 4 measured
+    1.2e-3 here (the fp16 rounding of the LayerNorm-folded weights on top of the operand roundings) and set the bar to 2e-3.  With the
+    power-of-two LayerNorm fold of round 5 (W * pow2(gamma) is exact in fp16, the rest of the gain rides on the pair stream) the mode measures
+    7.7e-4: the bar is north_star's 1e-3 and a tenth of the fast mode's error."""
     model, w, H = load('esmc_600m')
     tokens, cu, max_len, lengths = syn.uniform_batch(32 * 1002, 1002, seed=5)
     cul = cu.tolist()
@@ -280,5 +279,5 @@ def test_half_mode_esmc_600m_full_depth():
     e = rel_fro(got, ref32)
     e_fast = rel_fro(fast, ref32)
     print(f'\n[precision] ESMC-600M x 36 layers, 32 x 1 002 residues: rel_fro vs fp32 oracle: half {e:.3e} | fast {e_fast:.3e}')
-    assert e <= 2.0e-3 and e <= 0.25 * e_fast, (e, e_fast)
+    assert e <= 1.0e-3 and e <= 0.1 * e_fast, (e, e_fast)
 
