@@ -66,7 +66,7 @@ def parse():
                     help="model.set_precision('high'): fp32 residual stream (not the headline mode; see DESIGN.md section 4)")
     ap.add_argument('--precision', choices=['fast', 'high', 'half', 'exact'], default=None,
                     help="model.set_precision(...): 'fast' = the headline mode (bf16 storage at the reference's rounding points); 'high' = fp32 "
-                         "residual stream; 'half' = fp32 residual stream + IEEE fp16 MFMA operands, fp32 logits within ~5e-4 of the fp32 forward at "
+                         "residual stream; 'half' = fp16-pair residual stream + IEEE fp16 MFMA operands, fp32 logits within ~4e-4 of the fp32 forward at "
                          "~1.1x the time (the line then says dtype f16); 'exact' = split (hi, lo) bf16 operand pairs, fp32 logits: the "
                          "reference's fp32 forward to ~1e-5 at ~2.2x the time (DESIGN.md section 4).  Not the headline; the line says which mode ran.")
     ap.add_argument('--no-half', action='store_true',

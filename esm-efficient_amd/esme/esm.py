@@ -71,10 +71,11 @@ class ESM2(nn.Module):
     # LayerNorm statistics + exact online softmax, bf16 only at MFMA operands; slower.
     # 'exact': split-operand mode -- every activation feeding a matrix product is a (hi, lo) bf16 pair, fp32 everywhere else;
     # reproduces the reference's fp32 forward (esme/esm.py:132-141 `dtype=`) to ~1e-5, returns fp32.
-    # 'half': IEEE fp16 MFMA operands (weights converted once -- exact for bf16 checkpoints --, activations rounded to 11 significant
-    # bits instead of 8, same MFMA rate), the residual stream as an fp16 pair (22 bits) updated in place by the residual GEMMs, the LM
-    # head in split-operand form: fp32 logits within ~5e-4 of the fp32 forward at ~1.1x the time of 'fast' (benchmark weights; massive
-    # stream channels cost every mode a factor 4-7: DESIGN.md section 4).  Values must stay inside fp16's range (|x| < 65 504).
+    # 'half': IEEE fp16 MFMA operands (weights converted once -- exact for bf16 checkpoints; LayerNorm gains folded as powers of two, the rest
+    # rides on the stream --, activations rounded to 11 significant bits instead of 8, same MFMA rate), the residual stream as an fp16 pair
+    # (22 bits) updated in place by the residual GEMMs, the LM head in split-operand form: fp32 logits within ~4e-4 of the fp32 forward at
+    # ~1.1x the time of 'fast'.  A calibration forward switches on, per model, an extension K-tile for massive stream channels and fp16-pair
+    # q / k (`half_robust`, `half_plan()`); activations must stay inside fp16's range (|x| < 65 504): `check_overflow()`.
     precision = os.environ.get('ESME_PRECISION', 'fast')
     # all layers + final LayerNorm through ONE C call (esme_hip_forward) instead of ~5 Python-issued launches per layer
     c_forward = os.environ.get('ESME_NO_C_FORWARD', '0') != '1'

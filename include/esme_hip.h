@@ -329,7 +329,7 @@ int esme_hip_gemm_qkv_rotary(const void* A, int64_t lda, const void* W, const vo
  *  - f16 != 0 (precision 'half', model.set_precision('half')): A, W, the rotary tables and C are IEEE fp16 instead of bf16 (`bias`
  *              stays bf16: a checkpoint parameter).  bf16 weights convert to fp16 exactly (|w| >= 2^-14; below that to 2^-24
  *              absolute), and an fp16 activation carries 11 significant bits instead of 8 at the same MFMA rate: with the fp32
- *              residual stream (resid32) or the stream as an fp16 PAIR the logits land at ~5e-4 of the reference's fp32
+ *              residual stream (resid32) or the stream as an fp16 PAIR the logits land at ~4e-4 of the reference's fp32
  *              forward in ONE pass over K.  Plain (+ LN-folded fused rotary), GELU, LN-folded SwiGLU and
  *              residual epilogues; 16-byte addressable C.  The caller guarantees |values| < 65 504 (fp16's range).
  *              ESME_EPI_RESIDUAL with f16 needs resid32 OR pair_off != 0: the residual stream is then the fp16 pair
