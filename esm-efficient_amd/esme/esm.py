@@ -255,7 +255,7 @@ class ESM2(nn.Module):
         if rot is not None:
             dt = {'exact': torch.float32, 'half': torch.float16}.get(self.precision, torch.bfloat16)
             if plan is not None and plan.qk_pair:
-                dt = torch.float32                                # q / k pairs are rotated by a pass of their own with fp32 tables
+                dt = torch.float32                                # q / k pairs are rotated with fp32 tables (in the projection's pair epilogue)
             cos, sin = rot.tables(int(max_len), device, dt)
         ctx = ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high',
                              f16=self.precision == 'half', plan=plan)
