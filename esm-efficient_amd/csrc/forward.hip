@@ -166,6 +166,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
     ESME_CHECK_ARG(m->half_ext_n >= 0 && m->half_ext_n <= 64 && (m->half_ext_n == 0 || m->half_ext_sel), "forward_half: half_ext_n in [0, 64] with its channel list");
     ESME_CHECK_ARG(ws_bytes >= carve_half(m, T, nullptr, nullptr) && aligned16(workspace), "forward_half: workspace too small or misaligned");
     ESME_CHECK_ARG(!m->rotary || (m->cos && m->sin && pos), "forward_half: rotary models need cos, sin and pos");
+    ESME_CHECK_ARG(!m->half_qk_pair || !m->rotary || (m->cos32 && m->sin32), "forward_half: q/k pairs need the fp32 rotary tables cos32 / sin32");
     WsHalf w;
     carve_half(m, T, &w, (char*)workspace);
     const int Ep = m->phys_dim, E = m->embed_dim, H = m->heads, dp = m->head_pad;
@@ -201,10 +202,10 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         fu.f16 = 1; fu.overflow_flag = m->half_overflow_flag;
         fu.ln_partial = stats; fu.ln_nblk = stats_nblk; fu.ln_dim = E; fu.ln_eps = m->ln_eps; fu.ln_c1 = L.qkv_c1; fu.ln_c2 = L.qkv_c2;
         char* q = w.qkv; char* k = w.qkv + Ea * 2; char* v = w.qkv + 2 * Ea * 2;
-        if (qk_pair) {
-            // large attention scores: q / k as fp16 pairs [q k v | q_lo k_lo], rotated with fp32 tables, scores from three MFMA passes
+        if (qk_pair && L.half_qk_pair) {
+            // large attention scores in THIS layer: q / k as fp16 pairs [q k v | q_lo k_lo], rotated with fp32 tables, scores from three MFMA passes
             fu.pair_off = 3 * Ea; fu.pair_cols = (int)(2 * Ea);
-            if (m->rotary) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }     // (fp32 tables)
+            if (m->rotary) { fu.cos = m->cos32; fu.sin = m->sin32; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }     // (fp32 tables)
             ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 5 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
             ESME_TRY(esme_hip_attn_varlen_fwd_qkpair_f16(q, k, v, 5 * Ea, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, aopts.seq_order, stream));
         } else {

@@ -48,7 +48,7 @@ class LayerWeights(Structure):
     _fields_ = [(n, c_void_p) for n in ('qkv_w', 'qkv_c1', 'qkv_c2', 'out_w', 'out_b', 'up_w', 'up_c1', 'up_c2',
                                         'down_w', 'down_b', 'lnq_w', 'lnk_w', 'lnq_b', 'lnk_b',
                                         'ps_attn', 'ps_attn_inv', 'ps_ffn', 'ps_ffn_inv',
-                                        'ln1_w', 'ln1_b', 'ln2_w', 'ln2_b', 'qkv_b', 'up_b')]
+                                        'ln1_w', 'ln1_b', 'ln2_w', 'ln2_b', 'qkv_b', 'up_b')] + [('half_qk_pair', c_int), ('reserved_', c_int)]
 
 
 class ModelDesc(Structure):
@@ -59,7 +59,8 @@ class ModelDesc(Structure):
                    ('layers', POINTER(LayerWeights))]
                 + [(n, c_void_p) for n in ('final_ln_w', 'final_ln_b', 'head_dense_w', 'head_dense_b', 'head_ln_w',
                                            'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')]
-                + [('half_ext_n', c_int), ('half_ext_sel', c_void_p), ('half_qk_pair', c_int), ('half_overflow_flag', c_void_p)])
+                + [('half_ext_n', c_int), ('half_ext_sel', c_void_p), ('half_qk_pair', c_int), ('half_overflow_flag', c_void_p),
+                   ('cos32', c_void_p), ('sin32', c_void_p)])
 
 
 # name -> (restype, argtypes); must list every symbol include/esme_hip.h declares

@@ -48,13 +48,14 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe', 'ovf')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe', 'ovf', 'cos32', 'sin32')
 
     def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False, plan=None):
         self.pos, self.cos, self.sin = pos, cos, sin
         self.plan = plan            # precision 'half': HalfPlan (which robustness measures this model needs) or None
         self.probe = None           # calibration forward: list collecting a per-layer upper bound of |attention score|
         self.ovf = None             # precision 'half': int32 device flag of the run-time range guard (esme_gemm_fusion_t.overflow_flag)
+        self.cos32 = self.sin32 = None    # precision 'half': float32 rotary tables of the layers whose q / k travel as pairs
         self.f16 = f16              # precision 'half': IEEE fp16 MFMA operands (weights converted once, activations rounded to fp16)
         self.fold = fold            # run the LN-folded fast path
         self.exact_attn = exact_attn    # high-precision mode: classic online softmax, every row maximum exact
@@ -139,17 +140,24 @@ class HalfPlan:
       qk_pair   q and k travel as fp16 (hi, lo) pairs, rotated with fp32 tables, and the scores come from three MFMA passes
                 (esme_hip_attn_varlen_fwd_qkpair_f16): needed once |score| reaches the hundreds (2^-12 |q||k| is then tenths of a score unit).
       info      the measurements the decision was taken from (reported by tools / bench)."""
-    __slots__ = ('ext_sel', 'qk_pair', 'info')
+    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info')
 
-    def __init__(self, ext_sel=None, qk_pair=False, info=None):
-        self.ext_sel, self.qk_pair, self.info = ext_sel, bool(qk_pair), dict(info or {})
+    def __init__(self, ext_sel=None, qk_pair=False, info=None, qk_layers=None):
+        # qk_layers: per-layer flags (the pair form is paid only where a layer's own score bound asks for it); None = every layer
+        self.qk_layers = None if qk_layers is None else tuple(bool(f) for f in qk_layers)
+        self.ext_sel, self.info = ext_sel, dict(info or {})
+        self.qk_pair = bool(qk_pair) and (self.qk_layers is None or any(self.qk_layers))
+
+    def pairs_at(self, layer: int) -> bool:
+        return self.qk_pair and (self.qk_layers is None or (0 <= layer < len(self.qk_layers) and self.qk_layers[layer]))
 
     @property
     def ext(self) -> int:
         return 64 if self.ext_sel is not None else 0        # width of the extension tile in the pair row
 
     def describe(self) -> str:
-        return f"ext channels {0 if self.ext_sel is None else self.ext_sel.numel()}, q/k pairs {'on' if self.qk_pair else 'off'}"
+        where = '' if (not self.qk_pair or self.qk_layers is None) else f' in {sum(self.qk_layers)} of {len(self.qk_layers)} layers'
+        return f"ext channels {0 if self.ext_sel is None else self.ext_sel.numel()}, q/k pairs {'on' if self.qk_pair else 'off'}{where}"
 
 
 def _extend_k(wf: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
@@ -230,6 +238,7 @@ class FlashMultiheadAttention(nn.Module):
         self._fold16_key = None
         self._rho16 = None          # (rho, 1 / rho) float32 (phys_dim): the part of gamma that rides on the pair stream (_fold_layernorm_pow2)
         self._fold16x = None        # (key, [W' | W'[:, sel] | 0]): the extension K-tile form (HalfPlan.ext_sel)
+        self.layer_index = 0        # position in the model's layer stack (set by the model; HalfPlan.pairs_at)
         self._out16 = None
         self._out16_key = None
         self._q4_qkv = None         # esme.quantization.Q4Matrix pair when the layer is 4-bit
@@ -401,7 +410,7 @@ class FlashMultiheadAttention(nn.Module):
         if f16 and (x_stats is None or (resid32 is None and resid_pair is None) or (self.pre_layernorm and not qk_pass)):
             raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 / pair stream (ESM-C: with the fused q/k pass)")
         plan = ctx.plan if (f16 and ctx is not None) else None
-        qk_pair = bool(plan is not None and plan.qk_pair)
+        qk_pair = bool(plan is not None and plan.pairs_at(self.layer_index))
         if qk_pair:
             # precision 'half' on a model with large attention scores: q / k leave the LN-folded projection as fp16 (hi, lo) pairs, are rotated
             # with FP32 tables (ctx.cos / ctx.sin are float32 then) and multiplied in three MFMA passes; v, P and the output stay single fp16
@@ -409,7 +418,7 @@ class FlashMultiheadAttention(nn.Module):
                 raise NotImplementedError("precision='half' with q/k pairs covers ESM-2 / ESM-1 blocks with head dim 16 / 32 / 64 and a 128-aligned width")
             wf, _, c1, c2 = self._weights_qkv(True, True, pair_ext)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2, ctx.ovf), pair_out=True, pair_cols=2 * E,
-                                  rot=(ctx.cos, ctx.sin, ctx.pos, d, 2 * E) if self.rot_emb is not None else None)     # (fp32 tables, in the epilogue)
+                                  rot=(ctx.cos32, ctx.sin32, ctx.pos, d, 2 * E) if self.rot_emb is not None else None)     # (fp32 tables, in the epilogue)
             if ctx.probe is not None:
                 ctx.probe.append(_score_bound(qkv[:, :E], qkv[:, E:2 * E], H, d, self.head_dim ** -0.5))
             a = _hip.attn_varlen_qkpair(qkv, cu_lens, max_len, H, d, self.head_dim ** -0.5, order=ctx.order)

@@ -63,6 +63,8 @@ class ModelDescriptor:
                 lw.lnq_w, lw.lnk_w = _ptr(att.layernorm_q.weight), _ptr(att.layernorm_k.weight)
                 lw.lnq_b, lw.lnk_b = _ptr(att.layernorm_q.bias), _ptr(att.layernorm_k.bias)
             self.keep += [wq, c1, c2, wo, bo, wu, u1, u2, wd, bd]
+            if f16 and plan is not None:
+                lw.half_qk_pair = int(plan.pairs_at(i))
             if f16:                                            # the pair stream's column scalings (attention._fold_layernorm_pow2)
                 (a_rho, a_inv), (f_rho, f_inv) = att.stream_scale(), layer.stream_scale()
                 lw.ps_attn, lw.ps_attn_inv, lw.ps_ffn, lw.ps_ffn_inv = _ptr(a_rho), _ptr(a_inv), _ptr(f_rho), _ptr(f_inv)
@@ -195,7 +197,7 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
 
 
 
-def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None, ovf=None):
+def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None, ovf=None, cos32=None, sin32=None):
     """precision 'half': fp32 stream at the start `x32` (T, phys_dim) -> all layers + final LayerNorm through ONE C call
     (esme_hip_forward_half); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32.
     `plan`: the model's HalfPlan (cos / sin are float32 tables when it asks for q / k pairs)."""
@@ -208,6 +210,7 @@ def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32
     d.cos, d.sin = _ptr(cos), _ptr(sin)
     d.table_len = int(cos.shape[0]) if cos is not None else 0
     d.half_overflow_flag = _ptr(ovf)                  # the run-time range guard (model.check_overflow reads it)
+    d.cos32, d.sin32 = _ptr(cos32), _ptr(sin32)       # fp32 tables of the layers whose q / k travel as pairs
     T = x32.shape[0]
     nbytes = int(lib.esme_hip_forward_half_workspace_bytes(ctypes.byref(d), T))
     ws = _workspace(model, (x32.device.index, _hip._stream(), 'half'), nbytes, x32.device)

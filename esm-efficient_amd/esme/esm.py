@@ -105,6 +105,8 @@ class ESM2(nn.Module):
         self.embed_tokens.weight.requires_grad_(False)
         self.layers = nn.ModuleList(self._make_layer(rotary_embedding, dropout, dtype)
                                     for _ in range(num_layers))
+        for i, layer in enumerate(self.layers):
+            layer.self_attn.layer_index = i
         self.emb_layer_norm_after = self._make_final_norm(dtype)
         self.lm_head = RobertaLMHead(embed_dim, self.vocab_size, dtype=dtype, phys_dim=self.phys_dim)
 
@@ -217,7 +219,8 @@ class ESM2(nn.Module):
         for site in [x0] + [taps[:, i] for i in range(L - 1)]:        # the inputs of the L attention LayerNorms
             rms = site.pow(2).mean(dim=0).sqrt()
             ratio = torch.maximum(ratio, rms / rms.median().clamp_min(1e-30))
-        bound = float(torch.stack(probe).max()) if probe else 0.0
+        bounds = [float(b) for b in torch.stack(probe).tolist()] if probe else []        # one per layer, in layer order
+        bound = max(bounds) if bounds else 0.0
         mass = torch.nonzero(ratio > self.HALF_CHANNEL_RATIO).flatten()
         if mass.numel() > 64:
             mass = mass[torch.argsort(ratio[mass], descending=True)[:64]]
@@ -229,9 +232,11 @@ class ESM2(nn.Module):
             import warnings
             warnings.warn(f"precision='half': attention scores of this model can reach |s| ~ {bound:.0f}, where fp16 q / k cost more than 1e-3, and its block "
                           "(q/k LayerNorm, head dim 128 or a width that is not a multiple of 128) has no q/k-pair form; use precision 'exact' if 1e-3 must hold")
+        # the pair form is paid per layer: only where that layer's own bound asks for it (robust=True: everywhere)
+        flags = None if (self.half_robust is True or len(bounds) != L) else [b >= self.HALF_SCORE_BOUND for b in bounds]
         info = {'calibrated': True, 'max_channel_ratio': float(ratio.max()), 'score_bound': bound, 'massive_channels': int(mass.numel()),
-                'qk_pair_supported': bool(pair_ok)}
-        return HalfPlan(sel, qk_pair, info)
+                'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0}
+        return HalfPlan(sel, qk_pair, info, qk_layers=flags)
 
     def _apply(self, fn, *a, **kw):
         """`.to()`, `.cuda()`, dtype casts: the parameters' storage moves -- drop everything derived from it."""
@@ -252,13 +257,15 @@ class ESM2(nn.Module):
         rot = self.layers[0].self_attn.rot_emb if len(self.layers) else None
         cos = sin = None
         plan = self.half_plan(device) if self.precision == 'half' else None
+        cos32 = sin32 = None
         if rot is not None:
             dt = {'exact': torch.float32, 'half': torch.float16}.get(self.precision, torch.bfloat16)
-            if plan is not None and plan.qk_pair:
-                dt = torch.float32                                # q / k pairs are rotated with fp32 tables (in the projection's pair epilogue)
+            if plan is not None and plan.qk_pair:                 # q / k pairs are rotated with fp32 tables (in the projection's pair epilogue),
+                cos32, sin32 = rot.tables(int(max_len), device, torch.float32)      # the other layers with the mode's fp16 tables
             cos, sin = rot.tables(int(max_len), device, dt)
         ctx = ForwardContext(pos, cos, sin, fold=self.fold_layernorm, exact_attn=self.precision == 'high',
                              f16=self.precision == 'half', plan=plan)
+        ctx.cos32, ctx.sin32 = cos32, sin32
         ctx.probe = getattr(self, '_calib_probe', None)
         if self.precision == 'half':
             ctx.ovf = self._overflow_flag(device)
@@ -387,7 +394,7 @@ class ESM2(nn.Module):
                 alloc = torch.zeros if self.padded else torch.empty
                 pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
                 x = alloc(T, Ep, dtype=torch.float32, device=x.device)
-                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan, ctx.ovf)
+                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan, ctx.ovf, ctx.cos32, ctx.sin32)
                 if want_pair:
                     x = pair
                 return self._finish_representation(x, [], pad_output, pad_args, pad_indices, cu_lens, pad_width)

@@ -21,7 +21,7 @@ import torch
 # attributes under which modules cache DERIVED device tensors (packed / LayerNorm-folded / padded weight copies,
 # rotary tables): allocated outside a graph's private pool, read by the captured kernels through raw pointers
 _DERIVED_ATTRS = ('_qkv_w', '_qkv_b', '_fold', '_out_w', '_out_b', '_down_pad', '_packed', '_pad', '_embed_pad',
-                  '_cos_cached', '_sin_cached', '_fold16', '_out16', '_down16', '_rho16', '_fold16x', '_half_ovf', '_up_pad')
+                  '_cos_cached', '_sin_cached', '_fold16', '_out16', '_down16', '_rho16', '_fold16x', '_half_ovf', '_up_pad', '_table_cache')
 
 
 def _flatten(x):
@@ -29,6 +29,9 @@ def _flatten(x):
         yield x
     elif isinstance(x, (tuple, list)):
         for y in x:
+            yield from _flatten(y)
+    elif isinstance(x, dict):
+        for y in x.values():
             yield from _flatten(y)
 
 

@@ -45,10 +45,13 @@ class RotaryEmbedding(nn.Module):
 
     def _update_cos_sin_cache(self, seqlen: int, device=None, dtype=torch.bfloat16) -> None:
         """Tables are built on the host in fp32 and rounded to `dtype` exactly as the
-        reference does on its device (rotary.py:116-149), then uploaded once."""
-        if (seqlen > self._seq_len_cached or self._cos_cached is None
-                or self._cos_cached.device != torch.device(device) or self._cos_cached.dtype != dtype):
-            seqlen = max(seqlen, self._seq_len_cached)
+        reference does on its device (rotary.py:116-149), then uploaded once.  One cached pair per dtype (precision 'half' may need
+        float16 tables for some layers and float32 tables for others in the same forward); `_cos_cached` / `_sin_cached` are the
+        pair requested last."""
+        cache = self.__dict__.setdefault('_table_cache', {})
+        hit = cache.get(dtype)
+        if hit is None or seqlen > hit[2] or hit[0].device != torch.device(device):
+            seqlen = max(seqlen, hit[2] if hit is not None else 0, self._seq_len_cached)
             t = torch.arange(seqlen, dtype=torch.float32)
             ang = torch.outer(t, self._compute_inv_freq())
             ang = torch.cat((ang, ang), dim=-1)
@@ -60,9 +63,9 @@ class RotaryEmbedding(nn.Module):
                     pc[:, dst:dst + h] = cos[:, src:src + h]
                     ps[:, dst:dst + h] = sin[:, src:src + h]
                 cos, sin = pc, ps
-            self._cos_cached = cos.to(device)
-            self._sin_cached = sin.to(device)
-            self._seq_len_cached = seqlen
+            hit = cache[dtype] = (cos.to(device), sin.to(device), seqlen)
+            self._seq_len_cached = max(self._seq_len_cached, seqlen)
+        self._cos_cached, self._sin_cached = hit[0], hit[1]
 
     def tables(self, max_len: int, device, dtype=torch.bfloat16) -> Tuple[torch.Tensor, torch.Tensor]:
         self._update_cos_sin_cache(max_len, device, dtype)

@@ -122,18 +122,20 @@ def synthetic_state_dict(kind: str, num_layers: int, embed_dim: int, seed: int =
             for n, s in tensor_shapes(kind, num_layers, embed_dim).items()}
 
 
-def massive_channel_state_dict(num_layers: int, embed_dim: int, scale: float, seed: int = 2, n_channels: int = 4):
+def massive_channel_state_dict(num_layers: int, embed_dim: int, scale: float, seed: int = 2, n_channels: int = 4, gain_layers=None):
     """The ill-conditioned ESM-2 probe model of tools/half_outlier_probe.py / bench.py (`precision_half.outlier_model`): the synthetic
     weights with `n_channels` residual-stream channels made MASSIVE -- their embedding columns and FFN-down biases multiplied by `scale`
     (so every layer feeds them again), the attention LayerNorm gains of the first two by min(scale, 10) (which pushes attention scores
-    into the hundreds) -- the regime trained checkpoints are known for and N(0, 0.02) weights are not.  Returns (state dict, channel ids)."""
+    into the hundreds) -- the regime trained checkpoints are known for and N(0, 0.02) weights are not.  `gain_layers`: the layers whose gains are
+    raised (default: all).  Returns (state dict, channel ids)."""
     w = synthetic_state_dict('esm2', num_layers, embed_dim, seed=seed)
     g = torch.Generator().manual_seed(0)
     cols = torch.randperm(embed_dim, generator=g)[:n_channels]
     w['embed_tokens.weight'][:, cols] *= scale
     for i in range(num_layers):
         w[f'layers.{i}.final.3.bias'][cols] *= scale
-        w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= min(scale, 10.0)
+        if gain_layers is None or i in gain_layers:
+            w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= min(scale, 10.0)
     return w, cols
 
 

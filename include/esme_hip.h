@@ -512,6 +512,9 @@ typedef struct esme_layer_weights {
      * down_w as above -- plus the two LayerNorms' parameters (bf16 (embed_dim); biases may be NULL) and the projection biases (bf16 or NULL);
      * qkv_c1 / c2, up_c1 / c2 and ps_* are ignored. */
     const void* ln1_w; const void* ln1_b; const void* ln2_w; const void* ln2_b; const void* qkv_b; const void* up_b;
+    /* esme_hip_forward_half with esme_model_desc_t.half_qk_pair != 0: THIS layer's q / k travel as fp16 pairs (the pair form is paid per
+     * layer: a calibration flags the layers whose own attention-score bound asks for it); the other layers run the plain form. */
+    int half_qk_pair; int reserved_;
 } esme_layer_weights_t;
 
 typedef struct esme_model_desc {
@@ -536,11 +539,13 @@ typedef struct esme_model_desc {
      * (esme.attention.HalfPlan):
      *   half_ext_n > 0: the half_ext_n <= 64 "massive" stream channels half_ext_sel (int32, device, ascending) ride in an extension K-tile
      *       (esme_gemm_fusion_t.ext_sel): the pair rows are [hi | ext (64) | lo], qkv_w / up_w are (N, phys_dim + 64) = [W' | W'[:, sel] | 0];
-     *   half_qk_pair != 0: q and k leave the QKV projection as fp16 pairs (esme_gemm_fusion_t.pair_cols), rotated in its epilogue
-     *       -- cos / sin are then FP32 tables -- and are multiplied by esme_hip_attn_varlen_fwd_qkpair_f16
+     *   half_qk_pair != 0: in the layers flagged by esme_layer_weights_t.half_qk_pair q and k leave the QKV projection as fp16 pairs
+     *       (esme_gemm_fusion_t.pair_cols), rotated in its epilogue with the FP32 tables cos32 / sin32 (float (table_len, head_pad)), and
+     *       are multiplied by esme_hip_attn_varlen_fwd_qkpair_f16; the other layers use the fp16 tables cos / sin as before
      *       (ESM-2 / ESM-1 blocks, head_pad in {16, 32, 64}, heads * head_pad a multiple of 128). */
     int half_ext_n; const int32_t* half_ext_sel; int half_qk_pair;
     int* half_overflow_flag;     /* esme_hip_forward_half: the run-time range guard (esme_gemm_fusion_t.overflow_flag), int32 on the device or NULL */
+    const float* cos32; const float* sin32;      /* esme_hip_forward_half with half_qk_pair: fp32 rotary tables of the flagged layers */
 } esme_model_desc_t;
 
 int64_t esme_hip_forward_workspace_bytes(const esme_model_desc_t* model, int64_t T);

@@ -352,3 +352,36 @@ def test_half_robust_plan_2d_input_taps_and_alone_vs_packed():
     taps = model.forward_representation(tokens.to(DEV), (cu.to(DEV), max(lengths)), layers=[0, 3])
     ref_taps = O.forward_representation(w, H, tokens, cu, max(lengths), torch.float32, layers=[0, 3])
     assert taps.shape == ref_taps.shape and rel_fro(taps.cpu(), ref_taps) <= 1e-3
+
+
+def test_half_plan_pays_for_qk_pairs_per_layer():
+    """Massive channels everywhere, but the large attention-LayerNorm gains (hence the large scores) only in layers 2 and 5 of 8: the calibration
+    flags exactly those layers for the q/k-pair form (the others keep the fused-rotary fp16 projection and the ping-pong attention kernel), the
+    logits stay inside 1e-3, and the C entry (esme_layer_weights_t.half_qk_pair per layer, both table precisions in the descriptor) equals the
+    module path bit for bit."""
+    L, E, H = 8, 640, 20
+    w = syn.synthetic_state_dict('esm2', L, E, seed=2)
+    g = torch.Generator().manual_seed(0)
+    cols = torch.randperm(E, generator=g)[:4]
+    w['embed_tokens.weight'][:, cols] *= 50.0
+    for i in range(L):
+        w[f'layers.{i}.final.3.bias'][cols] *= 50.0
+    for i in (2, 5):
+        w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= 10.0
+    model = build('esm2', L, E, H, seed=2)
+    model.load_state_dict({k: v.clone() for k, v in w.items()}, strict=False)
+    model.to(DEV)
+    lengths = [150, 61, 300]
+    tokens, cu = syn.random_tokens(lengths, seed=1), syn.cu_lens_of(lengths)
+    ref = O.forward_logits(w, H, tokens, cu, max(lengths), torch.float32).float()
+    args = (tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    out = model.set_precision('half', robust='auto')(*args)
+    plan = model.half_plan()
+    model.c_forward = False
+    out_m = model(*args)
+    model.c_forward = True
+    plain = rel_fro(model.set_precision('half', robust=False)(*args).cpu(), ref)
+    e = rel_fro(out.cpu(), ref)
+    print(f'\n[half] large scores in 2 of 8 layers: {plan.describe()} -> {e:.2e} (plain form {plain:.2e})')
+    assert plan.qk_pair and plan.qk_layers == tuple(i in (2, 5) for i in range(L)), plan.qk_layers
+    assert e <= 1e-3 and torch.equal(out, out_m)

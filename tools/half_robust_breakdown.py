@@ -10,7 +10,8 @@ from safetensors.torch import save_file
 
 L, E, H, T, S = 33, 1280, 20, 50000, 500
 dev = 'cuda:0'
-w, _ = syn.massive_channel_state_dict(L, E, float(os.environ.get('SCALE', 50)), seed=0)
+gl = os.environ.get('GAIN_LAYERS')          # e.g. "3,7,12,...": the large LayerNorm gains (hence the large scores) only in these layers
+w, _ = syn.massive_channel_state_dict(L, E, float(os.environ.get('SCALE', 50)), seed=0, gain_layers=None if gl is None else {int(i) for i in gl.split(',')})
 with tempfile.TemporaryDirectory() as td:
     p = os.path.join(td, 'm.safetensors')
     save_file(w, p, metadata=syn.checkpoint_metadata('esm2_650m', L, E, H))
