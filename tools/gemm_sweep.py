@@ -26,7 +26,7 @@ for name, M, N, K, epi in cases:
     r = torch.randn(M, n_out, device='cuda').to(torch.bfloat16) if epi == _hip.EPI_RESIDUAL else None
     out = torch.empty(M, n_out, device='cuda', dtype=torch.bfloat16)
     for tile, (gm, gn), nt, stg in [(t, r, n, sg) for t in tiles for r in rasters for n in NT for sg in STAG]:
-        if nt or stg:                      # instrumented build only (ESME_HIP_LIB=.../libesme_hip_trace.so)
+        if any(NT) or any(STAG):           # instrumented build only (ESME_HIP_LIB=.../libesme_hip_trace.so); set on every case, zeros too
             _hip.load().esme_hip_debug_set_gemm_nt(nt); _hip.load().esme_hip_debug_set_gemm_stagger(stg)
         _hip.set_gemm_options(tile=tile)
         _hip.set_gemm_options(raster=(gm, gn))
