@@ -469,7 +469,7 @@ class ESM2(nn.Module):
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
             y = _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
-            if self.precision == 'half':
+            if self.precision == 'half' and not getattr(self, '_defer_overflow', False):      # (esme.pipeline reads the flag with each result instead)
                 self.check_overflow()
             return y
 
@@ -477,7 +477,7 @@ class ESM2(nn.Module):
                      lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
             y = _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
-            if self.precision == 'half':
+            if self.precision == 'half' and not getattr(self, '_defer_overflow', False):      # (esme.pipeline reads the flag with each result instead)
                 self.check_overflow()
             return y
 

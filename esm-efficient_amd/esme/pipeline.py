@@ -65,6 +65,32 @@ class StreamedInference:
         # produced, i.e. through iteration i + 2*depth + 1: its slot may be re-targeted in iteration i + 2*depth + 2
         ring_out = _PinnedRing(2 * self.depth + 2)
         pending = deque()
+        # precision 'half': the run-time range guard (ESM2.check_overflow) would cost a device synchronisation per batch if predict_* asked for
+        # it inline.  Here the sticky device flag travels to the host WITH each result (4 bytes on the output stream, pinned) and is looked at
+        # when the result is handed out: no extra synchronisation, and an activation that left fp16's range surfaces as OverflowError at the
+        # first result that may carry it.
+        guard = getattr(self.model, 'precision', None) == 'half'
+        ring_flag = _PinnedRing(2 * self.depth + 2) if guard else None
+        deferred_before = getattr(self.model, '_defer_overflow', False)
+        if guard:
+            self.model._defer_overflow = True
+        try:
+            yield from self._run(batches, dev, compute, copy_s, out_s, ring_in, ring_cu, ring_out, ring_flag, pending)
+        finally:
+            if guard:
+                self.model._defer_overflow = deferred_before
+
+    def _hand_out(self, item, index):
+        h, ev, flag_h = item
+        ev.synchronize()
+        if flag_h is not None and int(flag_h[0]) != 0:
+            self.model._overflow_flag(self.device).zero_()
+            raise OverflowError(f"precision='half': an activation left IEEE fp16's range (|x| >= 65 504) by batch {index} of this stream; its result "
+                                "(and possibly the next batch's) holds inf / NaN.  Use precision 'exact' for this checkpoint / input.")
+        return h
+
+    def _run(self, batches, dev, compute, copy_s, out_s, ring_in, ring_cu, ring_out, ring_flag, pending):
+        handed = 0
         with torch.no_grad():
             for tokens, (cu_lens, max_len) in batches:
                 tok_h = ring_in.take(tokens.shape, torch.int64)
@@ -85,18 +111,19 @@ class StreamedInference:
                 computed = torch.cuda.Event()
                 computed.record(compute)
                 host = ring_out.take(out.shape, out.dtype)
+                flag_h = ring_flag.take((1,), torch.int32) if ring_flag is not None else None
                 with torch.cuda.stream(out_s):
                     out_s.wait_event(computed)
                     host.copy_(out, non_blocking=True)
                     out.record_stream(out_s)
+                    if flag_h is not None:
+                        flag_h.copy_(self.model._overflow_flag(dev), non_blocking=True)
                     downloaded = torch.cuda.Event()
                     downloaded.record(out_s)
-                pending.append((host, downloaded))
+                pending.append((host, downloaded, flag_h))
                 while len(pending) > self.depth:
-                    h, ev = pending.popleft()
-                    ev.synchronize()
-                    yield h
+                    yield self._hand_out(pending.popleft(), handed)
+                    handed += 1
             while pending:
-                h, ev = pending.popleft()
-                ev.synchronize()
-                yield h
+                yield self._hand_out(pending.popleft(), handed)
+                handed += 1

@@ -301,6 +301,39 @@ def test_half_mode_range_guard_raises_on_fp16_overflow():
     model.check_overflow()
 
 
+def test_half_mode_range_guard_travels_with_streamed_results():
+    """esme.pipeline.StreamedInference in precision 'half': the guard's flag is downloaded WITH each result (no per-batch synchronisation --
+    predict_log_prob's inline check is deferred while the stream runs) and an overflow surfaces as OverflowError when the first result that may
+    carry it is handed out; a healthy stream yields what the direct calls return, and the model's own check works again afterwards."""
+    from esme.pipeline import StreamedInference
+    batches = []
+    for seed, lengths in enumerate(([40, 130], [77], [12, 33, 90], [64, 65])):
+        batches.append((syn.random_tokens(lengths, seed=10 + seed), (syn.cu_lens_of(lengths), max(lengths))))
+    model = build('esm2', 3, 320, 20, seed=4).set_precision('half', robust=False)
+    for what in ('forward', 'predict_log_prob'):
+        direct = [getattr(model, what)(t.to(DEV), (c.to(DEV), m)).cpu() for t, (c, m) in batches]
+        got = [h.clone() for h in StreamedInference(model, what, depth=2).run(iter(batches))]
+        assert len(got) == len(direct) and all(torch.equal(a, b) for a, b in zip(got, direct))
+    assert not getattr(model, '_defer_overflow', False)
+    with torch.no_grad():
+        model.layers[1].final[3].bias.data[7] = 2.0e5
+    model.invalidate_graphs()
+    for what in ('forward', 'predict_log_prob'):
+        with pytest.raises(OverflowError):
+            for _ in StreamedInference(model, what, depth=2).run(iter(batches)):
+                pass
+        assert not getattr(model, '_defer_overflow', False)          # restored although the generator ended by an exception
+        torch.cuda.synchronize()
+        model._overflow_flag(DEV).zero_()                               # (batches still in flight when the error surfaced set it again)
+    with pytest.raises(OverflowError):                                  # the inline check is back
+        model.predict_log_prob(batches[0][0].to(DEV), (batches[0][1][0].to(DEV), batches[0][1][1]))
+    with torch.no_grad():
+        model.layers[1].final[3].bias.data[7] = 0.0
+    model.invalidate_graphs()
+    out = list(StreamedInference(model, 'forward', depth=1).run(iter(batches)))
+    assert len(out) == len(batches) and all(torch.isfinite(o).all() for o in out)
+
+
 @pytest.mark.parametrize('d,H', [(64, 4), (32, 6), (16, 8)])
 def test_attention_qk_pairs_ragged_lengths_and_dispatch_order(d, H):
     """The three-pass score kernel on the edge lengths the other attention kernels are tested on (1, 7, 64, 65, 130, 300, 517 residues:
