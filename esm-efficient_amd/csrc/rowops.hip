@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __rest
     if (ext_off) {                                         // extension K-tile of the pair stream: lo of the selected channels, zeros behind them
         u16 val = 0;
         if (lane < ext_n) {
-            const int c = ext_sel[lane];
+            int c = ext_sel[lane];                          // (a device-side list: clamped, so a bad entry cannot read outside the row)
+            c = c < 0 ? 0 : (c < E ? c : E - 1);
             const float v = scale ? __fmul_rn(xr[c], scale[c]) : xr[c];
             val = f2h<F16>(v - h2f<F16>(f2h<F16>(v)));
         }

@@ -490,7 +490,10 @@ class ESM2(nn.Module):
         if getattr(self, '_graph_cache', None) is None:
             from esme.graph import GraphCache
             self._graph_cache = GraphCache(self)
-        return self._graph_cache.run(what, tokens, pad_args, clone)
+        y = self._graph_cache.run(what, tokens, pad_args, clone)
+        if what == 'predict_log_prob' and self.precision == 'half' and not getattr(self, '_defer_overflow', False):
+            self.check_overflow()           # (skipped while capturing; a replay sets the same sticky flag the eager call checks)
+        return y
 
     def invalidate_graphs(self):
         """Forget captured hipGraphs and the C-entry model descriptor (after changing weights in place, in particular

@@ -291,6 +291,11 @@ def test_half_mode_range_guard_raises_on_fp16_overflow():
         model.check_overflow()                                          # cleared
         with pytest.raises(OverflowError):
             model.predict_log_prob(*args)
+        with pytest.raises(OverflowError):                              # ... and from a hipGraph replay of it (the capture itself cannot synchronise)
+            model.graphed(*args, what='predict_log_prob')
+        with pytest.raises(OverflowError):
+            model.graphed(*args, what='predict_log_prob')               # (second call: a pure replay)
+        model.invalidate_graphs()
     model.c_forward = True
     ok = model.set_precision('exact')(*args)
     assert torch.isfinite(ok).all()
