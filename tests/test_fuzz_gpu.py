@@ -1,6 +1,11 @@
 """Seeded random-shape sweeps of the HIP kernels against plain torch fp32 references: odd row counts,
 edge tiles in both tile configurations, every epilogue, ragged sequence lengths down to 1.  Complements the
-hand-picked shapes of test_hip_kernels.py (same tolerances)."""
+hand-picked shapes of test_hip_kernels.py (same tolerances).
+
+ESME_FUZZ_BASE=<n> shifts every seed by n: `for b in 100 200 ...; do ESME_FUZZ_BASE=$b python -m pytest tests/test_fuzz_gpu.py -q -m gpu; done` is a
+campaign over fresh shapes (profiles/r05_fuzz_campaign.txt); the default (0) is what the suite runs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +15,7 @@ from oracle import esm_oracle as O
 from test_hip_kernels import BF16_RTOL, check, dev, rnd
 
 pytestmark = pytest.mark.gpu
+BASE = int(os.environ.get('ESME_FUZZ_BASE', '0'))
 
 
 def _gelu(x):
@@ -18,6 +24,7 @@ def _gelu(x):
 
 @pytest.mark.parametrize('seed', range(24))
 def test_fuzz_gemm(seed):
+    seed += BASE
     from esme import _hip
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     M = int(rng.choice([1, 3, 17, 64, 129, 255, 256, 257, 511, 700, 1025]))
@@ -51,6 +58,7 @@ def test_fuzz_gemm(seed):
 
 @pytest.mark.parametrize('seed', range(16))
 def test_fuzz_attention(seed):
+    seed += BASE
     from esme import _hip
     rng = np.random.Generator(np.random.PCG64(2000 + seed))
     d = int(rng.choice([16, 32, 64, 128]))
@@ -66,11 +74,13 @@ def test_fuzz_attention(seed):
         got = _hip.attn_varlen(x[:, :E], x[:, E:2 * E], x[:, 2 * E:], cu.to(dev()), max(lengths), H)
     q, k, v = (qkv[:, i * E:(i + 1) * E].float().view(T, H, d) for i in range(3))
     ref = O.varlen_attention(q, k, v, cu).reshape(T, E)
-    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn lengths={lengths} H={H} d={d} qb={qb}')
+    mag = O.varlen_attention(q, k, v.abs(), cu).reshape(T, E)           # sum_j p_j |v_j|: what the rounding of P is relative to
+    check(got, ref, rtol=2.0 ** -6, atol_scale=2.0 ** -6, what=f'attn lengths={lengths} H={H} d={d} qb={qb}', mag=mag)
 
 
 @pytest.mark.parametrize('seed', range(8))
 def test_fuzz_rowops(seed):
+    seed += BASE
     from esme import _hip
     rng = np.random.Generator(np.random.PCG64(3000 + seed))
     E = 8 * int(rng.integers(1, 161))
@@ -111,6 +121,7 @@ def test_attention_long_sequences(lengths, H, d):
 def test_fuzz_gemm_f16_pair_stream(seed):
     """Residual epilogue on the fp16 pair stream at odd row counts / edge tiles in both tile configurations: the pair holds
     x + alpha (a W^T + b) to ~2^-22, hi is its fp16 rounding, nothing outside the (M, N) blocks of hi and lo is written."""
+    seed += BASE
     from esme import _hip
     rng = np.random.Generator(np.random.PCG64(5000 + seed))
     M = int(rng.choice([1, 3, 17, 64, 129, 255, 256, 257, 511, 700, 1025, 2049]))
@@ -148,6 +159,7 @@ def test_fuzz_gemm_f16_pair_stream(seed):
 
 @pytest.mark.parametrize('seed', range(12))
 def test_fuzz_attention_f16(seed):
+    seed += BASE
     from esme import _hip
     rng = np.random.Generator(np.random.PCG64(6000 + seed))
     d = int(rng.choice([16, 32, 64, 128]))
@@ -170,10 +182,11 @@ def test_fuzz_attention_f16(seed):
 def test_fuzz_half_mode_model(seed):
     """Random small ESM-2 geometries and ragged batches (1-residue sequences included) in precision 'half': inside 1e-3 of the fp32 oracle,
     and every sequence bit-identical alone and packed."""
+    seed += BASE
     from esme import synthetic as syn
     from test_model_gpu import build
     rng = np.random.Generator(np.random.PCG64(7000 + seed))
-    E, H = [(320, 20), (384, 6), (640, 20), (480, 20), (512, 8), (256, 16)][seed]
+    E, H = [(320, 20), (384, 6), (640, 20), (480, 20), (512, 8), (256, 16)][seed % 6]
     L = int(rng.integers(1, 4))
     lengths = [int(v) for v in rng.choice([1, 2, 9, 33, 64, 100, 257, 300], size=int(rng.integers(1, 6)))]
     model = build('esm2', L, E, H, seed=seed).set_precision('half')
@@ -187,3 +200,31 @@ def test_fuzz_half_mode_model(seed):
     i = int(rng.integers(0, len(lengths)))
     alone = model(tokens[cul[i]:cul[i + 1]].to(dev()), (syn.cu_lens_of([lengths[i]]).to(dev()), lengths[i]))
     assert torch.equal(alone, out[cul[i]:cul[i + 1]])
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_fuzz_attention_qk_pairs(seed):
+    """The q/k-pair attention of precision 'half' (fp16 (hi, lo) q and k, three-pass scores, exact maxima) on random heads, head dims, ragged
+    lengths and score magnitudes up to the hundreds -- against float64 attention on the same pairs; the dispatch order changes no bit."""
+    seed += BASE
+    from esme import _hip
+    rng = np.random.Generator(np.random.PCG64(8000 + seed))
+    d = int(rng.choice([16, 32, 64]))
+    H = int(rng.integers(1, 7))
+    nseq = int(rng.integers(1, 7))
+    lengths = [int(v) for v in rng.choice([1, 2, 8, 31, 32, 33, 63, 64, 65, 127, 129, 200, 257, 300, 513, 700], size=nseq)]
+    T, E = sum(lengths), H * d
+    g = torch.Generator().manual_seed(seed)
+    amp = float(rng.choice([0.5, 2.0, 6.0, 12.0]))                      # |score| up to ~ amp^2 * sqrt(d) * a few: tens to hundreds
+    q, k, v = (torch.randn(T, E, generator=g) * a for a in (amp, amp, 1.0))
+    qh, kh = q.to(torch.float16), k.to(torch.float16)
+    qkv = torch.cat((qh, kh, v.to(torch.float16), (q - qh.float()).to(torch.float16), (k - kh.float()).to(torch.float16)), dim=1).to(dev())
+    cu = torch.tensor(np.r_[0, np.cumsum(lengths)], dtype=torch.int32)
+    out = _hip.attn_varlen_qkpair(qkv, cu.to(dev()), max(lengths), H, d, d ** -0.5)
+    out2 = _hip.attn_varlen_qkpair(qkv, cu.to(dev()), max(lengths), H, d, d ** -0.5, order=_hip.seq_order(cu.to(dev())))
+    c = qkv.double().cpu()
+    qd, kd, vd = c[:, :E] + c[:, 3 * E:4 * E], c[:, E:2 * E] + c[:, 4 * E:], c[:, 2 * E:3 * E]
+    ref = O.varlen_attention(qd.view(T, H, d), kd.view(T, H, d), vd.view(T, H, d), cu).reshape(T, E)
+    err = float((out.cpu().double() - ref).norm() / ref.norm())
+    assert out.dtype == torch.float16 and bool(torch.isfinite(out).all()) and err <= 8e-4, f'qk-pair attn lengths={lengths} H={H} d={d} amp={amp}: {err:.2e}'
+    assert torch.equal(out, out2)

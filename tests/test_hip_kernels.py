@@ -29,13 +29,16 @@ def rnd(shape, seed, scale=1.0):
     return (torch.from_numpy(rng.standard_normal(shape, dtype=np.float32)) * scale).to(torch.bfloat16)
 
 
-def check(got, ref, rtol=BF16_RTOL, atol_scale=2.0 ** -7, what=''):
+def check(got, ref, rtol=BF16_RTOL, atol_scale=2.0 ** -7, what='', mag=None):
+    """|got - ref| <= atol_scale * rms(ref) + rtol * |ref| elementwise.  `mag` (>= |ref|) replaces |ref| in the relative term where the result is a
+    sum that may cancel: for attention, sum_j p_j |v_j| -- the bf16 rounding of P is relative to the TERMS of the sum, and a two-key sequence with
+    v0 = -v1 has |ref| far below them (found by the seed campaign: 1 element of 9 600 at 0.0065 against a bound of 0.0062)."""
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert torch.isfinite(got).all(), f'{what}: non-finite output'
     atol = atol_scale * float(ref.pow(2).mean().sqrt())
     err = (got - ref).abs()
-    bad = err > (atol + rtol * ref.abs())
+    bad = err > (atol + rtol * (ref.abs() if mag is None else mag.detach().float().cpu()))
     assert not bad.any(), (f'{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.4g} '
                            f'at {np.unravel_index(int(err.argmax()), err.shape)}, rel_fro {rel_fro(got, ref):.3g}')
 
