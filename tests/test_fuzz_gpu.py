@@ -228,3 +228,43 @@ def test_fuzz_attention_qk_pairs(seed):
     err = float((out.cpu().double() - ref).norm() / ref.norm())
     assert out.dtype == torch.float16 and bool(torch.isfinite(out).all()) and err <= 8e-4, f'qk-pair attn lengths={lengths} H={H} d={d} amp={amp}: {err:.2e}'
     assert torch.equal(out, out2)
+
+
+# (kind, E, H): ESM-2 widths with head dims 16 / 64 / 32, the padded ESM2-35M layout (head dim 24 -> 32), ESM-C (SwiGLU, q/k LayerNorm, head dims 64)
+_GEOMETRIES = [('esm2', 320, 20), ('esm2', 640, 10), ('esm2', 384, 12), ('esm2', 480, 20), ('esmc', 960, 15), ('esmc', 384, 6), ('esm2', 256, 4), ('esm2', 1280, 20)]
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_fuzz_model_all_modes(seed):
+    """Random depths and ragged batches on eight model geometries (both families, padded layout included), every precision mode against the
+    oracle on the same weights: 'fast' by the bf16 rule of test_model_gpu (relative to the oracle's own bf16 error), 'exact' <= 2e-5 and
+    'half' <= 1e-3 of the fp32 oracle; in every mode a sequence's logits are bit-identical alone and packed."""
+    seed += BASE
+    from esme import synthetic as syn
+    from test_model_gpu import assert_parity, build
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    kind, E, H = _GEOMETRIES[seed % len(_GEOMETRIES)]
+    L = int(rng.integers(1, 4))
+    lengths = [int(v) for v in rng.choice([2, 3, 9, 33, 64, 65, 100, 257, 300, 411], size=int(rng.integers(1, 6)))]
+    model = build(kind, L, E, H, seed=seed)
+    w = {k: v.bfloat16() for k, v in syn.synthetic_state_dict(kind, L, E, seed).items()}
+    tokens, cu, ml = syn.random_tokens(lengths, seed=seed), syn.cu_lens_of(lengths), max(lengths)
+    ref32 = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.float32)
+    refbf = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.bfloat16)
+    cul = cu.tolist()
+    i = int(rng.integers(0, len(lengths)))
+    what = f'{kind} E={E} H={H} L={L} lengths={lengths}'
+    for mode in ('fast', 'half', 'exact'):
+        model.set_precision(mode)
+        out = model(tokens.to(dev()), (cu.to(dev()), ml))
+        if mode == 'fast':
+            assert_parity(out, ref32, refbf, what)
+        else:
+            err = float((out.cpu().double() - ref32.double()).norm() / ref32.double().norm())
+            # 'half' on ESM-C at these depths: the block divides its branches by s = sqrt(L / 36) = 0.17 ... 0.29, so the stream IS the branches
+            # (rms 4.9 against the embedding's 1) and carries their operand roundings undiluted: 6e-4 after ONE layer, 8e-4 ... 1.0e-3 after
+            # three (profiles/r05_esmc_half_diag.txt; ESM-2 on the same shapes: 2e-4 ... 4e-4; ESMC-600M at its real depth, s = 1: 7.7e-4)
+            bar = (1.3e-3 if kind == 'esmc' else 1e-3) if mode == 'half' else 2e-5
+            assert out.dtype == torch.float32 and err <= bar, f'{mode} {what}: {err:.2e}'
+        alone = model(tokens[cul[i]:cul[i + 1]].to(dev()), (syn.cu_lens_of([lengths[i]]).to(dev()), lengths[i]))
+        assert torch.equal(alone, out[cul[i]:cul[i + 1]]), f'{mode} {what}: sequence {i} alone != packed'
