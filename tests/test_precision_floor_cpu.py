@@ -55,3 +55,60 @@ def test_half_mode_emulation_orders_the_fixes():
     assert m['sel'] == 4 and m['smax'] > 100                                        # the probe model's four massive channels; scores in the hundreds
     assert min(m['r4'], m['pow2'], m['ext']) > 1.5e-3                               # no single measure is enough
     assert m['robust'] < 1e-3 and m['robust+pow2'] < 1e-3                           # all of them together are
+
+
+# ---- host-side pieces of the robust 'half' plan (pure torch: no GPU, no library call)
+
+def test_pow2_layernorm_fold_is_exact_and_algebraically_the_layernorm():
+    """esme.attention._fold_layernorm_pow2: W * pow2(gamma) is exactly representable in fp16 for bf16 weights, rho = gamma / pow2(gamma) stays in
+    [2^-1/2, 2^1/2] (zero gains: rho = 1, W' column = 0), and rstd * ((rho x) W'^T - mean c1) + c2 IS LayerNorm(x) W^T + b in float64."""
+    import torch
+    from esme.attention import _fold_layernorm_pow2, _extend_k
+    g = torch.Generator().manual_seed(0)
+    N, E, T = 96, 128, 50
+    w = (torch.randn(N, E, generator=g) * E ** -0.5).to(torch.bfloat16)
+    b = (0.1 * torch.randn(N, generator=g)).to(torch.bfloat16)
+    gamma = (1 + 0.4 * torch.randn(E, generator=g)).to(torch.bfloat16)
+    gamma[3], gamma[17], gamma[40] = 0.0, -0.37, 9.5                     # a dead channel, a negative gain, a large one
+    beta = (0.05 * torch.randn(E, generator=g)).to(torch.bfloat16)
+    wf, c1, c2, rho, rinv = _fold_layernorm_pow2(w, b, gamma, beta)
+    assert wf.dtype == torch.float16 and c1.dtype == c2.dtype == rho.dtype == torch.float32
+    g2 = gamma.double() / rho.double()
+    nz = gamma != 0
+    assert torch.equal(torch.log2(g2[nz].abs()), torch.log2(g2[nz].abs()).round())                # signed powers of two ...
+    want = w.double()[:, nz] * g2[nz]
+    normal = want.abs() >= 2.0 ** -14
+    assert torch.equal(wf.double()[:, nz][normal], want[normal])                                       # ... so the fp16 weight is EXACT
+    assert float((wf.double()[:, nz] - want).abs().max()) <= 2.0 ** -25                              # (below fp16's normal range: half a subnormal step)
+    assert not wf[:, 3].any() and rho[3] == 1.0
+    assert float(rho.min()) >= 2 ** -0.5 - 1e-6 and float(rho.max()) <= 2 ** 0.5 + 1e-6
+    assert torch.allclose(rho * rinv, torch.ones(E))
+    x = torch.randn(T, E, generator=g, dtype=torch.float64) * 3 + 0.7
+    mean = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    y = rstd * ((x * rho.double()) @ wf.double().T - mean * c1.double()) + c2.double()
+    ref = torch.nn.functional.layer_norm(x, (E,), gamma.double(), beta.double(), 1e-5) @ w.double().T + b.double()
+    assert float((y - ref).norm() / ref.norm()) < 1e-6                    # (c1 / c2 are fp32 sums)
+    # the extension K-tile's weight: [W' | W'[:, sel] | 0], 64 columns wide whatever the list's length
+    sel = torch.tensor([5, 17, 99], dtype=torch.int32)
+    wk = _extend_k(wf, sel)
+    assert wk.shape == (N, E + 64) and torch.equal(wk[:, :E], wf) and torch.equal(wk[:, E:E + 3], wf[:, sel.long()]) and not wk[:, E + 3:].any()
+
+
+def test_half_plan_bookkeeping_and_score_bound():
+    import torch
+    from esme.attention import HalfPlan, _score_bound
+    p = HalfPlan()
+    assert not p.qk_pair and p.ext == 0 and not p.pairs_at(0) and p.describe() == 'ext channels 0, q/k pairs off'
+    p = HalfPlan(ext_sel=torch.tensor([1, 9], dtype=torch.int32), qk_pair=True, qk_layers=[False, True, False])
+    assert p.ext == 64 and p.qk_pair and [p.pairs_at(i) for i in range(-1, 4)] == [False, False, True, False, False]
+    assert p.describe() == 'ext channels 2, q/k pairs on in 1 of 3 layers'
+    assert not HalfPlan(qk_pair=True, qk_layers=[False, False]).qk_pair          # no layer asks for it: the form is off
+    assert HalfPlan(qk_pair=True).pairs_at(7)                                    # no per-layer list: every layer
+    # _score_bound: max |q_i| max |k_j| per head, times the scale -- an upper bound of every |score|
+    g = torch.Generator().manual_seed(1)
+    T, H, d = 40, 3, 16
+    q, k = torch.randn(T, H * d, generator=g) * 3, torch.randn(T, H * d, generator=g) * 2
+    bound = float(_score_bound(q, k, H, d, d ** -0.5))
+    s = torch.einsum('thd,shd->hts', q.view(T, H, d), k.view(T, H, d)) * d ** -0.5
+    assert float(s.abs().max()) <= bound <= 4 * float(s.abs().max())
