@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../../esm-efficient_amd/csrc"
 name=$1; variant=$2
 mkdir -p build_alt
-flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I."
+flags="$ALT_DEFS -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I."
 objs=""
 for f in api.hip rowops.hip gemm.hip attn.hip quant.hip forward.hip; do
   if [ "$f" == "$name" ]; then
