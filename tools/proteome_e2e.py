@@ -3,14 +3,14 @@
 workflow/inference/inference_on_human.py:55-65), on synthetic data of the human proteome's size.
 
     synthetic FASTA (20 400 proteins, ~11.4 M residues, log-normal lengths clipped to 30 .. 3 500 aa)
-      -> esme.fasta index -> FastaTokenDataset(token_per_batch=50 000, max_len=3 500) in DataLoader workers (read + tokenise + pack)
+      -> esme.fasta index -> FastaTokenDataset(token_per_batch=50 000, max_len=3 500): read + tokenise + pack, in the main thread (--workers 0) or in DataLoader workers
       -> StreamedInference(model, 'forward'): pinned H2D on a copy stream, forward, LOGITS D2H on an output stream -> host
 
 Timed like the reference: `time.time()` around the loop over the DataLoader (worker start-up, FASTA reads, tokenisation, H2D, forward,
 D2H of every batch's logits), model already loaded.  Beside it: the same batches replayed from HBM with HIP events around every forward
 (kernel-only time of THIS workload), which gives the share the host costs.  Writes one JSON line (profiles/rNN_proteome_e2e.json).
 
-    python tools/proteome_e2e.py [--model esm2_650m] [--proteins 20400] [--median 422] [--workers 16] [--precision fast]
+    python tools/proteome_e2e.py [--model esm2_650m] [--proteins 20400] [--median 422] [--workers 0] [--precision fast]
 """
 import argparse, json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +26,7 @@ def main():
     ap.add_argument('--median', type=float, default=422.0, help='median aa length of the log-normal law (sigma 0.75, clipped 30 .. 3 500): 422 gives the '
                                                                  'human proteome\'s ~11.4 M residues at 20 400 proteins; SURVEY 8d C3(ii) uses 350')
     ap.add_argument('--tokens', type=int, default=50000)
-    ap.add_argument('--workers', type=int, default=16)
+    ap.add_argument('--workers', type=int, default=0, help='DataLoader worker processes; 0 (default) = read + tokenise + pack in the main thread between launches (20 ms per batch against 61 - 72 ms of GPU time): forking workers from a process with a live GPU context stalls its queues for 1 - 3 s at the start of the stream (profiles/r05_e2e_fork_stall.txt)')
     ap.add_argument('--precision', default='fast', choices=['fast', 'half', 'exact'])
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
@@ -68,7 +68,7 @@ def main():
             rows = 0
             checksum = 0.0
             t = time.time()
-            for logits in StreamedInference(model, 'forward', depth=3).run(ds.to_dataloader(num_workers=args.workers, prefetch_factor=4)):
+            for logits in StreamedInference(model, 'forward', depth=3).run(ds.to_dataloader(**({'num_workers': args.workers, 'prefetch_factor': 4} if args.workers else {'num_workers': 0}))):
                 rows += logits.shape[0]
                 checksum += float(logits[0, 0])                  # (touch the host copy)
             wall = time.time() - t
@@ -91,7 +91,7 @@ def main():
     out = {
         'workload': f'{args.model} ({args.precision}): synthetic proteome of {len(lens)} proteins, {residues} residues incl. cls/eos (log-normal aa lengths, median '
                     f'{args.median:g}, sigma 0.75, clipped 30..3500; max {int(lens.max())}), {len(ds)} shuffled batches of <= {args.tokens} tokens, '
-                    f'{args.workers} DataLoader workers; logits ({residues} x {V}) delivered to host memory',
+                    f'{args.workers} DataLoader workers' + ('' if args.workers else ' (FASTA read + tokenisation + packing in the main thread, between launches)') + f'; logits ({residues} x {V}) delivered to host memory',
         'bracket': 'time.time() around the loop over the DataLoader (worker start-up, FASTA reads, tokenisation, H2D, forward, D2H), model loaded and '
                    'warmed up: workflow/inference/inference_on_human.py:55-65',
         'wall_s': round(wall, 2), 'residues_per_s': round(residues / wall, 1), 'proteins_per_s': round(len(lens) / wall, 1),
