@@ -47,7 +47,13 @@ class StreamedInference:
     or its DataLoader.  `what` is 'forward' (logits), 'predict_log_prob' or 'forward_representation';
     `pool='mean'` reduces a representation to one row per protein on the GPU before the download.
     Each result is a pinned host tensor that stays valid until `depth + 1` further results were produced
-    (clone it to keep it longer)."""
+    (clone it to keep it longer).
+
+    Feeding it: a DataLoader with `num_workers=0` is the fast choice on one GPU -- reading, tokenising and packing a 50 000-token batch takes ~20 ms
+    of one core against 60 - 70 ms of GPU time, and three batches are in flight.  Worker PROCESSES forked from a process that already holds a GPU
+    context stall its queues for 1 - 3 s when they start (copy-on-write protection of the parent's pages makes the driver evict and restore the
+    queues: profiles/r05_e2e_fork_stall.txt); if workers are needed, create the DataLoader's iterator before the model is loaded, or use the
+    'forkserver' start method."""
 
     def __init__(self, model, what: str = 'forward_representation', pool: Optional[str] = None, depth: int = 2):
         assert what in ('forward', 'predict_log_prob', 'forward_representation')
