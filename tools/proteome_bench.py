@@ -3,7 +3,7 @@
 (esme.data.FastaTokenDataset in DataLoader workers) -> three-stream pipeline (esme.pipeline) -> per-protein
 mean-pooled embeddings on the host.  Compares against the plain synchronous loop.
 
-    python tools/proteome_bench.py [--model esm2_650m] [--proteins 3000] [--tokens 50000] [--workers 4]
+    python tools/proteome_bench.py [--model esm2_650m] [--proteins 3000] [--tokens 50000] [--workers 0]
 """
 import argparse, json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ def main():
     ap.add_argument('--model', default='esm2_650m')
     ap.add_argument('--proteins', type=int, default=3000)
     ap.add_argument('--tokens', type=int, default=50000)
-    ap.add_argument('--workers', type=int, default=4)
+    ap.add_argument('--workers', type=int, default=0)      # 0: batches prepared in the main thread (forked workers stall the GPU queues at start-up: profiles/r05_e2e_fork_stall.txt)
     args = ap.parse_args()
     from esme import ESM, synthetic as syn
     from esme.alphabet import Alphabet, Alphabet3
