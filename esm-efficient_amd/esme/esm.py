@@ -235,7 +235,8 @@ class ESM2(nn.Module):
         # the pair form is paid per layer: only where that layer's own bound asks for it (robust=True: everywhere)
         flags = None if (self.half_robust is True or len(bounds) != L) else [b >= self.HALF_SCORE_BOUND for b in bounds]
         info = {'calibrated': True, 'max_channel_ratio': float(ratio.max()), 'score_bound': bound, 'massive_channels': int(mass.numel()),
-                'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0}
+                'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0,
+                'score_bounds': [round(b, 2) for b in bounds]}
         return HalfPlan(sel, qk_pair, info, qk_layers=flags)
 
     def _apply(self, fn, *a, **kw):

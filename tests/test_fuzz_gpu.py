@@ -268,3 +268,45 @@ def test_fuzz_model_all_modes(seed):
             assert out.dtype == torch.float32 and err <= bar, f'{mode} {what}: {err:.2e}'
         alone = model(tokens[cul[i]:cul[i + 1]].to(dev()), (syn.cu_lens_of([lengths[i]]).to(dev()), lengths[i]))
         assert torch.equal(alone, out[cul[i]:cul[i + 1]]), f'{mode} {what}: sequence {i} alone != packed'
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_fuzz_half_robust_on_random_massive_channel_models(seed):
+    """The calibrated form of precision 'half' (extension K-tile + per-layer q/k pairs) on random ill-conditioned ESM-2 models: width / head dim
+    (16 / 32 / 64), depth, outlier scale, number of massive channels and WHICH layers carry the large LayerNorm gains are drawn per seed.  Inside
+    1e-3 of the fp32 oracle, the C entry and the module path agree bit for bit, a sequence is bit-identical alone and packed, and the plan pays
+    for q/k pairs in no layer whose own score bound is small."""
+    seed += BASE
+    from esme import synthetic as syn
+    from test_model_gpu import build
+    rng = np.random.Generator(np.random.PCG64(10000 + seed))
+    E, H = [(256, 16), (640, 20), (512, 8), (384, 12)][seed % 4]              # (heads x head dim a multiple of 128: the q/k-pair form's condition)
+    L = int(rng.integers(2, 7))
+    scale = float(rng.choice([10.0, 50.0, 200.0]))
+    nch = int(rng.integers(1, 7))
+    gain_layers = {int(i) for i in rng.choice(L, size=int(rng.integers(0, L + 1)), replace=False)}
+    w, chans = syn.massive_channel_state_dict(L, E, scale, seed=seed, n_channels=nch, gain_layers=gain_layers)
+    model = build('esm2', L, E, H, seed=seed)
+    model.load_state_dict({k: v.clone() for k, v in w.items()}, strict=False)
+    model = model.to(dev())
+    lengths = [int(v) for v in rng.choice([5, 33, 64, 65, 100, 150, 257, 300], size=int(rng.integers(1, 5)))]
+    tokens, cu, ml = syn.random_tokens(lengths, seed=seed), syn.cu_lens_of(lengths), max(lengths)
+    ref = O.forward_logits(w, H, tokens, cu, ml, dtype=torch.float32)
+    args = (tokens.to(dev()), (cu.to(dev()), ml))
+    out = model.set_precision('half', robust='auto')(*args)
+    plan = model.half_plan()
+    what = f'E={E} H={H} L={L} scale={scale:g} channels={nch} gain_layers={sorted(gain_layers)} lengths={lengths}: {plan.describe()}'
+    err = float((out.cpu().double() - ref.double()).norm() / ref.double().norm())
+    assert bool(torch.isfinite(out).all()) and err <= 1e-3, f'{what}: {err:.2e}'
+    model.check_overflow()
+    model.c_forward = False
+    assert torch.equal(model(*args), out), f'{what}: module path != C entry'
+    model.c_forward = True
+    cul = cu.tolist()
+    i = int(rng.integers(0, len(lengths)))
+    alone = model(tokens[cul[i]:cul[i + 1]].to(dev()), (syn.cu_lens_of([lengths[i]]).to(dev()), lengths[i]))
+    assert torch.equal(alone, out[cul[i]:cul[i + 1]]), f'{what}: sequence {i} alone != packed'
+    if plan.qk_pair and plan.qk_layers is not None:
+        bounds = plan.info.get('score_bounds')
+        if bounds is not None:
+            assert len(bounds) == L and all((b >= model.HALF_SCORE_BOUND) == f for b, f in zip(bounds, plan.qk_layers)), (what, bounds, plan.qk_layers)
