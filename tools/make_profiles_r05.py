@@ -74,7 +74,7 @@ def main():
         if f and w:
             fk, wk = sum(f) / len(f), sum(w) / len(w)
             traffic = int((2 * fk + wk) * 1024)
-            json.dump({'_comment': 'HBM/fabric bytes per launch of the dominant kernel (FFN-up GEMM) from the round-4 rocprofv3 PMC passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); KiB units',
+            json.dump({'_comment': 'HBM/fabric bytes per launch of the dominant kernel (FFN-up GEMM) from the round-5 rocprofv3 PMC passes (gpurun_out/r05/final/pmc_fetch, pmc_write: profiles/r05_pmc_traffic.md); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); KiB units',
                        'kernel': key[0] + ' M=50000 N=5120 K=1280', 'fetch_size_kib_raw': fk, 'write_size_kib': wk,
                        'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': 653107200}, open(os.path.join(P, 'r05_traffic.json'), 'w'), indent=1)
             print('traffic', traffic)
