@@ -86,12 +86,12 @@ def parse():
     return args
 
 
-def pmc_traffic():
+def pmc_traffic(suffix=''):
     """(bytes, source): HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (newest
     profiles/rNN_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  Counters cannot be read
     from inside the process, so this is the last PROFILED value -- a static file, not an observation of this run -- valid
     for the default workload only; (None, None) otherwise."""
-    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json'):
+    for name in ((f'r05_traffic{suffix}.json',) if suffix else ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json')):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:
@@ -279,9 +279,11 @@ def half_leg(model, tokens, cu, max_len, steps, T, E, kind, lengths, flops_step,
             ms = sum(up) / len(up)
             res['roofline'] = {'bound': 'mfma', 'kernel': f'gemm_bf16_kernel<F16> M={T} N={4 * E} K={E} (FFN up, LN-folded, GELU epilogue, fp16 operands)',
                                'achieved': round(fl / (ms * 1e-3) / 1e12, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                               'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), 'traffic': None, 'traffic_source': None,
                                'avg_launch_ms': round(ms, 4), 'launches_timed': len(up),
                                'all_gemms': {'achieved': round(g_fl / (g_ms * 1e-3) / 1e12, 1), 'frac': round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}}
+            if E == 1280 and T == 50000 and max_len == 500:          # the headline workload: the mode's own PMC passes (a static file, like the fast leg's)
+                res['roofline']['traffic'], res['roofline']['traffic_source'] = pmc_traffic('_half')
         at = [(meta, s.elapsed_time(e)) for op, meta, s, e in trace if op in ('attn', 'attn_qkpair')]
         if at:
             ams = sum(v for _, v in at) / len(at)
