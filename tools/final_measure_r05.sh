@@ -35,6 +35,10 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /root/repo/$O/pmc_
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /root/repo/$O/pmc_write -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-half > /root/repo/$O/pmc_write.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d /root/repo/$O/pmc_sq -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-half > /root/repo/$O/pmc_sq.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d /root/repo/$O/pmc_sq2 -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-half > /root/repo/$O/pmc_sq2.log 2>&1
+# precision 'half': the mode's own traffic / SQ passes (profiles/r05_traffic_half.json, r05_pmc_traffic_half.md, r05_pmc_counters_half.md)
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /root/repo/$O/pmc_fetch_half -- python /root/repo/bench.py --precision half --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_fetch_half.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /root/repo/$O/pmc_write_half -- python /root/repo/bench.py --precision half --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_write_half.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /root/repo/$O/pmc_sq_half -- python /root/repo/bench.py --precision half --steps 2 --warmup 1 --no-cpu-baseline > /root/repo/$O/pmc_sq_half.log 2>&1
 cd /root/repo
 # keep the merge-back small: the per-dispatch traces are large, the stats / counter CSVs are what the profiles are made from
 find $O -name '*kernel_trace.csv' -size +8M -delete
