@@ -78,6 +78,18 @@ def main():
                        'kernel': key[0] + ' M=50000 N=5120 K=1280', 'fetch_size_kib_raw': fk, 'write_size_kib': wk,
                        'traffic_bytes_per_launch': traffic, 'algorithmic_bytes_per_launch': 653107200}, open(os.path.join(P, 'r05_traffic.json'), 'w'), indent=1)
             print('traffic', traffic)
+    # precision 'half': its own passes (bench.py's half leg reads r05_traffic_half.json)
+    aggh = pmc(['pmc_fetch_half', 'pmc_write_half'], 'r05_pmc_traffic_half.md', "HBM / fabric traffic counters in precision 'half' (FETCH_SIZE, WRITE_SIZE in KiB; `bench.py --precision half`)")
+    keyh = [k for k in aggh if k.startswith('gemm_bf16_kernel<256, 256, 2, 4, 1, 0, true, false, true, false, false, true')]
+    if keyh and aggh[keyh[0]].get('FETCH_SIZE') and aggh[keyh[0]].get('WRITE_SIZE'):
+        f, w = aggh[keyh[0]]['FETCH_SIZE'], aggh[keyh[0]]['WRITE_SIZE']
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        json.dump({'_comment': "HBM/fabric bytes per launch of precision 'half''s dominant kernel (FFN-up GEMM, fp16 operands, LN-folded, GELU) from the round-5 rocprofv3 PMC passes of "
+                               "`bench.py --precision half`; FETCH_SIZE doubled per MI355X_MICROARCH.md; KiB units",
+                   'kernel': keyh[0] + ' M=50000 N=5120 K=1280', 'fetch_size_kib_raw': fk, 'write_size_kib': wk,
+                   'traffic_bytes_per_launch': int((2 * fk + wk) * 1024), 'algorithmic_bytes_per_launch': 653107200}, open(os.path.join(P, 'r05_traffic_half.json'), 'w'), indent=1)
+    if glob.glob(os.path.join(O, 'pmc_sq_half', '**', '*counter_collection.csv'), recursive=True) and not os.path.exists(os.path.join(P, 'r05_pmc_counters_half.md')):
+        pmc(['pmc_sq_half'], 'r05_pmc_counters_half.md', "SQ / MFMA counters per kernel in precision 'half' (round 5)")     # (the committed file also carries derived ratios)
     sq = pmc(['pmc_sq', 'pmc_sq2'], 'r05_pmc_counters.md', 'SQ / LDS / MFMA / L2 counters per kernel (round 5)')
     # derived ratios (1 024 SIMDs, 8 XCDs: GRBM_GUI_ACTIVE is summed over the XCDs)
     mean = lambda v: sum(v) / len(v)
