@@ -308,3 +308,38 @@ def test_oracle_int8_rows_match_reference_functions():
     assert sorted(k for k in w2 if not torch.equal(w2[k], q[k])) == sorted(
         f'layers.0.{s}' for s in ('self_attn.q.weight', 'self_attn.k.weight', 'self_attn.v.weight',
                                   'self_attn.out.weight', 'final.1.weight', 'final.3.weight'))
+
+
+def test_token_size_batch_sampler_properties_hypothesis():
+    """TokenSizeBatchSampler on arbitrary length lists and budgets (the reference's greedy rule, data.py:33-54): without drop_last every index appears
+    exactly once and in the walk's order; a batch of more than one sequence stays within the budget; a batch closes only when the next sequence would
+    overflow it; the only empty batch possible is the first (when the very first sequence overflows); tokenize_unpad of a batch's sequences has exactly
+    the batch's token count."""
+    from hypothesis import given, settings, strategies as st
+    from esme.alphabet import Alphabet, tokenize_unpad
+    from esme.data import TokenSizeBatchSampler
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=600), min_size=0, max_size=80), st.integers(min_value=8, max_value=1500), st.booleans())
+    def check(lens, budget, shuffle):
+        s = TokenSizeBatchSampler(lens, budget, shuffle=shuffle, random_state=3)
+        batches = list(s)
+        assert len(s) == len(batches) and all(s[i] == b for i, b in enumerate(batches))
+        flat = [i for b in batches for i in b]
+        assert sorted(flat) == list(range(len(lens)))
+        if not shuffle:
+            assert flat == list(range(len(lens)))
+        for n, b in enumerate(batches):
+            used = sum(lens[i] + 2 for i in b)
+            assert b or n == 0
+            assert len(b) <= 1 or used <= budget
+            if n + 1 < len(batches) and batches[n + 1]:
+                assert used + lens[batches[n + 1][0]] + 2 > budget            # it closed because the next one did not fit
+        assert TokenSizeBatchSampler(lens, budget, shuffle=shuffle, random_state=3)._batches == batches      # deterministic for a seed
+        dropped = list(TokenSizeBatchSampler(lens, budget, drop_last=True, shuffle=shuffle, random_state=3))
+        assert dropped == batches[:-1] if (batches and batches[-1]) else dropped == batches
+        if batches and batches[-1]:
+            seqs = ['A' * lens[i] for i in batches[-1]]
+            tok, _, cu, ml = tokenize_unpad(seqs, alphabet=Alphabet)
+            assert tok.numel() == sum(lens[i] + 2 for i in batches[-1]) == int(cu[-1]) and ml == max(lens[i] for i in batches[-1]) + 2
+    check()
