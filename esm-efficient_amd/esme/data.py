@@ -105,4 +105,7 @@ class FastaTokenDataset(BaseFastaDataset):
         return token, (cu_lens, max_len)
 
     def to_dataloader(self, num_workers=0, **kwargs):
+        """One packed batch per item (batch_size=None).  On one GPU keep `num_workers=0`: an item takes ~20 ms of one core against 60 - 70 ms of GPU time
+        for it, while worker processes FORKED from a process that already holds a GPU context stall its queues for 1 - 3 s when they start
+        (profiles/r05_e2e_fork_stall.txt); pass `multiprocessing_context='forkserver'` if workers are needed."""
         return DataLoader(self, num_workers=num_workers, batch_size=None, **kwargs)
