@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """precision 'half' on a model with MASSIVE stream channels (what real checkpoints have and N(0, 0.02) synthetic weights do not): a few
 embedding columns, LayerNorm gains and FFN biases scaled up by 10-100x.  Prints rel-Frobenius of the logits vs the fp32 oracle for fast /
-half / exact, so the margin of the fp16 operand mode under outliers is a measured number."""
+half / exact, so the margin of the fp16 operand mode under outliers is a measured number.
+A measurement tool of the test infrastructure: it uses oracle/ as the checker, like tests/; nothing in the product imports it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'esm-efficient_amd')):

@@ -1,5 +1,6 @@
 """Where does precision 'half' lose accuracy on small ESM-C models?  (found by the model fuzz campaign: esmc E=384 H=6 L=3 at 1.0025e-3)
-rel-Frobenius vs the fp32 oracle of the representation (layers= taps: raw stream after each layer, final LayerNorm output) and the logits."""
+rel-Frobenius vs the fp32 oracle of the representation (layers= taps: raw stream after each layer, final LayerNorm output) and the logits.
+Lab tool of the test infrastructure: uses oracle/ as the checker, like tests/; nothing in the product imports it."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'esm-efficient_amd')); sys.path.insert(0, ROOT)

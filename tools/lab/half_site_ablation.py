@@ -2,6 +2,8 @@
 site at a time left in fp32: the error that remains tells what that site contributes.  Sites: A (the LayerNorm-folded GEMMs read hi(rho x)),
 qk0 (ESM-C only: q / k leave the QKV projection as fp16 before their LayerNorm), qk (q / k after rotary), v, P, o (attention output), mid (FFN intermediate).
 
+Lab tool of the test infrastructure (CPU only): built on oracle/ pieces like tests/half_emulate.py; nothing in the product imports it.
+
     python tools/lab/half_site_ablation.py [--kind esmc] [--layers 3] [--embed 384] [--heads 6]
 """
 import argparse, math, os, sys
