@@ -17,6 +17,8 @@ pos = (torch.arange(T, device=dev, dtype=torch.int32) % 1002).contiguous()
 ang = torch.outer(torch.arange(1002.), 1.0 / (10000 ** (torch.arange(0, d, 2) / d)))
 ang = torch.cat((ang, ang), -1)
 cos, sin = ang.cos().bfloat16().to(dev), ang.sin().bfloat16().to(dev)
+W = int(os.environ.get('ROW_WIDTH', 3))          # row of 3E = [q | k | v] as the QKV projection leaves it (default); 2: a contiguous (T, 2E) buffer of q and k only
+qkv = qkv[:, :W * E].contiguous()
 fn = lambda: _hip.qk_norm_rotary_(qkv[:, :E], qkv[:, E:2 * E], wq, wk, None, None, 1e-5, cos, sin, pos, H)
 for _ in range(5):
     fn()
@@ -30,4 +32,4 @@ for r in range(5):
     e.record(); torch.cuda.synchronize()
     ts.append(s.elapsed_time(e) / 50 * 1e3)
 t = sorted(ts)[2]
-print(f'qk_norm_rotary T={T} E={E}: {t:.1f} us per launch, {8.0 * E * T / t / 1e6:.2f} TB/s (8*E*T bytes)')
+print(f'qk_norm_rotary T={T} E={E} row stride {W}E: {t:.1f} us per launch, {8.0 * E * T / t / 1e6:.2f} TB/s (8*E*T bytes)')
