@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
         const int e0 = (c * 64 + lane) * 8;
         if (e0 < E) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; ss += d * d; }
+            for (int j = 0; j < 8; ++j) { const float d = v[c][j] - mean; ss = fmaf(d, d, ss); }
         }
     }
     const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
+    // (every product and sum below is spelled out -- no contraction freedom -- so that this kernel and the fused q/k LayerNorm + rotary pass, which
+    // must equal it bit for bit, compute the same bits in every instantiation: hipcc's own fma pairing differed between NCH = 2 / 10 and the rest)
     u16* yr = y + row * ldy;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -136,10 +138,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const u16* __restrict__ 
                 float bfv[8];
                 unpack8(*reinterpret_cast<const u32x4*>(b + e0), bfv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+                for (int j = 0; j < 8; ++j) o[j] = fmaf(__fmul_rn(v[c][j] - mean, rstd), wf[j], bfv[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
+                for (int j = 0; j < 8; ++j) o[j] = __fmul_rn(__fmul_rn(v[c][j] - mean, rstd), wf[j]);
             }
             *reinterpret_cast<u32x4*>(yr + e0) = pack8(o);
         }
@@ -518,12 +520,31 @@ __global__ __launch_bounds__(256) void pair_to_f32_kernel(const u16* __restrict_
 // rotary partner of a lane's 8 elements (d/2 further inside the head) lives d/16 lanes away, so
 // the exchange is four 32-bit lane shuffles.  One read + one write of q and k: 8*E bytes per row,
 // instead of three passes (two LayerNorms + rotary).
-// The pass is bound by vector-memory INSTRUCTIONS, not bytes (a 64-lane 16-byte access occupies the address
-// unit ~16 cycles; ~10 B/clk/CU): the first version issued 15 per 2.3 KB row item (3 row loads, 3 weight, 3
-// cos, 3 sin, 3 stores) and ran at 4.2 TB/s.  Here the LayerNorm weights (biases) of the wave's type are loaded
-// once for its RPW rows, and the cos / sin chunk of a lane is the same for every 64-lane chunk of the row
-// (512 elements per chunk step is a multiple of the head dim), so it is ONE load each per row: 8 + 6 / RPW.
+// The LayerNorm weights (biases) of the wave's type are loaded once for its RPW rows, and the cos / sin chunk of a lane is the same for
+// every 64-lane chunk of the row (512 elements per chunk step is a multiple of the head dim), so it is ONE load each per row: 8 + 6 / RPW
+// vector-memory instructions per 2.3 KB row item.  What bounds the pass since then is LATENCY x occupancy (round 5, profiles/r05_qk_norm_ab.txt):
+// a row's first store waits for a full-row reduction and the kernel needs ~100 - 120 VGPRs (4 waves per SIMD), so it is written memory-first
+// (positions of all the wave's rows, then the next row and its table chunks requested before the current row is reduced) and VALU-lean.
 // F16 (precision 'half'): q, k and the rotary tables are IEEE fp16 (the LayerNorm parameters stay bf16).
+// Sum over the 64 lanes, every lane gets the total: the xor-butterfly 32, 16, 8, 4, 2, 1 of wave_sum() -- the SAME additions in the same order, hence the same
+// bits -- on the VALU's cross-lane paths (v_permlane32_swap / v_permlane16_swap, DPP row_ror / quad_perm) instead of six dependent ds_bpermute round trips
+// through the LDS unit.  (After a step, lanes that are congruent modulo the step hold identical sums, so a rotation by the step is as good as the xor.)
+__device__ __forceinline__ float wave_sum_valu(float v) {
+    {
+        const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);      // {[lo | lo], [hi | hi]}: own + lane ^ 32
+        v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+    }
+    {
+        const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);      // own + lane ^ 16
+        v = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+    }
+    v += dpp_f32<0x128>(v);      // row_ror:8
+    v += dpp_f32<0x124>(v);      // row_ror:4
+    v += dpp_f32<0x4E>(v);       // quad_perm [2, 3, 0, 1]: lane ^ 2
+    v += dpp_f32<0xB1>(v);       // quad_perm [1, 0, 3, 2]: lane ^ 1
+    return v;
+}
+
 template <int NCH, int RPW, bool F16 = false>
 __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q, u16* __restrict__ k, int64_t ld,
                                                              const u16* __restrict__ wq, const u16* __restrict__ wk,
@@ -538,13 +559,20 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
     if (row0 >= T) return;
     const u16* w = is_k ? wk : wq;
     const u16* b = is_k ? bk : bq;
-    u32x4 wraw[NCH], braw[NCH];
+    // The pass is bound by VALU ISSUE, not by bytes (round 5: ~600 vector instructions per 2.3 KB row item = 63 us of issue per SIMD at the ESMC-600M shape,
+    // against 47 us of memory time): the LayerNorm weights of the wave's rows are unpacked once, the rotation's sign is folded into the sine once per row,
+    // lanes past the row's end skip the arithmetic (the rotary partner lane ^ d/16 of an active lane is active: E is a multiple of d), and the two row
+    // reductions run on the VALU's cross-lane paths.
+    float wf[NCH][8];
+    u32x4 braw[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int e0 = (c * 64 + lane) * 8;
-        wraw[c] = braw[c] = u32x4{0u, 0u, 0u, 0u};
+        braw[c] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[c][j] = 0.f;
         if (e0 < E) {
-            wraw[c] = *reinterpret_cast<const u32x4*>(w + e0);
+            unpack8(*reinterpret_cast<const u32x4*>(w + e0), wf[c]);
             if (b) braw[c] = *reinterpret_cast<const u32x4*>(b + e0);
         }
     }
@@ -552,85 +580,97 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
     const int local = (lane * 8) % d;                   // position inside the head: the same for every chunk step
     const bool lower = local < half;
     const int jc = lower ? local : local - half;
+    const float sgn = lower ? -1.0f : 1.0f;             // lower half: lo c - up s; upper: up c + lo s
     const float inv_e = 1.0f / (float)E;
+    // Memory first: a row's first store waits for a full-row reduction, so what hides the load latency is rows in flight.  The positions of all the wave's
+    // rows and the first row are requested before anything else; inside the loop the NEXT row and its table chunks are requested before this row is reduced.
+    int prow[RPW];
+#pragma unroll
+    for (int it = 0; it < RPW; ++it) prow[it] = pos[row0 + it < T ? row0 + it : T - 1];
+    u32x4 cur[NCH], nxt[NCH];
+    {
+        const u16* x0 = (is_k ? k : q) + row0 * ld;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { const int e0 = (c * 64 + lane) * 8; cur[c] = e0 < E ? *reinterpret_cast<const u32x4*>(x0 + e0) : u32x4{0u, 0u, 0u, 0u}; }
+    }
+    u32x4 craw, sraw, cnxt, snxt;
+    {
+        int p = prow[0];
+        p = p < max_len ? p : max_len - 1;
+        craw = *reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc);
+        sraw = *reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc);
+    }
+#pragma unroll
     for (int it = 0; it < RPW; ++it) {
         const int64_t row = row0 + it;
         if (row >= T) break;
         u16* xr = (is_k ? k : q) + row * ld;
-        int p = pos[row];
-        p = p < max_len ? p : max_len - 1;
-        // (round 5 A/B: ONE partial vector load of the row's 2 * d/16 distinct table chunks + ds_bpermute instead of these two full-wave
-        // loads changes nothing -- 66.6 / 67.5 / 68.1 us against 66.1 / 65.7 / 69.3 on one box at the ESMC-600M shape: the pass is no longer
-        // bound by vector-memory instructions; profiles/r05_qk_norm_ab.txt)
-        const u32x4 craw = *reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc);
-        const u32x4 sraw = *reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc);
+        if (it + 1 < RPW && row + 1 < T) {
+            const u16* xn = xr + ld;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { const int e0 = (c * 64 + lane) * 8; nxt[c] = e0 < E ? *reinterpret_cast<const u32x4*>(xn + e0) : u32x4{0u, 0u, 0u, 0u}; }
+            int p = prow[it + 1 < RPW ? it + 1 : it];
+            p = p < max_len ? p : max_len - 1;
+            cnxt = *reinterpret_cast<const u32x4*>(cosT + (int64_t)p * d + jc);
+            snxt = *reinterpret_cast<const u32x4*>(sinT + (int64_t)p * d + jc);
+        }
         float v[NCH][8];
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e0 = (c * 64 + lane) * 8;
             if (e0 < E) {
-                unpack8t<F16>(*reinterpret_cast<const u32x4*>(xr + e0), v[c]);
+                unpack8t<F16>(cur[c], v[c]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[c][j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
             }
         }
-        const float mean = wave_sum(s) * inv_e;
+        const float mean = wave_sum_valu(s) * inv_e;
         float ss = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e0 = (c * 64 + lane) * 8;
             if (e0 < E) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float dv = v[c][j] - mean; ss += dv * dv; }
+                for (int j = 0; j < 8; ++j) { const float dv = v[c][j] - mean; ss = fmaf(dv, dv, ss); }
             }
         }
-        const float rstd = rsqrtf(wave_sum(ss) * inv_e + eps);
+        const float rstd = rsqrtf(wave_sum_valu(ss) * inv_e + eps);
         float cs[8], sn[8];
         unpack8t<F16>(craw, cs);
         unpack8t<F16>(sraw, sn);
 #pragma unroll
+        for (int j = 0; j < 8; ++j) sn[j] *= sgn;            // (exact: fmul(o2, -s) = -fmul(o2, s))
+#pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e0 = (c * 64 + lane) * 8;
-            const bool ok = e0 < E;
-            u32x4 y = {0u, 0u, 0u, 0u};
-            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                float wf[8];
-                unpack8(wraw[c], wf);
+            if (e0 < E) {                                     // (lane-divergent only in the last chunk; the partner lane takes the same branch)
+                float o[8];
+                // (every product and sum spelled out: no contraction freedom, the same bits in every instantiation)
                 if (b) {
                     float bfv[8];
                     unpack8(braw[c], bfv);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j] + bfv[j];
+                    for (int j = 0; j < 8; ++j) o[j] = fmaf(__fmul_rn(v[c][j] - mean, rstd), wf[c][j], bfv[j]);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * wf[j];
+                    for (int j = 0; j < 8; ++j) o[j] = __fmul_rn(__fmul_rn(v[c][j] - mean, rstd), wf[c][j]);
                 }
-                if constexpr (!F16) y = pack8(o);             // bf16 rounding point of the LayerNorm output (the reference's; precision 'half'
-                                                              // answers to the fp32 forward instead and keeps the fp32 values: one rounding fewer on q, k)
-            }
-            float a[8], o2[8];
-            if constexpr (F16) {
+                float a[8], o2[8];
+                if constexpr (F16) {                          // precision 'half' answers to the fp32 forward and keeps the fp32 values: one rounding fewer on q, k
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { a[j] = o[j]; o2[j] = __shfl_xor(o[j], shift, 64); }
-            } else {
-                u32x4 other;
+                    for (int j = 0; j < 8; ++j) { a[j] = o[j]; o2[j] = __shfl_xor(o[j], shift, 64); }
+                } else {
+                    const u32x4 y = pack8(o);                 // bf16 rounding point of the LayerNorm output (the reference's)
+                    u32x4 other;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
-                unpack8(y, a);
-                unpack8(other, o2);
-            }
-            if (ok) {
+                    for (int i = 0; i < 4; ++i) other[i] = (unsigned int)__shfl_xor((int)y[i], shift, 64);
+                    unpack8(y, a);
+                    unpack8(other, o2);
+                }
                 float r[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = __fmul_rn(o2[j], sn[j]);
-                    r[j] = fmaf(a[j], cs[j], lower ? -t : t);
-                }
+                for (int j = 0; j < 8; ++j) r[j] = fmaf(a[j], cs[j], __fmul_rn(o2[j], sn[j]));
                 if (!is_k && q_scale != 1.0f) {              // softmax_scale * log2(e) folded into q (fp32, before the rounding): attention's q_prescaled
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r[j] *= q_scale;
@@ -638,6 +678,9 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
                 *reinterpret_cast<u32x4*>(xr + e0) = pack8t<F16>(r);
             }
         }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+        craw = cnxt; sraw = snxt;
     }
 }
 
