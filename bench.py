@@ -39,7 +39,9 @@ for _p in (ROOT, os.path.join(ROOT, 'esm-efficient_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+_t_import = time.perf_counter()
 import torch
+_IMPORT_S = time.perf_counter() - _t_import
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md (measured 2495)
 PEAK_HBM_GBS = 8000.0
@@ -55,7 +57,7 @@ def parse():
     ap.add_argument('--seq-len', type=int, default=500)
     ap.add_argument('--batch', choices=['uniform', 'proteome'], default='uniform')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-tokens', type=int, default=8000)
+    ap.add_argument('--cpu-sample-tokens', type=int, default=4000)
     ap.add_argument('--no-gather', action='store_true', help='skip the (separately timed) logits all-gather when N>1')
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU rehearsal of the N-rank bookkeeping (gloo, NO kernel runs, logits are zeros): launcher, barriers, '
@@ -293,8 +295,31 @@ def half_leg(model, tokens, cu, max_len, steps, T, E, kind, lengths, flops_step,
     return res
 
 
+class PhaseClock:
+    """Wall-clock seconds of the UNTIMED parts of a run (checkpoint synthesis, load, setup forwards, instrumented pass, the secondary legs,
+    the CPU legs), reported as `untimed_s` so that the line says where a slow host spent the driver's time."""
+
+    def __init__(self):
+        self.t0 = self.last = time.perf_counter()
+        self.phases = {}
+
+    def mark(self, name):
+        now = time.perf_counter()
+        self.phases[name] = round(self.phases.get(name, 0.0) + now - self.last, 2)
+        self.last = now
+
+    def report(self, timed_s):
+        self.mark('other')
+        out = dict(self.phases)
+        out['timed_region'] = round(timed_s, 2)
+        out['total_since_main'] = round(time.perf_counter() - self.t0, 2)
+        out['import_torch_before_main'] = round(_IMPORT_S, 2)
+        return out
+
+
 def main():
     args = parse()
+    clock = PhaseClock()
     launched = 'RANK' in os.environ                 # under torch.distributed.run (driver's N>1 form, or self_launch)
     if not launched and (args.gpus > 1 or args.spawn or args.dry_run):
         self_launch(args)
@@ -326,6 +351,7 @@ def main():
 
     # ---- synthetic checkpoint in the reference layout -> from_pretrained
     weights = syn.synthetic_state_dict(kind, L, E, seed=0)
+    clock.mark('synthesise_checkpoint')
     with tempfile.TemporaryDirectory() as td:
         from safetensors.torch import save_file
         path = os.path.join(td, f'{args.model}.safetensors')
@@ -334,6 +360,7 @@ def main():
                                     device=str(dev))
     if args.precision != 'fast':
         model.set_precision(args.precision)
+    clock.mark('write_and_load_checkpoint')
 
     # ---- this rank's packed batch (resident in HBM before the timed region)
     if args.batch == 'uniform':
@@ -360,6 +387,7 @@ def main():
         for _ in range(2):
             step()
         fence()
+        clock.mark('setup_forwards')
         for i in range(args.warmup):
             step()
         fence()
@@ -370,6 +398,8 @@ def main():
             ev[i][1].record()
         fence()
         elapsed = time.perf_counter() - t0
+    clock.mark('warmup_and_timed_steps')
+    timed_s = elapsed
     step_ms = sorted(s.elapsed_time(e) for s, e in ev)
     multi = None
     if launched:
@@ -487,6 +517,7 @@ def main():
         if 'dequant4_ms' in hbm:
             hbm['dequant4'] = round(hbm.pop('dequant4_bytes') / (hbm.pop('dequant4_ms') * 1e-3) / 1e9, 1)
         result['hbm_bound_GBps'] = hbm
+        clock.mark('instrumented_pass')
         # ---- the same batch through precision 'half' (fp16 MFMA operands, fp16-pair residual stream, fp32 logits): the mode that meets
         # north_star's 1e-3 in one pass.  After the timed region, its own fences, per-step HIP events and its own roofline object; reported
         # beside the headline, never as `value`.  Then the same on the ill-conditioned probe model (massive stream channels: the regime
@@ -505,24 +536,28 @@ def main():
                 result['precision_half'] = {'skipped': f'{type(e).__name__}: {e}'[:300]}
             finally:
                 model.set_precision('fast')
+            clock.mark('half_leg')
             if half_rows is not None and kind == 'esm2' and not args.no_cpu_baseline:
+                # the probe model is the SAME synthetic state dict with 1 + 2L small tensors patched (massive_channel_state_dict(base=...)): the
+                # loaded model is patched in place and restored afterwards -- no second 650 M-parameter synthesis, no second checkpoint file
+                patched = syn.massive_channel_patched_names(L)
                 try:
-                    w_out, _ = syn.massive_channel_state_dict(L, E, 50.0, seed=0)
-                    with tempfile.TemporaryDirectory() as td2:
-                        from safetensors.torch import save_file
-                        path2 = os.path.join(td2, 'probe.safetensors')
-                        save_file(w_out, path2, metadata=syn.checkpoint_metadata(args.model, L, E, H))
-                        m2 = ESM.from_pretrained(path2, device=str(dev)).set_precision('half')
-                    h2 = half_leg(m2, tokens, cu, max_len, max(1, min(hs, 3)), T, E, kind, lengths, flops_step, rooflines=False)
+                    w_out, _ = syn.massive_channel_state_dict(L, E, 50.0, seed=0, base=weights)
+                    model.load_state_dict({n: w_out[n] for n in patched}, strict=False)
+                    model.set_precision('half')
+                    h2 = half_leg(model, tokens, cu, max_len, max(1, min(hs, 3)), T, E, kind, lengths, flops_step, rooflines=False)
                     outlier = (w_out, h2.pop('rows'))
                     h2['weights'] = ('synthetic + 4 massive stream channels (embedding columns and FFN-down biases x 50, two attention-LayerNorm '
                                      'gains x 10: esme.synthetic.massive_channel_state_dict), the probe model of tools/half_outlier_probe.py')
                     h2['vs_fast_mode'] = round(h2['ms_per_step'] / ms_per_step, 4)
                     result['precision_half']['outlier_model'] = h2
-                    del m2
                 except Exception as e:       # (a secondary leg: report, never fail the run)
                     outlier = None
                     result['precision_half']['outlier_model'] = {'skipped': f'{type(e).__name__}: {e}'[:300]}
+                finally:
+                    model.load_state_dict({n: weights[n] for n in patched}, strict=False)
+                    model.set_precision('fast')
+                clock.mark('half_leg_outlier_model')
         if not args.no_cpu_baseline and world == 1:          # CPU leg: rank 0 of the single-GPU run only
             n = min(args.cpu_sample_tokens, T)
             n = max(args.seq_len, n // args.seq_len * args.seq_len) if n >= args.seq_len else n      # whole sequences only
@@ -543,6 +578,8 @@ def main():
                         parity['rel_fro_half_outlier_model_vs_oracle_fp32'] = round(float((got - ref32).norm() / ref32.norm()), 6)
                     except Exception as e:
                         parity['rel_fro_half_outlier_model_vs_oracle_fp32'] = f'skipped: {type(e).__name__}'
+            clock.mark('cpu_oracle_legs')
+        result['untimed_s'] = clock.report(timed_s)
         print(json.dumps(result), flush=True)
     if launched:
         dist.barrier()

@@ -68,19 +68,46 @@ def gather_rows_all_ranks(local: torch.Tensor, counts: Sequence[int], group=None
     return torch.cat([recv[r * tmax:r * tmax + counts[r]] for r in range(world)])
 
 
+_LOGIT_METHODS = ('forward', '__call__', 'predict_log_prob', 'predict_prob')
+
+
 def _output_spec(forward, out_width, out_dtype):
-    """(width, dtype) of `forward`'s rows for a rank that has no sequence to run.  Both are known locally -- from the arguments, or from
-    the model when `forward` is a model or a bound method of one (vocab_size; fp32 logits in precision 'exact' / 'half', bf16
-    otherwise) -- so no collective is spent on them."""
-    model = forward if hasattr(forward, 'vocab_size') else getattr(forward, '__self__', None)
-    if model is not None and hasattr(model, 'vocab_size'):
-        if out_width is None:
-            out_width = model.vocab_size
-        if out_dtype is None:
-            out_dtype = torch.float32 if getattr(model, 'precision', 'fast') in ('exact', 'half') else torch.bfloat16
-    if out_width is None or out_dtype is None:
-        raise ValueError('sharded_forward: a rank without sequences needs out_width / out_dtype (pass them, or pass the model / a bound model method)')
-    return int(out_width), out_dtype
+    """(width, dtype) of `forward`'s rows for a rank that has no sequence to run, or None when they cannot be PROVEN locally.  They are
+    known locally from the arguments, or from the model when `forward` is a model or one of its LOGIT-returning bound methods
+    (`forward` / `predict_log_prob` / `predict_prob`: vocab_size wide; fp32 in precision 'exact' / 'half', bf16 otherwise).  Any other
+    callable (`model.forward_representation`, a lambda around it, ...) has rows this function knows nothing about: the caller then
+    agrees on them with one small collective (a (0, vocab) block against (tmax, embed_dim) blocks would hang the gather)."""
+    if out_width is not None and out_dtype is not None:
+        return int(out_width), out_dtype
+    model = None
+    if hasattr(forward, 'vocab_size') and hasattr(forward, 'forward_representation'):
+        model = forward                                       # the model itself: model(...) returns logits
+    elif getattr(forward, '__name__', None) in _LOGIT_METHODS and hasattr(getattr(forward, '__self__', None), 'vocab_size'):
+        model = forward.__self__
+    if model is None:
+        return None
+    width = model.vocab_size if out_width is None else out_width
+    dtype = out_dtype if out_dtype is not None else (
+        torch.float32 if getattr(model, 'precision', 'fast') in ('exact', 'half') else torch.bfloat16)
+    return int(width), dtype
+
+
+_DTYPE_CODES = (torch.bfloat16, torch.float32, torch.float16, torch.float64)
+
+
+def _agree_output_spec(out_r, device, group):
+    """One MAX all-reduce of (width, dtype code) for callables whose row shape is not known locally (see _output_spec): ranks that ran
+    contribute their output's, idle ranks zeros.  Only taken when some rank is idle AND the spec is unknown -- every rank takes the same
+    branch because both conditions are functions of the (identical) plan and arguments."""
+    import torch.distributed as dist
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if out_r is not None:
+        meta[0], meta[1] = out_r.shape[1], _DTYPE_CODES.index(out_r.dtype) + 1
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+    width, code = int(meta[0]), int(meta[1])
+    if code == 0:
+        raise ValueError('sharded_forward: no rank produced an output (empty batch) and out_width / out_dtype were not given')
+    return width, _DTYPE_CODES[code - 1]
 
 
 def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], torch.Tensor],
@@ -90,7 +117,9 @@ def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], 
     batch and return the logits of the WHOLE batch, in input order, on every rank.  ONE collective: the logits all-gather.
 
     `tokens` / `cu_lens` are the full (host) batch, identical on all ranks.  `out_width` / `out_dtype`: shape of `forward`'s rows,
-    needed only by a rank that receives no sequence (fewer sequences than ranks) when `forward` is not a model / bound model method.
+    used only when some rank receives no sequence (fewer sequences than ranks); unnecessary for a model or its logit methods
+    (`model`, `model.forward`, `model.predict_log_prob`, `model.predict_prob`), and for any other callable their absence costs one extra
+    16-byte all-reduce in that case instead of a wrong guess.
     """
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -103,9 +132,12 @@ def sharded_forward(forward: Callable[[torch.Tensor, Tuple[torch.Tensor, int]], 
         out_r = forward(tok_r.to(device), (cu_r.to(device), max_r))
     else:
         out_r = None
-    if out_r is None:                                     # width and dtype are known locally: no second collective
-        width, dtype = _output_spec(forward, out_width, out_dtype)
-        out_r = torch.zeros(0, width, dtype=dtype, device=device)
+    if any(c == 0 for c in counts):                       # some rank is idle (every rank sees the same plan)
+        spec = _output_spec(forward, out_width, out_dtype)        # a function of the arguments only: the same answer on every rank
+        if spec is None:                                  # rows of an arbitrary callable: agree with one tiny collective (never for logits)
+            spec = _agree_output_spec(out_r, device, group)
+        if out_r is None:
+            out_r = torch.zeros(0, spec[0], dtype=spec[1], device=device)
     gathered = gather_rows_all_ranks(out_r, counts, group)
     # gathered holds rank 0's sequences, then rank 1's, ...: build the inverse permutation
     src = np.concatenate([np.arange(cu[i], cu[i + 1]) for p in plan for i in p]) if len(lengths) else np.zeros(0, int)

@@ -122,13 +122,19 @@ def synthetic_state_dict(kind: str, num_layers: int, embed_dim: int, seed: int =
             for n, s in tensor_shapes(kind, num_layers, embed_dim).items()}
 
 
-def massive_channel_state_dict(num_layers: int, embed_dim: int, scale: float, seed: int = 2, n_channels: int = 4, gain_layers=None):
+def massive_channel_state_dict(num_layers: int, embed_dim: int, scale: float, seed: int = 2, n_channels: int = 4, gain_layers=None, base=None):
     """The ill-conditioned ESM-2 probe model of tools/half_outlier_probe.py / bench.py (`precision_half.outlier_model`): the synthetic
     weights with `n_channels` residual-stream channels made MASSIVE -- their embedding columns and FFN-down biases multiplied by `scale`
     (so every layer feeds them again), the attention LayerNorm gains of the first two by min(scale, 10) (which pushes attention scores
     into the hundreds) -- the regime trained checkpoints are known for and N(0, 0.02) weights are not.  `gain_layers`: the layers whose gains are
-    raised (default: all).  Returns (state dict, channel ids)."""
-    w = synthetic_state_dict('esm2', num_layers, embed_dim, seed=seed)
+    raised (default: all).  `base`: an already synthesised state dict of the same (num_layers, embed_dim, seed) -- the result then SHARES every
+    untouched tensor with it and clones only the 1 + 2L patched ones (bench.py: no second 650 M-parameter synthesis).  Returns (state dict, channel ids)."""
+    if base is None:
+        w = synthetic_state_dict('esm2', num_layers, embed_dim, seed=seed)
+    else:
+        w = dict(base)
+        for n in massive_channel_patched_names(num_layers):
+            w[n] = base[n].clone()
     g = torch.Generator().manual_seed(0)
     cols = torch.randperm(embed_dim, generator=g)[:n_channels]
     w['embed_tokens.weight'][:, cols] *= scale
@@ -136,6 +142,35 @@ def massive_channel_state_dict(num_layers: int, embed_dim: int, scale: float, se
         w[f'layers.{i}.final.3.bias'][cols] *= scale
         if gain_layers is None or i in gain_layers:
             w[f'layers.{i}.self_attn.norm.weight'][cols[:2]] *= min(scale, 10.0)
+    return w, cols
+
+
+def massive_channel_patched_names(num_layers: int) -> List[str]:
+    """The tensors massive_channel_state_dict changes (everything else equals the plain synthetic state dict of the same seed)."""
+    names = ['embed_tokens.weight']
+    for i in range(num_layers):
+        names += [f'layers.{i}.final.3.bias', f'layers.{i}.self_attn.norm.weight']
+    return names
+
+
+def token_outlier_state_dict(kind: str, num_layers: int, embed_dim: int, scale: float, token_ids, seed: int = 2, n_channels: int = 4,
+                             gain_scale: float = 10.0, base=None):
+    """Counter-example model for the calibration of precision 'half' (VERDICT r5 item 1): the massive channels exist ONLY in the embedding
+    rows of `token_ids` (e.g. `X`, `<unk>`, `<mask>`): those rows' entries in `n_channels` columns are set to +-`scale` (the typical entry is
+    N(0, 1)), and the attention LayerNorm gains of the first two of these channels are multiplied by `gain_scale` in every layer.  A
+    calibration batch that never contains these tokens sees a perfectly benign model.  Returns (state dict, channel ids)."""
+    w = dict(base) if base is not None else synthetic_state_dict(kind, num_layers, embed_dim, seed=seed)
+    g = torch.Generator().manual_seed(1)
+    cols = torch.randperm(embed_dim, generator=g)[:n_channels]
+    emb = w['embed_tokens.weight'].clone()
+    for t in token_ids:
+        sign = torch.where(torch.rand(n_channels, generator=g) < 0.5, -1.0, 1.0)
+        emb[int(t), cols] = (sign * scale).to(emb.dtype)
+    w['embed_tokens.weight'] = emb
+    for i in range(num_layers):
+        n = f'layers.{i}.self_attn.norm.weight'
+        w[n] = w[n].clone()
+        w[n][cols[:2]] *= gain_scale
     return w, cols
 
 

@@ -224,7 +224,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, lengths, out_path, dtype=torch.bfloat16):
+def _worker(rank, world, port, lengths, out_path, dtype=torch.bfloat16, pass_spec=True):
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, 'esm-efficient_amd'))
     from esme import shard, synthetic as syn
@@ -241,7 +241,10 @@ def _worker(rank, world, port, lengths, out_path, dtype=torch.bfloat16):
         out[:, 0] = pos.to(torch.bfloat16)             # position inside its own sequence
         return out.to(dtype)
 
-    full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu', out_width=8, out_dtype=dtype)     # (known locally: no second collective)
+    if pass_spec:
+        full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu', out_width=8, out_dtype=dtype)     # (known locally: no second collective)
+    else:
+        full = shard.sharded_forward(fake_forward, tokens, cu, 'cpu')      # an arbitrary callable: the idle rank learns width / dtype from one tiny all-reduce
     if rank == 0:
         torch.save(full, out_path)
     dist.barrier()
@@ -280,6 +283,40 @@ def test_sharded_forward_gloo_world2_fp32_logits_and_an_empty_rank():
     ref = table[tokens].clone()
     ref[:, 0] = torch.arange(11).to(torch.bfloat16)
     assert full.dtype == torch.float32 and torch.equal(full, ref.float())
+
+
+def test_sharded_forward_gloo_world2_unknown_callable_and_an_empty_rank():
+    """`forward` is an arbitrary callable (think model.forward_representation: rows are embed_dim wide, not vocab_size) and one
+    rank is idle.  The idle rank must not GUESS a logits-shaped block (mismatched all_gather sizes hang): without out_width / out_dtype the
+    ranks agree on the row shape with one small all-reduce."""
+    from esme import synthetic as syn
+    lengths = [9]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'full.pt')
+        mp.spawn(_worker, args=(2, _free_port(), lengths, out, torch.float32, False), nprocs=2, join=True)
+        full = torch.load(out)
+    assert full.dtype == torch.float32 and full.shape == (9, 8)
+
+
+def test_output_spec_is_only_inferred_for_logit_methods():
+    from esme import shard
+
+    class FakeModel:
+        vocab_size, precision = 33, 'half'
+        def forward(self, *a): ...
+        def predict_log_prob(self, *a): ...
+        def forward_representation(self, *a): ...
+        __call__ = forward
+
+    m = FakeModel()
+    assert shard._output_spec(m, None, None) == (33, torch.float32)
+    assert shard._output_spec(m.forward, None, None) == (33, torch.float32)
+    assert shard._output_spec(m.predict_log_prob, None, None) == (33, torch.float32)
+    m.precision = 'fast'
+    assert shard._output_spec(m.predict_log_prob, None, None) == (33, torch.bfloat16)
+    assert shard._output_spec(m.forward_representation, None, None) is None          # embed_dim-wide rows: not guessed
+    assert shard._output_spec(lambda t, p: None, None, None) is None
+    assert shard._output_spec(m.forward_representation, 1280, torch.bfloat16) == (1280, torch.bfloat16)
 
 
 def test_feedforward_head_module():
