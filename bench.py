@@ -257,6 +257,17 @@ def half_leg(model, tokens, cu, max_len, steps, T, E, kind, lengths, flops_step,
     assert torch.isfinite(out_h).all()
     ems = sorted(s.elapsed_time(e) for s, e in ev)
     plan = model.half_plan()
+    # the run-time plan guard (model.check_plan): the device maxima of every forward of this leg against the plan the mode ran with
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        verdict = model.check_plan(update=False)
+    guard = ({'verdict': 'plan holds on this batch', 'checked': 'largest |value| of every stream channel after every branch of every layer vs the median channel '
+                                                                   f'(threshold {model.HALF_CHANNEL_RATIO}x outside the extension tile); score bound of every layer without q/k pairs '
+                                                                   f'(threshold {model.HALF_SCORE_BOUND})'}
+             if verdict is None else {'verdict': 'STALE', 'channels': verdict['channels'][:8], 'layers': verdict['layers'][:8]})
+    if getattr(model, '_half_guard', None) is None:
+        guard = {'verdict': 'guard off'}
     res = {'what': "model.set_precision('half'): IEEE fp16 MFMA operands (the bf16 checkpoint converts exactly; LayerNorm gains folded as "
                    "powers of two, the rest rides on the stream), residual stream as an fp16 pair, split-operand LM head, fp32 logits; "
                    "same batch, after the timed region",
@@ -265,7 +276,7 @@ def half_leg(model, tokens, cu, max_len, steps, T, E, kind, lengths, flops_step,
            'value': round(T / (h_ms * 1e-3), 1), 'unit': 'residues/s',
            'frac_bf16_mfma_peak': round(flops_step / (h_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            'plan': {'extension_channels': 0 if plan.ext_sel is None else int(plan.ext_sel.numel()), 'qk_pairs': bool(plan.qk_pair),
-                    **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in plan.info.items()}},
+                    **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in plan.info.items()}, 'guard': guard},
            'rows': out_h}
     if rooflines:
         with torch.no_grad():

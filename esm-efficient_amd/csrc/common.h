@@ -116,6 +116,48 @@ __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_u32(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// ---- plan guard of precision 'half' (esme_gemm_fusion_t.col_absmax / .qk_sumsq): running maxima kept next to results that are in registers anyway.
+// |x| of two packed fp16 values as unsigned 16-bit integers: non-negative IEEE fp16 bit patterns order like integers (inf = 0x7c00 above
+// every finite value, NaN above inf: a non-finite value sticks as "huge"), so the running column maximum is ONE v_pk_max_u16 per dword.
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+__device__ __forceinline__ unsigned int pk_absmax_f16(unsigned int acc, unsigned int v) {
+    const u16x2 a = __builtin_bit_cast(u16x2, acc), b = __builtin_bit_cast(u16x2, v & 0x7fff7fffu);
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(a, b));
+}
+__device__ __forceinline__ unsigned int pk_max_u16(unsigned int x, unsigned int y) {
+    return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y)));
+}
+// max over the 8 lanes {l, l ^ 8, l ^ 16, ..., l ^ 56} (the lanes of a wave that hold the same 16-byte column chunk in the slab store layout):
+// row_ror:8 inside the 16-lane row, then v_permlane16_swap / v_permlane32_swap -- VALU cross-lane paths, no LDS
+__device__ __forceinline__ unsigned int lanes8_max_pk_u16(unsigned int v) {
+    v = pk_max_u16(v, dpp_u32<0x128>(v));
+    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = pk_max_u16(a[0], a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return pk_max_u16(b[0], b[1]);
+}
+__device__ __forceinline__ float lanes8_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<0x128>(v));
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+// sum of squares of 8 packed fp16 values in fp32 (v_dot2_f32_f16: both products exact, fp32 accumulation)
+__device__ __forceinline__ float sumsq8_f16(const u32x4 v) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const f16x2 h = __builtin_bit_cast(f16x2, v[i]); s = __builtin_amdgcn_fdot2(h, h, s, false); }
+    return s;
+}
+// running maximum of a NON-NEGATIVE float kept in memory as its bit pattern (integer order = float order there; NaN / inf stick on top)
+__device__ __forceinline__ void atomic_max_nonneg(unsigned int* p, float v) { atomicMax(p, __float_as_uint(v)); }
+
 // erf-form GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x) -- the form the reference uses (nn.GELU() /
 // F.gelu default: attention.py:233, head.py:26), NOT the tanh approximation.  Written as
 //     gelu(x) = max(x, 0) - |x| Phi(-|x|),      Phi(-z) = 2^p(z)

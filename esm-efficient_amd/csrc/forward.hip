@@ -210,6 +210,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
             ESME_TRY(esme_hip_attn_varlen_fwd_qkpair_f16(q, k, v, 5 * Ea, 3 * Ea, w.attn, Ea, cu_lens, B, T, H, dp, max_len, m->softmax_scale, aopts.seq_order, stream));
         } else {
             if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
+            if (rot_fused && m->half_qk_sumsq) fu.qk_sumsq = m->half_qk_sumsq + (int64_t)i * 2 * H;          // plan guard: this layer's q / k row norms
             ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
             if (m->qk_norm) {
                 ESME_TRY(esme_hip_qk_norm_rotary_f16(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
@@ -221,6 +222,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         esme_gemm_fusion_t fo{};
         stream_fields(fo); fo.stats_out = w.part_b;
         fo.pair_scale_in = L.ps_attn_inv; fo.pair_scale_out = L.ps_ffn;               // the stream arrives scaled for this layer's attention LayerNorm, leaves scaled for its FFN LayerNorm
+        if (m->half_col_absmax) fo.col_absmax = m->half_col_absmax + (int64_t)(2 * i) * Ep;                                          // plan guard: column maxima of the stream
         ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, ldxs, w.xs, ldxs, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
         esme_gemm_fusion_t fup{};
         fup.f16 = 1; fup.overflow_flag = m->half_overflow_flag;
@@ -231,6 +233,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         esme_gemm_fusion_t fd{};
         stream_fields(fd); fd.stats_out = w.part_a;
         fd.pair_scale_in = L.ps_ffn_inv; fd.pair_scale_out = i + 1 < m->n_layers ? m->layers[i + 1].ps_attn : nullptr;    // (the final LayerNorm reads the stream unscaled)
+        if (m->half_col_absmax) fd.col_absmax = m->half_col_absmax + (int64_t)(2 * i + 1) * Ep;
         ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, w.xs, ldxs, w.xs, ldxs, T, Ep, m->ffn_dim,
                                           ESME_EPI_RESIDUAL, m->alpha, &fd, stream));
         stats = w.part_a; stats_nblk = nblk;

@@ -45,6 +45,9 @@ struct GemmArgs {
     const int32_t* ext_sel = nullptr; int ext_n = 0; int64_t ext_off = 0;     // pair stream: lo of the selected columns also goes to C[m, ext_off + slot] (the extension K-tile)
     int* ovf = nullptr;          // LN fold: set to 1 when a row's statistics are not finite (precision 'half': a stream value left fp16's range)
     int pair_cols = 0;           // PAIR output: only columns < pair_cols get their lo half (0 = all)
+    // plan guard of precision 'half' (esme_gemm_fusion_t.col_absmax / .qk_sumsq): running maxima the host compares with what the mode's calibration assumed
+    unsigned int* col_absmax = nullptr;       // pair-stream residual epilogue: per output column, max |hi| of the stored (scaled) stream, float bits
+    unsigned int* qk_sumsq = nullptr;         // fp16 LN-folded projection with fused rotary: [2][heads] max over rows of sum_c q[t, h, c]^2 (then k), float bits
     int stream_out = 0;          // host side: the results are larger than the memory-side cache -> stored with the non-temporal hint (common.h store_stream)
 };
 

@@ -738,6 +738,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         char* slab_lo = slab + RPP * ROWB;
         const f32x4* sc_in = pscale + sp * (BN / 2) + ((wn * WTN) >> 2);     // this wave's 64 columns of {1 / rho_in, rho_out}
         const f32x4* sc_out = sc_in + BN / 4;
+        // plan guard (esme_gemm_fusion_t.col_absmax): running max |hi| of the lane's 8 stored columns over the tile's rows, as packed unsigned
+        // 16-bit patterns -- 4 registers, 2 VALU per dword in the store loop (the values are in registers there anyway)
+        u32x4 cmx = {0u, 0u, 0u, 0u};
+        unsigned int* const guard_cols = a.col_absmax;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slabs
@@ -849,6 +853,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 if (col_ok && m < a.M) {
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n), v, a.stream_out);
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n), vl, a.stream_out);
+                }
+                if (guard_cols) {                              // (rows past M re-read row M - 1: harmless duplicates)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cmx[q] = pk_absmax_f16(cmx[q], v[q]);
+                }
+            }
+        }
+        if (guard_cols) {                                      // once per tile: the 8 lanes that hold the same column chunk combine, lanes 0..7 publish 8 columns each
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cmx[q] = lanes8_max_pk_u16(cmx[q]);
+            const int n = nw0 + (lane & 7) * 8;
+            if (lane < 8 && n < n_out) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    atomic_max_nonneg(guard_cols + n + 2 * q, lo16<true>(cmx[q]));
+                    atomic_max_nonneg(guard_cols + n + 2 * q + 1, hi16<true>(cmx[q]));
                 }
             }
         }
@@ -976,6 +996,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         const int rl = lane / CH, ch = lane % CH;
         const int n = nw0 + ch * 8;
         const bool col_ok = n < n_out && !(PAIR && half == 1 && a.pair_cols > 0 && en0 >= a.pair_cols);   // n_out % 8 == 0 on this path; (block-uniform) tiles right of pair_cols write no lo half
+        // plan guard (esme_gemm_fusion_t.qk_sumsq; precision 'half', plain q / k): max over the tile's rows of sum_c q[t, h, c]^2 per head -- the 8 / 4 / 2
+        // lanes that hold a head's chunks of a row combine by DPP; wave-uniform switch
+        constexpr bool QKG = F16 && LNF && ROTD > 0 && !PAIR;
+        const bool qk_guard = QKG && a.qk_sumsq != nullptr && nw0 < a.rot_cols;
+        float qk_max = 0.f;
         if (col_ok || STATS) {
 #pragma unroll
             for (int it = 0; it < RPP / RPI; ++it) {
@@ -984,6 +1009,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 ESME_LDS_CHECK(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4), 16, smem, 2 * STAGE);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (col_ok && m < a.M && ESME_TUNE_STORE_OK) store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n + (PAIR ? half * a.pair_off : 0)), v, a.stream_out);
+                if constexpr (QKG) {
+                    if (qk_guard) {
+                        float ss = sumsq8_f16(v);
+                        ss += dpp_f32<0xB1>(ss);                                   // lane ^ 1: 16 columns
+                        if constexpr (ROTD >= 32) ss += dpp_f32<0x4E>(ss);         // lane ^ 2: 32 columns
+                        if constexpr (ROTD == 64) ss += dpp_f32<0x141>(ss);        // the other quad: 64 columns
+                        qk_max = fmaxf(qk_max, ss);
+                    }
+                }
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
                     // holds 8 of the row's 64 columns of this wave; the 8 lanes of a row combine
@@ -999,6 +1033,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     ESME_LDS_CHECK(&blkst[wn * BM + wm * WTM + pass * RPP + r], 8, smem, LDS_BYTES);
                     if (ch == 0) blkst[wn * BM + wm * WTM + pass * RPP + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
                 }
+            }
+        }
+        if constexpr (QKG) {
+            if (qk_guard) {                                    // rows combine (lanes 8 apart), then one atomic per head of the wave's 64 columns
+                qk_max = lanes8_max_f32(qk_max);
+                const int ea = a.rot_cols >> 1;                // width of q (= of k)
+                if (lane < 8 && (n % ROTD) == 0 && n < a.rot_cols)
+                    atomic_max_nonneg(a.qk_sumsq + (n >= ea ? ea / ROTD : 0) + (n % ea) / ROTD, qk_max);
             }
         }
         if constexpr (PERSIST) { if (pass == 0) ESME_TRACE_SEAM(22, 1); else ESME_TRACE_SEAM(25, 1); }
@@ -1285,6 +1327,8 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     ESME_CHECK_ARG(!fu || (!fu->pair_scale_in && !fu->pair_scale_out && !fu->ext_off) || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_RESIDUAL),
                    "gemm: pair_scale_in / pair_scale_out / ext_* belong to the fp16 pair stream's residual epilogue");
     ESME_CHECK_ARG(!fu || !fu->pair_cols || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_NONE), "gemm: pair_cols belongs to the fp16 pair output");
+    ESME_CHECK_ARG(!fu || !fu->col_absmax || (fu->f16 && fu->pair_off && epilogue == ESME_EPI_RESIDUAL), "gemm: col_absmax belongs to the fp16 pair stream's residual epilogue");
+    ESME_CHECK_ARG(!fu || !fu->qk_sumsq || (fu->f16 && fu->ln_partial && fu->head_dim != 0 && !fu->pair_off), "gemm: qk_sumsq belongs to the fp16 LN-folded projection with fused rotary (single output)");
     if (fu && fu->f16 && fu->pair_off && epilogue == ESME_EPI_NONE) {   // precision 'half', q / k as pairs: pair output of the LN-folded plain projection
         ESME_CHECK_ARG(fu->ln_partial && !r32 && !fu->w_k && !fu->c32 && !fu->stats_out, "gemm: the fp16 pair output belongs to the LN-folded plain epilogue");
         ESME_CHECK_ARG(fu->pair_off >= N && fu->pair_off % 8 == 0 && ldc >= fu->pair_off + (fu->pair_cols > 0 ? fu->pair_cols : N) && fu->pair_cols >= 0 && fu->pair_cols % 256 == 0,
@@ -1305,6 +1349,8 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
                            "gemm: the extension tile is 64 columns between hi and lo (N <= ext_off, ext_off + 64 <= pair_off) with <= 64 selected columns");
             a.ext_sel = fu->ext_sel; a.ext_n = fu->ext_n; a.ext_off = fu->ext_off;
         }
+        ESME_CHECK_ARG(!fu->col_absmax || (reinterpret_cast<uintptr_t>(fu->col_absmax) & 3u) == 0, "gemm: misaligned col_absmax");
+        a.col_absmax = fu->col_absmax;
     } else if (fu && (fu->w_k || fu->pair_off || fu->c32)) {        // split-operand ('exact') mode
         if (fu->w_k) {
             ESME_CHECK_ARG(fu->w_k > 0 && fu->w_k % BK == 0 && (K == fu->w_k || K == 2 * fu->w_k), "gemm: w_k (the K of W) must be a multiple of 64 with K = w_k or K = 2 w_k (the K-tile index of W wraps once)");
@@ -1356,6 +1402,11 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
             a.ln_c1 = fu->ln_c1; a.ln_c2 = fu->ln_c2;
             a.ovf = fu->overflow_flag;
             lnf = true;
+            if (fu->qk_sumsq) {
+                ESME_CHECK_ARG(fu->f16 && fu->head_dim != 0 && !fu->pair_off && (reinterpret_cast<uintptr_t>(fu->qk_sumsq) & 3u) == 0,
+                               "gemm: qk_sumsq belongs to the fp16 LN-folded projection with fused rotary and a single (non-pair) output");
+                a.qk_sumsq = fu->qk_sumsq;
+            }
         }
         if (fu->stats_out) {                                         // emit row statistics for the next LayerNorm
             ESME_CHECK_ARG(epilogue == ESME_EPI_RESIDUAL, "gemm: row statistics are emitted by the residual epilogue");

@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -29,7 +29,8 @@ class GemmFusion(Structure):
                 ('head_dim', c_int), ('max_len', c_int), ('rot_cols', c_int), ('resid32', c_void_p), ('ld32', c_int64), ('q_scale', c_float), ('q_cols', c_int),
                 ('w_k', c_int), ('pair_off', c_int64), ('c32', c_void_p), ('ldc32', c_int64), ('f16', c_int),
                 ('pair_scale_in', c_void_p), ('pair_scale_out', c_void_p),
-                ('ext_sel', c_void_p), ('ext_n', c_int), ('ext_off', c_int64), ('pair_cols', c_int), ('overflow_flag', c_void_p)]
+                ('ext_sel', c_void_p), ('ext_n', c_int), ('ext_off', c_int64), ('pair_cols', c_int), ('overflow_flag', c_void_p),
+                ('col_absmax', c_void_p), ('qk_sumsq', c_void_p)]
 
 
 class GemmOpts(Structure):
@@ -60,7 +61,7 @@ class ModelDesc(Structure):
                 + [(n, c_void_p) for n in ('final_ln_w', 'final_ln_b', 'head_dense_w', 'head_dense_b', 'head_ln_w',
                                            'head_ln_b', 'head_final_w', 'head_final_b', 'cos', 'sin')]
                 + [('half_ext_n', c_int), ('half_ext_sel', c_void_p), ('half_qk_pair', c_int), ('half_overflow_flag', c_void_p),
-                   ('cos32', c_void_p), ('sin32', c_void_p)])
+                   ('cos32', c_void_p), ('sin32', c_void_p), ('half_col_absmax', c_void_p), ('half_qk_sumsq', c_void_p)])
 
 
 # name -> (restype, argtypes); must list every symbol include/esme_hip.h declares
@@ -743,7 +744,7 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
                ln=None, stats_out: Optional[torch.Tensor] = None, rot=None, resid32: Optional[torch.Tensor] = None,
                q_scale: float = 0.0, split_a: bool = False, pair_out: bool = False, out32: Optional[torch.Tensor] = None,
                resid_pair: Optional[torch.Tensor] = None, pair_scale=None, pair_ext: Optional[torch.Tensor] = None,
-               pair_cols: int = 0) -> torch.Tensor:
+               pair_cols: int = 0, col_absmax: Optional[torch.Tensor] = None, qk_sumsq: Optional[torch.Tensor] = None) -> torch.Tensor:
     """esme_hip_gemm_bf16_fused.  `ln` = (partial (nblk,M,2) f32 sums, dim, eps, c1 (N,) f32, c2 (N,) f32) folds the
     LayerNorm in front of this GEMM into its epilogue (w must be the gamma-scaled weight);
     `stats_out` (stats_blocks(M, N), M, 2) f32 receives per-row partial sums of the rounded output (residual
@@ -761,7 +762,10 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     (esme_gemm_fusion_t.pair_scale_in / _out: x = (hi + lo) * scale_in on entry, (x_new * scale_out) written back).  `pair_ext` (int32, <= 64
     ascending columns; the pair is then (M, 2N + 64) = [hi | ext | lo]): lo of those columns is also written to the extension K-tile.
     float16 `pair_out` with `ln` (plain epilogue): the result leaves as a float16 (hi, lo) pair, lo only for the first `pair_cols` columns
-    (out is (M, N + pair_cols); 0 = all): q and k of a fused QKV projection as pairs."""
+    (out is (M, N + pair_cols); 0 = all): q and k of a fused QKV projection as pairs.
+    Plan guard of precision 'half' (esme_gemm_fusion_t.col_absmax / .qk_sumsq; int32 tensors holding float bit patterns, running maxima, never cleared
+    here): `col_absmax` (N,) with `resid_pair`: max |hi| of the stored stream per column; `qk_sumsq` (2, heads) with float16 `ln` + `rot` (single output):
+    max over rows of the squared q / k row norm per head."""
     f16 = a.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
     if f16 and (split_a or out32 is not None or (pair_out and (ln is None or epilogue != EPI_NONE))):
@@ -804,8 +808,12 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
             if resid_pair.shape[1] != 2 * N + 64 or pair_ext.numel() > 64:
                 raise ValueError('gemm: pair_ext needs the (M, 2N + 64) pair layout and at most 64 columns')
             fu.ext_sel, fu.ext_n, fu.ext_off = _dev(pair_ext, 'pair_ext', torch.int32), pair_ext.numel(), N
-    elif pair_scale is not None or pair_ext is not None:
-        raise ValueError('gemm: pair_scale / pair_ext belong to resid_pair')
+        if col_absmax is not None:
+            if col_absmax.numel() != N or not col_absmax.is_contiguous():
+                raise ValueError('gemm: col_absmax is a contiguous int32 (N) buffer')
+            fu.col_absmax = _dev(col_absmax, 'col_absmax', torch.int32)
+    elif pair_scale is not None or pair_ext is not None or col_absmax is not None:
+        raise ValueError('gemm: pair_scale / pair_ext / col_absmax belong to resid_pair')
     if pair_out:
         if out.shape[1] != n_out + lo_cols:
             raise ValueError('gemm: a pair output is (M, n_out + pair_cols) (pair_cols = 0: 2 * n_out)')
@@ -838,7 +846,13 @@ def gemm_fused(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
         fu.head_dim, fu.max_len, fu.rot_cols = int(head_dim), int(cos.shape[0]), int(rot_cols)
         if q_scale:
             fu.q_scale, fu.q_cols = float(q_scale), int(rot_cols) // 2
+        if qk_sumsq is not None:
+            if not f16 or ln is None or pair_out or qk_sumsq.numel() != int(rot_cols) // int(head_dim) or not qk_sumsq.is_contiguous():
+                raise ValueError('gemm: qk_sumsq is a contiguous int32 (2, heads) buffer of the float16 LN-folded projection with fused rotary (single output)')
+            fu.qk_sumsq = _dev(qk_sumsq, 'qk_sumsq', torch.int32)
         tag = 'qkv_rotary'
+    if qk_sumsq is not None and rot is None:
+        raise ValueError('gemm: qk_sumsq belongs to the fused-rotary projection')
     go = _TLS.gemm_opts
     if resid32 is not None:
         tag = 'residual_f32'

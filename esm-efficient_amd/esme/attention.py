@@ -48,13 +48,14 @@ def _q_scale(head_dim: int) -> float:
 class ForwardContext:
     """Per-forward shared state: row positions, rotary tables (computed once, not per
     layer) and the LayerNorm-statistics plumbing of the fused path."""
-    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe', 'ovf', 'cos32', 'sin32')
+    __slots__ = ('pos', 'cos', 'sin', 'sums', 'part_a', 'part_b', 'fold', 'exact_attn', 'x32', 'order', 'scratch', 'f16', 'xs', 'plan', 'probe', 'ovf', 'cos32', 'sin32', 'guard')
 
     def __init__(self, pos, cos, sin, fold=False, exact_attn=False, f16=False, plan=None):
         self.pos, self.cos, self.sin = pos, cos, sin
         self.plan = plan            # precision 'half': HalfPlan (which robustness measures this model needs) or None
         self.probe = None           # calibration forward: list collecting a per-layer upper bound of |attention score|
         self.ovf = None             # precision 'half': int32 device flag of the run-time range guard (esme_gemm_fusion_t.overflow_flag)
+        self.guard = None           # precision 'half': HalfGuard -- the device maxima the plan is checked against (esme_gemm_fusion_t.col_absmax / .qk_sumsq)
         self.cos32 = self.sin32 = None    # precision 'half': float32 rotary tables of the layers whose q / k travel as pairs
         self.f16 = f16              # precision 'half': IEEE fp16 MFMA operands (weights converted once, activations rounded to fp16)
         self.fold = fold            # run the LN-folded fast path
@@ -134,18 +135,23 @@ def _fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.
 class HalfPlan:
     """What precision 'half' runs for ONE model, decided by a calibration forward (esme.esm.ESM2._calibrate_half):
 
-      ext_sel   int32 device tensor of <= 64 ascending stream channels whose rms is `ratio` times the median channel's at some LayerNorm
-                input ("massive" channels), or None.  Their lo half rides to the LayerNorm-folded GEMMs in an extension K-tile
+      ext_sel   int32 device tensor of <= 64 ascending stream channels whose largest |value| at some stream site is `ratio` times the median
+                channel's ("massive" channels), or None.  Their lo half rides to the LayerNorm-folded GEMMs in an extension K-tile
                 (esme_gemm_fusion_t.ext_sel): a single fp16 rounding of such a channel is noise of the size of the other channels' signal.
       qk_pair   q and k travel as fp16 (hi, lo) pairs, rotated with fp32 tables, and the scores come from three MFMA passes
                 (esme_hip_attn_varlen_fwd_qkpair_f16): needed once |score| reaches the hundreds (2^-12 |q||k| is then tenths of a score unit).
-      info      the measurements the decision was taken from (reported by tools / bench)."""
-    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info')
+      info      the measurements the decision was taken from (reported by tools / bench).
+      ext_key   the channel list as a host tuple: what derived weight copies are keyed on (a device address can be reused by the caching
+                allocator after a recalibration: ADVICE r5)."""
+    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info', 'ext_key')
 
     def __init__(self, ext_sel=None, qk_pair=False, info=None, qk_layers=None):
         # qk_layers: per-layer flags (the pair form is paid only where a layer's own score bound asks for it); None = every layer
         self.qk_layers = None if qk_layers is None else tuple(bool(f) for f in qk_layers)
         self.ext_sel, self.info = ext_sel, dict(info or {})
+        self.ext_key = None if ext_sel is None else tuple(int(c) for c in ext_sel.tolist())
+        if ext_sel is not None:
+            ext_sel._esme_key = self.ext_key                # travels with the tensor to the weight caches (_ext_key)
         self.qk_pair = bool(qk_pair) and (self.qk_layers is None or any(self.qk_layers))
 
     def pairs_at(self, layer: int) -> bool:
@@ -158,6 +164,34 @@ class HalfPlan:
     def describe(self) -> str:
         where = '' if (not self.qk_pair or self.qk_layers is None) else f' in {sum(self.qk_layers)} of {len(self.qk_layers)} layers'
         return f"ext channels {0 if self.ext_sel is None else self.ext_sel.numel()}, q/k pairs {'on' if self.qk_pair else 'off'}{where}"
+
+
+def _ext_key(ext_sel: torch.Tensor):
+    """Host tuple of an extension-tile channel list (set by HalfPlan; computed once for a bare tensor)."""
+    key = getattr(ext_sel, '_esme_key', None)
+    if key is None:
+        key = ext_sel._esme_key = tuple(int(c) for c in ext_sel.tolist())
+    return key
+
+
+class HalfGuard:
+    """Device side of the plan guard of precision 'half' (esme_gemm_fusion_t.col_absmax / .qk_sumsq): running maxima the kernels keep next to
+    results they hold in registers anyway, as float bit patterns in int32 tensors.
+
+      col   (2 L, phys_dim): row 2 i = max |hi| per stream column after layer i's attention branch, row 2 i + 1 after its FFN branch -- of the
+            STORED stream, i.e. times the column scaling of the LayerNorm that reads it next (ESM2._guard_scales undoes it);
+      qk    (L, 2, heads): max over rows of the squared row norm of q (then k) per head, for layers whose q / k are single fp16 values and whose
+            rotary is fused into the projection (ESM-2 / ESM-1 blocks; zeros elsewhere: not covered).
+    Sticky across forwards until `clear()`; ESM2.check_plan reads them at a synchronisation point."""
+
+    def __init__(self, n_layers: int, phys_dim: int, heads: int, device):
+        self.col = torch.zeros(2 * n_layers, phys_dim, dtype=torch.int32, device=device)
+        self.qk = torch.zeros(n_layers, 2, heads, dtype=torch.int32, device=device)
+
+    def clear(self):
+        self.col.zero_()
+        self.qk.zero_()
+        return self
 
 
 def _extend_k(wf: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
@@ -323,7 +357,7 @@ class FlashMultiheadAttention(nn.Module):
                 raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
             wf, c1, c2 = self._pack_fold(True)
             if ext_sel is not None:
-                key = (self._fold16_key, ext_sel.data_ptr())
+                key = (self._fold16_key, _ext_key(ext_sel))       # (the channel LIST, not the tensor's address: ADVICE r5)
                 if self._fold16x is None or self._fold16x[0] != key:
                     with torch.no_grad():
                         self._fold16x = (key, _extend_k(wf, ext_sel))
@@ -411,6 +445,8 @@ class FlashMultiheadAttention(nn.Module):
             raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 / pair stream (ESM-C: with the fused q/k pass)")
         plan = ctx.plan if (f16 and ctx is not None) else None
         qk_pair = bool(plan is not None and plan.pairs_at(self.layer_index))
+        guard = ctx.guard if (f16 and ctx is not None) else None
+        g_col = guard.col[2 * self.layer_index] if guard is not None else None          # plan guard: column maxima of the stream after this branch
         if qk_pair:
             # precision 'half' on a model with large attention scores: q / k leave the LN-folded projection as fp16 (hi, lo) pairs, are rotated
             # with FP32 tables (ctx.cos / ctx.sin are float32 then) and multiplied in three MFMA passes; v, P and the output stay single fp16
@@ -424,11 +460,12 @@ class FlashMultiheadAttention(nn.Module):
             a = _hip.attn_varlen_qkpair(qkv, cu_lens, max_len, H, d, self.head_dim ** -0.5, order=ctx.order)
             wo, bo = self._weights_out(True)
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid_pair=resid_pair,
-                                   pair_scale=pair_scale, pair_ext=pair_ext)
+                                   pair_scale=pair_scale, pair_ext=pair_ext, col_absmax=g_col)
         if x_stats is not None:
             wf, _, c1, c2 = self._weights_qkv(True, f16, pair_ext)
             qkv = _hip.gemm_fused(x, wf, None, ln=(x_stats, self.embed_dim, self.norm.eps, c1, c2, ctx.ovf if ctx is not None else None), rot=rot,
-                                  q_scale=_q_scale(self.head_dim) if (qp and rot_fusable) else 0.0)
+                                  q_scale=_q_scale(self.head_dim) if (qp and rot_fusable) else 0.0,
+                                  qk_sumsq=guard.qk[self.layer_index] if (guard is not None and rot is not None) else None)
         else:
             if self.padded:
                 raise NotImplementedError('padded layouts run the LayerNorm-folded path only')
@@ -454,7 +491,7 @@ class FlashMultiheadAttention(nn.Module):
         wo, bo = self._weights_out(f16)
         if resid is not None or resid32 is not None or resid_pair is not None:
             return _hip.gemm_fused(a, wo, bo, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair,
-                                   pair_scale=pair_scale, pair_ext=pair_ext)
+                                   pair_scale=pair_scale, pair_ext=pair_ext, col_absmax=g_col if resid_pair is not None else None)
         return _hip.gemm(a, wo, bo, out=out)
 
 
@@ -580,7 +617,7 @@ class FlashTransformerLayer(nn.Module):
                 raise NotImplementedError("precision='half' runs the LayerNorm-folded path on unquantised weights")
             wf, c1, c2 = self._pack_fold(True)
             if ext_sel is not None:
-                key = (self._fold16_key, ext_sel.data_ptr())
+                key = (self._fold16_key, _ext_key(ext_sel))
                 if self._fold16x is None or self._fold16x[0] != key:
                     with torch.no_grad():
                         self._fold16x = (key, _extend_k(wf, ext_sel))
@@ -633,7 +670,7 @@ class FlashTransformerLayer(nn.Module):
             return self._down_pad
         return down.weight, down.bias
 
-    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None, pair_ext=None, ovf=None):
+    def _ffn(self, x, resid, alpha, out, x_stats=None, stats_out=None, resid32=None, resid_pair=None, pair_scale=None, pair_ext=None, ovf=None, col_absmax=None):
         epi = _hip.EPI_GELU if self.final_activation == 'gelu' else _hip.EPI_SWIGLU
         f16 = x.dtype == torch.float16                       # precision 'half': the operand type travels with the tensors
         if x_stats is not None:
@@ -644,7 +681,7 @@ class FlashTransformerLayer(nn.Module):
             u = _hip.gemm_fused(self.final[0](x), w, b, epi)
         wd, bd = self._weights_down(f16)
         return _hip.gemm_fused(u, wd, bd, _hip.EPI_RESIDUAL, resid, alpha, out, stats_out=stats_out, resid32=resid32, resid_pair=resid_pair,
-                               pair_scale=pair_scale, pair_ext=pair_ext)
+                               pair_scale=pair_scale, pair_ext=pair_ext, col_absmax=col_absmax if resid_pair is not None else None)
 
     def forward_high_precision(self, x16, cu_lens, max_len, ctx: ForwardContext, next_scale=None):
         """One layer with the residual stream in fp32 (`ctx.x32`, updated in place).  `x16` = bf16(stream) is the MFMA
@@ -671,7 +708,7 @@ class FlashTransformerLayer(nn.Module):
         self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
                        resid32=r32, resid_pair=rp, pair_scale=sa, pair_ext=ext)
         self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf, pair_ext=ext,
-                  ovf=ctx.ovf)
+                  ovf=ctx.ovf, col_absmax=ctx.guard.col[2 * self.self_attn.layer_index + 1] if (ctx.f16 and ctx.guard is not None) else None)
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):

@@ -197,7 +197,7 @@ def forward_layers(model, x, cu_lens, max_len, pos, cos, sin):
 
 
 
-def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None, ovf=None, cos32=None, sin32=None):
+def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32, plan=None, ovf=None, cos32=None, sin32=None, guard=None):
     """precision 'half': fp32 stream at the start `x32` (T, phys_dim) -> all layers + final LayerNorm through ONE C call
     (esme_hip_forward_half); fills `pair` (T, 2 * phys_dim) bf16 = [hi | lo] of the final LayerNorm and `rep32` (T, phys_dim) fp32.
     `plan`: the model's HalfPlan (cos / sin are float32 tables when it asks for q / k pairs)."""
@@ -211,6 +211,8 @@ def forward_layers_half(model, x32, cu_lens, max_len, pos, cos, sin, pair, rep32
     d.table_len = int(cos.shape[0]) if cos is not None else 0
     d.half_overflow_flag = _ptr(ovf)                  # the run-time range guard (model.check_overflow reads it)
     d.cos32, d.sin32 = _ptr(cos32), _ptr(sin32)       # fp32 tables of the layers whose q / k travel as pairs
+    d.half_col_absmax = _ptr(guard.col) if guard is not None else None      # the plan guard (model.check_plan reads them)
+    d.half_qk_sumsq = _ptr(guard.qk) if guard is not None else None
     T = x32.shape[0]
     nbytes = int(lib.esme_hip_forward_half_workspace_bytes(ctypes.byref(d), T))
     ws = _workspace(model, (x32.device.index, _hip._stream(), 'half'), nbytes, x32.device)

@@ -160,22 +160,42 @@ class ESM2(nn.Module):
     # decides, once per model, whether massive stream channels get the extension K-tile and whether q / k travel as pairs
     # (esme.attention.HalfPlan); False = the plain form; True = both measures on (the channel list still comes from the calibration).
     half_robust = {'0': False, '1': True}.get(os.environ.get('ESME_HALF_ROBUST', 'auto'), 'auto')
-    HALF_CHANNEL_RATIO = 6.0       # a channel is "massive" when its rms over the calibration rows exceeds this multiple of the median channel's
+    HALF_CHANNEL_RATIO = 6.0       # a channel is "massive" when its largest |value| at some stream site exceeds this multiple of the median channel's largest |value| there
     HALF_SCORE_BOUND = 32.0        # q / k become pairs when max |q_i| max |k_j| / sqrt(d) reaches this (2^-12 relative x that = 1e-2 of a score unit)
+    # The plan is CHECKED against every batch (round 6): the residual / projection epilogues keep running maxima of exactly the two quantities
+    # above (esme.attention.HalfGuard), `check_plan()` compares them with the plan at a synchronisation point -- predict_log_prob / predict_prob
+    # do (and re-run the batch once with the widened plan when it was stale), esme.pipeline.StreamedInference does with each result -- and
+    # `model(...)` stays asynchronous: call check_plan() yourself.  ESME_HALF_GUARD=0 switches the bookkeeping off.
+    half_guard = os.environ.get('ESME_HALF_GUARD', '1') != '0'
+    half_check = 'sync'            # 'sync': predict_* check overflow + plan inline (one device synchronisation per call); 'defer': they do not -- the
+                                   # caller polls check_overflow() / check_plan() (graph replays, latency-sensitive loops)
+    HALF_CALIB_VOCAB = 'all'       # calibration tokens: 'all' = every id of the alphabet (specials, X B U Z O . -, <mask>); 'residues' = ids 4..23 + cls / eos (round 5)
 
-    def set_precision(self, mode: str, robust=None):
+    def set_precision(self, mode: str, robust=None, calib=None):
         """'fast' (default), 'high' (fp32 residual stream), 'half' (fp16 MFMA operands, fp16-pair residual stream: ~4e-4 of the fp32
         forward, fp32 outputs, ~1.1x the time) or 'exact' (split bf16 operand pairs: the reference's fp32 forward to ~1e-5, fp32 outputs,
         ~2.2x the time); DESIGN.md section 4 has what each achieves.  `robust` ('half' only): 'auto' (default; see `half_robust`), True,
-        False, or a ready esme.attention.HalfPlan."""
+        False, or a ready esme.attention.HalfPlan.  `calib` ('half' only): `(tokens, cu_lens)` or `(tokens, (cu_lens, max_len))` of the caller's
+        OWN data, packed like a forward's input -- calibrated on in addition to the built-in whole-vocabulary batch (the plan is then decided
+        on what the model will really see; the run-time guard covers the rest)."""
         assert mode in ('fast', 'high', 'half', 'exact'), mode
-        self.precision = mode
         from esme.attention import HalfPlan
-        self._half_plan = robust if isinstance(robust, HalfPlan) else None
-        if robust is not None and not isinstance(robust, HalfPlan):
+        changed = mode != self.precision
+        self.precision = mode
+        if isinstance(robust, HalfPlan):
+            self._half_plan, changed = robust, True
+        elif robust is not None:
             assert robust in ('auto', True, False), robust
+            if robust != self.half_robust:                    # (only a CHANGE drops the plan: set_precision('half') on a calibrated model keeps it)
+                self._half_plan, changed = None, True
             self.half_robust = robust
-        self.invalidate_graphs()
+        if calib is not None:
+            tokens, rest = calib
+            cu = rest[0] if isinstance(rest, (tuple, list)) else rest
+            self._half_calib = (tokens.detach().reshape(-1).cpu().to(torch.int64), cu.detach().reshape(-1).cpu().to(torch.int32))
+            self._half_plan, changed = None, True
+        if changed:
+            self.invalidate_graphs()
         return self
 
     def half_plan(self, device=None):
@@ -190,42 +210,92 @@ class ESM2(nn.Module):
             self._half_plan = plan
         return plan
 
-    def _calibrate_half(self, device):
-        """One forward of the plain 'half' form over synthetic residues (4 sequences, 1 024 tokens, numpy PCG64: the same on every
-        machine), measuring (a) the rms of every stream channel at every layer boundary relative to the median channel and (b) an upper
-        bound of |attention score| per layer.  Nothing in it depends on the caller's data; ~L x 5 small launches, once per model."""
+    def _calibration_batch(self):
+        """The built-in calibration input: 8 sequences / 1 024 tokens from numpy PCG64 (the same on every machine) -- residues 4..23 with, for
+        HALF_CALIB_VOCAB = 'all', EVERY other id of the alphabet (<unk>, X B U Z O . -, <null_1> / |, <mask>; not <pad>, which never occurs in a
+        packed input) sprinkled over 8 interior positions each, <cls> / <eos> at the ends; then the caller's own batch if one was given
+        (set_precision(..., calib=)).  Returns (tokens int64, cu_lens int32, max_len) on the host."""
         import numpy as np
-        from esme.attention import HalfPlan
         rng = np.random.Generator(np.random.PCG64(20250929))
-        lengths = [384, 320, 192, 128]
-        toks = []
-        for n in lengths:
-            body = rng.integers(4, 24, size=n - 2)
-            toks.append(np.concatenate(([self.alphabet.cls_idx], body, [self.alphabet.eos_idx])))
-        tokens = torch.from_numpy(np.concatenate(toks).astype(np.int64)).to(device)
-        cu = torch.tensor(np.concatenate(([0], np.cumsum(lengths))), dtype=torch.int32, device=device)
+        al = self.alphabet
+        lengths = [192, 160, 160, 128, 128, 96, 96, 64]
+        toks = [np.concatenate(([al.cls_idx], rng.integers(4, 24, size=n - 2), [al.eos_idx])) for n in lengths]
+        tokens = np.concatenate(toks).astype(np.int64)
+        if self.HALF_CALIB_VOCAB == 'all':
+            starts = np.concatenate(([0], np.cumsum(lengths)))
+            interior = np.ones(tokens.size, dtype=bool)
+            interior[starts[:-1]] = False
+            interior[starts[1:] - 1] = False
+            others = [i for i in range(len(al.alphabet)) if not (4 <= i < 24) and i not in (al.cls_idx, al.eos_idx, al.padding_idx)]
+            spots = rng.choice(np.nonzero(interior)[0], size=8 * len(others), replace=False)
+            tokens[spots] = np.repeat(np.asarray(others, dtype=np.int64), 8)
+        lengths = list(lengths)
+        user = getattr(self, '_half_calib', None)
+        if user is not None:
+            ut, ucu = user
+            tokens = np.concatenate((tokens, ut.numpy()))
+            lengths += [int(b - a) for a, b in zip(ucu[:-1].tolist(), ucu[1:].tolist())]
+        cu = np.concatenate(([0], np.cumsum(lengths))).astype(np.int32)
+        return torch.from_numpy(tokens), torch.from_numpy(cu), int(max(lengths))
+
+    def _guard_scales(self, device):
+        """(2 L, phys_dim) float32: the per-column scaling the STORED pair stream carries at each guard site (HalfGuard.col rows): rho of the FFN
+        LayerNorm after layer i's attention branch, rho of layer i + 1's attention LayerNorm after its FFN branch, 1 after the last layer."""
+        rows, L = [], len(self.layers)          # (stream_scale() is cached per layer on the parameters' versions; this runs at synchronisation points only)
+        for i, layer in enumerate(self.layers):
+            rows.append(layer.stream_scale()[0])
+            rows.append(self.layers[i + 1].self_attn.stream_scale()[0] if i + 1 < L else torch.ones(self.phys_dim, dtype=torch.float32, device=device))
+        return torch.stack([r.to(device) for r in rows])
+
+    def _guard_measure(self, guard, device):
+        """(channel ratio (E,), score bound per layer (L,), covered (L,) bool) from a HalfGuard's device maxima -- device tensors, no sync.
+        ratio[c] = max over the sites of  max_t |x[t, c]| / median_c' max_t |x[t, c']|  (0 where a site saw nothing)."""
+        E = self.embed_dim
+        x = guard.col.view(torch.float32)[:, :E] / self._guard_scales(device)[:, :E]
+        med = x.median(dim=1).values
+        ratio = torch.where(med[:, None] > 0, x / med[:, None].clamp_min(1e-30), torch.zeros_like(x)).amax(dim=0)
+        qk = guard.qk.view(torch.float32)
+        att = self.layers[0].self_attn
+        bound = (qk[:, 0] * qk[:, 1]).sqrt().amax(dim=1) * (att.head_dim ** -0.5)
+        return ratio, bound, qk.amax(dim=(1, 2)) > 0
+
+    def _calibrate_half(self, device):
+        """One forward of the plain 'half' form over the calibration batch (_calibration_batch: the whole vocabulary, + the caller's own data if
+        given), measured by the SAME device maxima the run-time guard keeps (HalfGuard: largest |value| of every stream channel after every
+        branch of every layer relative to the median channel's; squared q / k row norms per head) plus the embedding output and, for blocks
+        whose projection does not carry the q / k guard (ESM-C, head dim 128, no rotary), a torch-side bound of |score| per layer."""
+        from esme.attention import HalfPlan, HalfGuard
+        tokens, cu, max_len = self._calibration_batch()
+        tokens, cu = tokens.to(device), cu.to(device)
+        att = self.layers[0].self_attn
+        L = len(self.layers)
+        guard = HalfGuard(L, self.phys_dim, att.num_heads, device)
+        saved = (self.precision, getattr(self, '_half_guard', None))
         self._half_plan = HalfPlan(info={'calibrating': True})          # the plain form, and no recursion
         probe = []
-        self._calib_probe = probe
+        self._calib_probe, self._half_guard, self.precision = probe, guard, 'half'
         try:
             with torch.no_grad():
-                rep = self._forward_representation(tokens, (cu, max(lengths)), False, None, list(range(len(self.layers))))
+                self._forward_representation(tokens, (cu, max_len), False, None, [L - 1])      # (`layers=`: the module-by-module path, which feeds the probe)
+                x0 = self._embedding_phys(tokens, (cu, max_len))[:, :self.embed_dim].float().abs().amax(dim=0)
+        except BaseException:
+            self._half_plan = None                                      # (ADVICE r5: no half-built plan survives a failed calibration)
+            raise
         finally:
             self._calib_probe = None
-        Ep, L = self.phys_dim, len(self.layers)
-        taps = rep[:, Ep:].reshape(rep.shape[0], L, Ep)[:, :, :self.embed_dim].float()      # raw stream after every layer
-        x0 = self._embedding_phys(tokens, (cu, max(lengths)))[:, :self.embed_dim].float()
-        ratio = torch.zeros(self.embed_dim, device=device)
-        for site in [x0] + [taps[:, i] for i in range(L - 1)]:        # the inputs of the L attention LayerNorms
-            rms = site.pow(2).mean(dim=0).sqrt()
-            ratio = torch.maximum(ratio, rms / rms.median().clamp_min(1e-30))
-        bounds = [float(b) for b in torch.stack(probe).tolist()] if probe else []        # one per layer, in layer order
+            self.precision, self._half_guard = saved
+        ratio, g_bound, covered = self._guard_measure(guard, device)
+        med0 = x0.median()
+        ratio = torch.maximum(ratio, torch.where(med0 > 0, x0 / med0.clamp_min(1e-30), torch.zeros_like(x0)))
+        bounds = [float(b) for b in torch.stack(probe).tolist()] if probe else []        # one per layer, in layer order (torch-side, every layout)
+        if len(bounds) == L:                                                              # the kernels' own figure where they keep one: the larger counts
+            bounds = [max(b, float(g)) if c else b for b, g, c in zip(bounds, g_bound.tolist(), covered.tolist())]
         bound = max(bounds) if bounds else 0.0
         mass = torch.nonzero(ratio > self.HALF_CHANNEL_RATIO).flatten()
-        if mass.numel() > 64:
+        n_mass = int(mass.numel())
+        if n_mass > 64:
             mass = mass[torch.argsort(ratio[mass], descending=True)[:64]]
         sel = torch.sort(mass).values.to(torch.int32).contiguous() if mass.numel() else None
-        att = self.layers[0].self_attn
         pair_ok = (not att.pre_layernorm) and att.head_pad in (16, 32, 64) and att.attn_dim % 128 == 0
         qk_pair = pair_ok and (bound >= self.HALF_SCORE_BOUND or self.half_robust is True)
         if bound >= self.HALF_SCORE_BOUND and not pair_ok:
@@ -234,10 +304,123 @@ class ESM2(nn.Module):
                           "(q/k LayerNorm, head dim 128 or a width that is not a multiple of 128) has no q/k-pair form; use precision 'exact' if 1e-3 must hold")
         # the pair form is paid per layer: only where that layer's own bound asks for it (robust=True: everywhere)
         flags = None if (self.half_robust is True or len(bounds) != L) else [b >= self.HALF_SCORE_BOUND for b in bounds]
-        info = {'calibrated': True, 'max_channel_ratio': float(ratio.max()), 'score_bound': bound, 'massive_channels': int(mass.numel()),
-                'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0,
-                'score_bounds': [round(b, 2) for b in bounds]}
+        others = ratio.clone()
+        if sel is not None:
+            others[sel.long()] = 0
+        info = {'calibrated': True, 'calibration_tokens': int(tokens.numel()), 'vocabulary': self.HALF_CALIB_VOCAB + (' + user batch' if getattr(self, '_half_calib', None) is not None else ''),
+                'max_channel_ratio': float(ratio.max()), 'max_unselected_channel_ratio': float(others.max()), 'score_bound': bound,
+                'massive_channels': n_mass, 'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0,
+                'score_guard_layers': int(covered.sum()), 'score_bounds': [round(b, 2) for b in bounds]}
         return HalfPlan(sel, qk_pair, info, qk_layers=flags)
+
+    # -- the plan checked against the data (round 6) -----------------------------------------------------------------------
+    def _guard_buffers(self, device):
+        """The model's HalfGuard (created with the first 'half' forward on `device`; None when half_guard is off)."""
+        if not self.half_guard or not len(self.layers):
+            return None
+        g = getattr(self, '_half_guard', None)
+        if g is None or g.col.device != torch.device(device) or g.col.shape != (2 * len(self.layers), self.phys_dim):
+            from esme.attention import HalfGuard
+            g = self._half_guard = HalfGuard(len(self.layers), self.phys_dim, self.layers[0].self_attn.num_heads, device)
+        return g
+
+    def _plan_masks(self, plan, dev):
+        """(selected-channel mask (E,) bool, per-layer pair flags (L,) bool) of `plan` on the device, built once per plan."""
+        c = self.__dict__.get('_plan_masks_cache')
+        if c is None or c[0] is not plan or c[1].device != torch.device(dev):
+            sel_mask = torch.zeros(self.embed_dim, dtype=torch.bool, device=dev)
+            if plan.ext_sel is not None:
+                sel_mask[plan.ext_sel.long()] = True
+            flags = torch.tensor([plan.pairs_at(i) for i in range(len(self.layers))], dtype=torch.bool, device=dev)
+            c = self.__dict__['_plan_masks_cache'] = (plan, sel_mask, flags)
+        return c[1], c[2]
+
+    def _guard_snapshot(self):
+        """Device-side half of check_plan (no synchronisation): float32 vector [stale, ratio (E), score bound (L), covered (L)] of everything the
+        guard saw since it was last cleared, judged against the CURRENT plan; the maxima are cleared.  None when there is nothing to check.
+        esme.pipeline.StreamedInference downloads it with each result."""
+        g = getattr(self, '_half_guard', None)
+        if g is None or self.precision != 'half' or torch.cuda.is_current_stream_capturing():
+            return None
+        plan = self.half_plan()
+        if not plan.info.get('calibrated', False):
+            g.clear()
+            return None                                           # (robust=False: the caller asked for the plain form; nothing to hold it to)
+        dev = g.col.device
+        ratio, bound, covered = self._guard_measure(g, dev)
+        sel_mask, flags = self._plan_masks(plan, dev)
+        bad_c = (ratio > self.HALF_CHANNEL_RATIO) & ~sel_mask
+        bad_l = (bound >= self.HALF_SCORE_BOUND) & ~flags & covered
+        stale = (bad_c.any() | bad_l.any()).to(torch.float32).reshape(1)
+        g.clear()
+        return torch.cat((stale, ratio, bound, covered.to(torch.float32)))
+
+    def _plan_verdict(self, vec, update: bool = True, where: str = ''):
+        """Host-side half of check_plan: `vec` = a _guard_snapshot() on the host.  None when the plan held; else the verdict dict (and, with
+        `update`, the widened plan installed)."""
+        if vec is None or float(vec[0]) == 0.0:
+            return None
+        E, L = self.embed_dim, len(self.layers)
+        ratio, bound, covered = vec[1:1 + E], vec[1 + E:1 + E + L], vec[1 + E + L:1 + E + 2 * L] > 0
+        plan = self.half_plan()
+        sel_mask = torch.zeros(E, dtype=torch.bool)
+        if plan.ext_key:
+            sel_mask[list(plan.ext_key)] = True
+        flags = torch.tensor([plan.pairs_at(i) for i in range(L)], dtype=torch.bool)
+        bad_c = (ratio > self.HALF_CHANNEL_RATIO) & ~sel_mask
+        bad_l = (bound >= self.HALF_SCORE_BOUND) & ~flags & covered
+        if not bool(bad_c.any() | bad_l.any()):
+            return None                                           # (judged against a plan that has been widened since the snapshot was taken)
+        chans = [(int(c), round(float(ratio[c]), 2)) for c in torch.nonzero(bad_c).flatten().tolist()]
+        layers = [(int(i), round(float(bound[i]), 1)) for i in torch.nonzero(bad_l).flatten().tolist()]
+        att = self.layers[0].self_attn
+        pair_ok = (not att.pre_layernorm) and att.head_pad in (16, 32, 64) and att.attn_dim % 128 == 0
+        verdict = {'channels': chans, 'layers': layers, 'updated': False}
+        msg = (f"precision='half': the plan is stale for this data{where} -- {len(chans)} stream channel(s) outside the extension tile reach "
+               f"{max([r for _, r in chans], default=0):.1f}x the median channel (threshold {self.HALF_CHANNEL_RATIO}), "
+               f"{len(layers)} layer(s) without q/k pairs reach a score bound of {max([b for _, b in layers], default=0):.0f} (threshold {self.HALF_SCORE_BOUND}); "
+               "results computed since the last check may miss the mode's 1e-3.")
+        if update:
+            from esme.attention import HalfPlan
+            dev = self.embed_tokens.weight.device
+            merged = torch.where(sel_mask, torch.full_like(ratio, float('inf')), ratio)        # the current selection stays; offenders join, largest first
+            cand = torch.nonzero(sel_mask | bad_c).flatten()
+            full = cand.numel() > 64
+            if full:
+                cand = cand[torch.argsort(merged[cand], descending=True)[:64]]
+            sel = torch.sort(cand).values.to(torch.int32).contiguous().to(dev) if cand.numel() else None
+            new_flags = [bool(f) or (pair_ok and bool(b)) for f, b in zip(flags.tolist(), bad_l.tolist())]
+            info = dict(plan.info)
+            info['updates'] = info.get('updates', 0) + 1
+            info['massive_channels'] = int(cand.numel())
+            info['qk_pair_layers'] = sum(new_flags) if pair_ok else 0
+            self._half_plan = HalfPlan(sel, pair_ok and any(new_flags), info, qk_layers=new_flags if pair_ok else None)
+            self.invalidate_graphs()
+            verdict['updated'] = True
+            msg += " The plan was widened (" + self._half_plan.describe() + "): re-run the batch."
+            if full or (layers and not pair_ok):
+                msg += (" It cannot cover everything (more than 64 massive channels, or large scores in a block without a q/k-pair form): "
+                        "use precision 'exact' if 1e-3 must hold.")
+                verdict['uncovered'] = True
+        verdict['message'] = msg
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        return verdict
+
+    def check_plan(self, update: bool = True):
+        """Compare what the forwards in precision 'half' since the last call actually saw with what the plan assumed: a stream channel outside the
+        extension tile whose largest |value| exceeds HALF_CHANNEL_RATIO x the median channel's, or a layer without q / k pairs whose score bound
+        reaches HALF_SCORE_BOUND, means the 1e-3 of the mode no longer rests on a measurement ("plan stale").  Synchronises with the device; the
+        maxima are cleared.  Returns None when the plan held, else a dict {'channels': [(id, ratio), ...], 'layers': [(layer, bound), ...],
+        'updated': bool, 'message': str}.  `update=True` widens the plan in place (the offending channels join the extension tile, up to 64; the
+        offending layers get q / k pairs where the block has that form), so that the NEXT forward is covered -- re-run the batch that tripped it
+        (predict_log_prob / predict_prob do that themselves).  A RuntimeWarning accompanies every stale verdict.  Coverage: the channel check runs
+        in every residual epilogue of every model; the score check in the LayerNorm-folded projections with fused rotary (ESM-2 family, head
+        dims 16 / 32 / 64) -- ESM-C (q / k LayerNorm), ESM-1b / 1v (no rotary) and head dim 128 rely on the calibration for it."""
+        vec = self._guard_snapshot()
+        if vec is None:
+            return None
+        return self._plan_verdict(vec.cpu(), update)              # the one synchronisation
 
     def _apply(self, fn, *a, **kw):
         """`.to()`, `.cuda()`, dtype casts: the parameters' storage moves -- drop everything derived from it."""
@@ -270,6 +453,7 @@ class ESM2(nn.Module):
         ctx.probe = getattr(self, '_calib_probe', None)
         if self.precision == 'half':
             ctx.ovf = self._overflow_flag(device)
+            ctx.guard = getattr(self, '_half_guard', None) if getattr(self, '_calib_probe', None) is not None else self._guard_buffers(device)
         return ctx
 
     # -- run-time range guard of precision 'half' --------------------------------------------------------------------
@@ -291,8 +475,9 @@ class ESM2(nn.Module):
             return self
         if int(f.item()) != 0:
             f.zero_()
-            raise OverflowError("precision='half': an activation left IEEE fp16's range (|x| >= 65 504) during a forward; the result holds "
-                                "inf / NaN.  Use precision 'exact' (bf16 pairs, fp32's range) for this checkpoint / input.")
+            raise OverflowError("precision='half': an activation left IEEE fp16's range (|x| >= 65 504) during a forward since the last check (this call's, "
+                                "or an earlier unchecked model(...) call's: the flag is sticky); the result holds inf / NaN.  Use precision 'exact' "
+                                "(bf16 pairs, fp32's range) for this checkpoint / input.")
         return self
 
     def _unpad(self, x, tokens):
@@ -395,7 +580,7 @@ class ESM2(nn.Module):
                 alloc = torch.zeros if self.padded else torch.empty
                 pair = alloc(T, 2 * Ep, dtype=torch.bfloat16, device=x.device)
                 x = alloc(T, Ep, dtype=torch.float32, device=x.device)
-                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan, ctx.ovf, ctx.cos32, ctx.sin32)
+                cforward.forward_layers_half(self, x32, cu_lens, max_len, ctx.pos, ctx.cos, ctx.sin, pair, x, ctx.plan, ctx.ovf, ctx.cos32, ctx.sin32, ctx.guard)
                 if want_pair:
                     x = pair
                 return self._finish_representation(x, [], pad_output, pad_args, pad_indices, cu_lens, pad_width)
@@ -467,20 +652,29 @@ class ESM2(nn.Module):
                 return y.view(*pair.shape[:-1], y.shape[-1])
             return self.lm_head(self._forward_representation(tokens, pad_args, pad_output, pad_indices, []))
 
+    def _checked(self, run):
+        """Run `run()` (a forward ending in a softmax) and, in precision 'half' with half_check = 'sync', look at the range flag and the plan
+        guard (one synchronisation; the result is about to be read anyway).  A stale plan is widened and the batch re-run ONCE with it, so
+        the value returned rests on a plan that covers this very batch; an overflow raises.  (esme.pipeline reads both with each result
+        instead: `_defer_overflow`.)"""
+        y = run()
+        if self.precision != 'half' or self.half_check != 'sync' or getattr(self, '_defer_overflow', False) or torch.cuda.is_current_stream_capturing():
+            return y
+        self.check_overflow()
+        if self.check_plan(update=True) is not None:
+            y = run()
+            self.check_overflow()
+            self.check_plan(update=False)                     # (whatever is left cannot be covered: warned about, not looped on)
+        return y
+
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            y = _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True)
-            if self.precision == 'half' and not getattr(self, '_defer_overflow', False):      # (esme.pipeline reads the flag with each result instead)
-                self.check_overflow()
-            return y
+            return self._checked(lambda: _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True))
 
     def predict_prob(self, tokens, log=False, pad_args=None, pad_output=False, pad_indices=None,
                      lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            y = _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log))
-            if self.precision == 'half' and not getattr(self, '_defer_overflow', False):      # (esme.pipeline reads the flag with each result instead)
-                self.check_overflow()
-            return y
+            return self._checked(lambda: _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log)))
 
     def graphed(self, tokens, pad_args, what: str = 'forward', clone: bool = True):
         """`getattr(self, what)(tokens, pad_args)` replayed from a hipGraph captured on first use of this
@@ -492,8 +686,10 @@ class ESM2(nn.Module):
             from esme.graph import GraphCache
             self._graph_cache = GraphCache(self)
         y = self._graph_cache.run(what, tokens, pad_args, clone)
-        if what == 'predict_log_prob' and self.precision == 'half' and not getattr(self, '_defer_overflow', False):
-            self.check_overflow()           # (skipped while capturing; a replay sets the same sticky flag the eager call checks)
+        if what == 'predict_log_prob' and self.precision == 'half' and self.half_check == 'sync' and not getattr(self, '_defer_overflow', False):
+            self.check_overflow()           # (skipped while capturing; a replay sets the same sticky flags the eager call checks)
+            if self.check_plan(update=True) is not None:          # (the widened plan dropped the captured graphs: this call captures anew)
+                y = self._graph_cache.run(what, tokens, pad_args, clone)
         return y
 
     def invalidate_graphs(self):

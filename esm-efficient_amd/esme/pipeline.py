@@ -75,8 +75,12 @@ class StreamedInference:
         # it inline.  Here the sticky device flag travels to the host WITH each result (4 bytes on the output stream, pinned) and is looked at
         # when the result is handed out: no extra synchronisation, and an activation that left fp16's range surfaces as OverflowError at the
         # first result that may carry it.
+        # The plan guard travels the same way (round 6): ESM2._guard_snapshot() judges the batch's device maxima against the plan ON the device, the
+        # few KB of the verdict vector ride to the host with the result, and a stale plan is widened when the first result computed under it is
+        # handed out (RuntimeWarning naming the batch; later batches run covered; results already in flight are named too).
         guard = getattr(self.model, 'precision', None) == 'half'
         ring_flag = _PinnedRing(2 * self.depth + 2) if guard else None
+        self._ring_plan = _PinnedRing(2 * self.depth + 2) if guard else None
         deferred_before = getattr(self.model, '_defer_overflow', False)
         if guard:
             self.model._defer_overflow = True
@@ -87,8 +91,13 @@ class StreamedInference:
                 self.model._defer_overflow = deferred_before
 
     def _hand_out(self, item, index):
-        h, ev, flag_h = item
+        h, ev, flag_h, plan_h = item
         ev.synchronize()
+        if plan_h is not None and float(plan_h[0]) != 0.0:
+            if self.model._plan_verdict(plan_h.clone(), update=True, where=f' (batch {index} of this stream)') is None:
+                import warnings                  # (an earlier batch's verdict has widened the plan meanwhile; THIS result still predates that)
+                warnings.warn(f"precision='half': batch {index} of this stream was computed under the plan an earlier batch showed to be stale (it has been "
+                              "widened since); re-run it if the mode's 1e-3 must hold for it", RuntimeWarning, stacklevel=2)
         if flag_h is not None and int(flag_h[0]) != 0:
             self.model._overflow_flag(self.device).zero_()
             raise OverflowError(f"precision='half': an activation left IEEE fp16's range (|x| >= 65 504) by batch {index} of this stream; its result "
@@ -114,19 +123,24 @@ class StreamedInference:
                 out = self.fn(tok_d, (cu_d, int(max_len)))
                 if self.pool == 'mean':
                     out = partition_mean_pool(out, cu_d)
+                host = ring_out.take(out.shape, out.dtype)
+                snap = self.model._guard_snapshot() if ring_flag is not None else None      # (compute stream, before `computed`: judged against the plan this batch ran with)
                 computed = torch.cuda.Event()
                 computed.record(compute)
-                host = ring_out.take(out.shape, out.dtype)
                 flag_h = ring_flag.take((1,), torch.int32) if ring_flag is not None else None
+                plan_h = self._ring_plan.take(snap.shape, torch.float32) if snap is not None else None
                 with torch.cuda.stream(out_s):
                     out_s.wait_event(computed)
                     host.copy_(out, non_blocking=True)
                     out.record_stream(out_s)
                     if flag_h is not None:
                         flag_h.copy_(self.model._overflow_flag(dev), non_blocking=True)
+                    if plan_h is not None:
+                        plan_h.copy_(snap, non_blocking=True)
+                        snap.record_stream(out_s)
                     downloaded = torch.cuda.Event()
                     downloaded.record(out_s)
-                pending.append((host, downloaded, flag_h))
+                pending.append((host, downloaded, flag_h, plan_h))
                 while len(pending) > self.depth:
                     yield self._hand_out(pending.popleft(), handed)
                     handed += 1

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 8
+#define ESME_HIP_ABI_VERSION 9
 
 enum {
     ESME_OK = 0,
@@ -389,6 +389,18 @@ typedef struct esme_gemm_fusion {
      * (the Python package: model.check_overflow(), predict_log_prob / predict_prob).  The reference's bf16 forward has no such hazard
      * (bf16 has fp32's range: esme/esm.py:268-298). */
     int* overflow_flag;
+    /* Plan guard of precision 'half' (ABI 9; DESIGN.md section 4, "the plan checked against the data").  The mode's calibration decides, per model, which
+     * stream channels are "massive" (ext_sel) and which layers need q / k as pairs; these two optional device buffers let the caller check those
+     * decisions against EVERY batch it runs, from values the epilogues hold in registers anyway (running maxima, atomic, never cleared by the
+     * library; read at the caller's next natural synchronisation like overflow_flag).  The reference has no counterpart (one dtype per forward:
+     * esme/esm.py:132-141).
+     *   col_absmax (uint32 (N), fp16 pair stream + ESME_EPI_RESIDUAL only): per output column n, the float bit pattern of max_m |hi[m, n]| of
+     *       the STORED stream (= rho_out[n] * x: divide by pair_scale_out to compare channels).  Non-negative floats order like their bit
+     *       patterns; inf / NaN stick on top.
+     *   qk_sumsq (uint32 (2, H), f16 + LN fold + fused rotary without pair output only; H = rot_cols / 2 / head_dim): [0][h] = float bits of
+     *       max_m sum_c q[m, h, c]^2 after rotation, [1][h] the same for k: sqrt(q2 k2) * softmax_scale bounds |score| of head h. */
+    uint32_t* col_absmax;
+    uint32_t* qk_sumsq;
 } esme_gemm_fusion_t;
 
 /* number of column-tile blocks a residual-epilogue GEMM of this shape writes to stats_out */
@@ -546,6 +558,11 @@ typedef struct esme_model_desc {
     int half_ext_n; const int32_t* half_ext_sel; int half_qk_pair;
     int* half_overflow_flag;     /* esme_hip_forward_half: the run-time range guard (esme_gemm_fusion_t.overflow_flag), int32 on the device or NULL */
     const float* cos32; const float* sin32;      /* esme_hip_forward_half with half_qk_pair: fp32 rotary tables of the flagged layers */
+    /* esme_hip_forward_half: the plan guard (esme_gemm_fusion_t.col_absmax / .qk_sumsq; ABI 9), device buffers or NULL:
+     *   half_col_absmax  uint32 (2 * n_layers, phys_dim): row 2 i = the stream after layer i's attention branch (scaled for its FFN LayerNorm:
+     *       ps_ffn), row 2 i + 1 = after its FFN branch (scaled for layer i + 1's attention LayerNorm; the last row unscaled);
+     *   half_qk_sumsq    uint32 (n_layers, 2, heads): layers whose q / k are NOT pairs and whose rotary is fused into the projection. */
+    uint32_t* half_col_absmax; uint32_t* half_qk_sumsq;
 } esme_model_desc_t;
 
 int64_t esme_hip_forward_workspace_bytes(const esme_model_desc_t* model, int64_t T);

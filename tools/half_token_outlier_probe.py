@@ -4,8 +4,9 @@ TOKEN -- they exist only in the embedding rows of `X` / `<unk>` (ESM-2; `<mask>`
 not zero them and which predict_mask_margin feeds on every row).  A calibration batch of residues 4..23 + cls / eos sees a benign model.
 
 Prints, per model: rel-Frobenius of the logits (ESM-C: of the masked rows' log-probs, through esme.variant.masked_row_log_prob) vs the fp32
-oracle for fast / half / exact, the plan the mode chose and the verdict of the run-time plan guard.  `ESME_CALIB_LEGACY=1` restores the
-round-5 calibration batch (ids 4..23 + cls / eos, 1 024 residues) so that the silent miss it allowed stays reproducible.
+oracle for fast / half / exact, the plan the mode chose and the verdict of the run-time plan guard.  `CALIB=residues` calibrates on the
+round-5 token set (ids 4..23 + cls / eos), which misses these models by construction: what then catches them is the guard (the run at
+commit a1b708a, before the guard existed, is kept as profiles/r06_half_token_outlier_before.txt: the silent miss).
 A measurement tool of the test infrastructure: it uses oracle/ as the checker, like tests/; nothing in the product imports it."""
 import os, sys, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,17 +36,14 @@ def sprinkle(tokens, cu, ids, frac, seed):
     return t
 
 
-def guard_verdict(model):
-    fn = getattr(model, 'check_plan', None)
-    if fn is None:
-        return 'no guard in this build'
-    try:
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter('always')
-            v = fn(update=False)
-        return v if v is not None else 'ok'
-    except Exception as e:           # noqa
-        return f'{type(e).__name__}: {e}'[:200]
+CALIB = os.environ.get('CALIB', 'all')
+
+
+def short(v):
+    if v is None:
+        return 'plan holds'
+    return (f"STALE: {len(v['channels'])} channel(s) up to {max([r for _, r in v['channels']], default=0):.0f}x, "
+            f"{len(v['layers'])} layer(s) up to score bound {max([b for _, b in v['layers']], default=0):.0f}" + (' -> widened' if v.get('updated') else ''))
 
 
 def esm2_case(L, E, H, scale, frac):
@@ -56,6 +54,7 @@ def esm2_case(L, E, H, scale, frac):
     model = build('esm2', L, E, H, seed=2)
     model.load_state_dict({k: v.clone() for k, v in w.items()}, strict=False)
     model.to(DEV)
+    model.HALF_CALIB_VOCAB = CALIB
     ref = O.forward_logits(w, H, tokens, cu, max(lengths), torch.float32).float()
     args = (tokens.to(DEV), (cu.to(DEV), max(lengths)))
     out = {}
@@ -65,11 +64,12 @@ def esm2_case(L, E, H, scale, frac):
             y = model.set_precision(mode)(*args).float().cpu()
             out[mode] = rel(y, ref)
             if mode == 'half':
-                plan, verdict, first = model.half_plan(), guard_verdict(model), out[mode]
-                upd = getattr(model, 'check_plan', None)
-                if upd is not None:
-                    upd(update=True)
-                    out['half (after plan update)'] = rel(model(*args).float().cpu(), ref)
+                plan = model.half_plan()
+                v = model.check_plan(update=True)
+                verdict = short(v)
+                if v is not None:
+                    out['half, re-run with the widened plan'] = rel(model(*args).float().cpu(), ref)
+                    verdict += f' ({model.half_plan().describe()}); second check: {short(model.check_plan(update=False))}'
     print(f'ESM-2 {L} x {E}, massive channels only in the rows of X / <unk> (x{scale:.0f}), {frac:.0%} of residues: '
           + '  '.join(f'{k} {v:.2e}' for k, v in out.items())
           + f'   | plan: {plan.describe()}, score bound {plan.info.get("score_bound", 0):.0f}, max channel ratio {plan.info.get("max_channel_ratio", 0):.1f}'
@@ -85,6 +85,8 @@ def esmc_case(L, E, H, scale):
     model = build('esmc', L, E, H, seed=2)
     model.load_state_dict({k: v.clone() for k, v in w.items()}, strict=False)
     model.to(DEV)
+    model.HALF_CALIB_VOCAB = CALIB
+    model.half_check = 'defer'                       # (this tool reads the guard itself, to print what it saw)
     batch = MaskMarginDataset(seq, alphabet=Alphabet3).batch(0, 32)
     tok = torch.as_tensor(batch['token'])
     B, S = tok.shape
@@ -98,11 +100,12 @@ def esmc_case(L, E, H, scale):
             with torch.no_grad():
                 out[mode] = rel(masked_row_log_prob(model.set_precision(mode), tok, torch.as_tensor(batch['local_pos'])).float().cpu(), ref)
                 if mode == 'half':
-                    plan, verdict = model.half_plan(), guard_verdict(model)
-                    upd = getattr(model, 'check_plan', None)
-                    if upd is not None:
-                        upd(update=True)
-                        out['half (after plan update)'] = rel(masked_row_log_prob(model, tok, torch.as_tensor(batch['local_pos'])).float().cpu(), ref)
+                    plan = model.half_plan()
+                    v = model.check_plan(update=True)
+                    verdict = short(v)
+                    if v is not None:
+                        out['half, re-run with the widened plan'] = rel(masked_row_log_prob(model, tok, torch.as_tensor(batch['local_pos'])).float().cpu(), ref)
+                        verdict += f' ({model.half_plan().describe()}); second check: {short(model.check_plan(update=False))}'
     print(f'ESM-C {L} x {E}, massive channels only in the <mask> row (x{scale:.0f}), masked-row log-probs of 32 masked copies (predict_mask_margin): '
           + '  '.join(f'{k} {v:.2e}' for k, v in out.items())
           + f'   | plan: {plan.describe()}, max channel ratio {plan.info.get("max_channel_ratio", 0):.1f} | guard: {verdict}', flush=True)
@@ -110,7 +113,7 @@ def esmc_case(L, E, H, scale):
 
 if __name__ == '__main__':
     L, E = int(os.environ.get('L', 12)), int(os.environ.get('E', 640))
-    print(f"calibration batch: {'round-5 (ids 4..23 + cls / eos)' if os.environ.get('ESME_CALIB_LEGACY') == '1' else 'whole vocabulary'}", flush=True)
+    print(f"calibration batch: {'round-5 token set (ids 4..23 + cls / eos)' if CALIB == 'residues' else 'whole vocabulary'}", flush=True)
     for scale in (10.0, 50.0):
         for frac in (0.03, 0.2):
             esm2_case(L, E, 20, scale, frac)
