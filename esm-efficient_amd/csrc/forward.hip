@@ -192,8 +192,8 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         aopts.seq_order = w.order;
     }
     // the stream as an fp16 pair [hi | lo] (scaled per column for the first LayerNorm-folded GEMM) + the statistics of the fp32 rows
-    ESME_TRY(esme_hip_stream_operand_scaled(x32, ld32, w.xs, ldxs, lo_off, 1, m->layers[0].ps_attn, ext ? m->half_ext_sel : nullptr, m->half_ext_n,
-                                            ext ? Ep : 0, w.sums, T, Ep, stream));
+    ESME_TRY(esme_hip_stream_operand_guarded(x32, ld32, w.xs, ldxs, lo_off, 1, m->layers[0].ps_attn, ext ? m->half_ext_sel : nullptr, m->half_ext_n,
+                                             ext ? Ep : 0, w.sums, m->half_col_absmax, T, Ep, stream));
     const float* stats = w.sums;
     int stats_nblk = 1;
     for (int i = 0; i < m->n_layers; ++i) {
@@ -222,7 +222,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         esme_gemm_fusion_t fo{};
         stream_fields(fo); fo.stats_out = w.part_b;
         fo.pair_scale_in = L.ps_attn_inv; fo.pair_scale_out = L.ps_ffn;               // the stream arrives scaled for this layer's attention LayerNorm, leaves scaled for its FFN LayerNorm
-        if (m->half_col_absmax) fo.col_absmax = m->half_col_absmax + (int64_t)(2 * i) * Ep;                                          // plan guard: column maxima of the stream
+        if (m->half_col_absmax) fo.col_absmax = m->half_col_absmax + (int64_t)(2 * i + 1) * Ep;                                          // plan guard: column maxima of the stream
         ESME_TRY(esme_hip_gemm_bf16_fused(w.attn, Ea, L.out_w, L.out_b, w.xs, ldxs, w.xs, ldxs, T, Ep, (int)Ea, ESME_EPI_RESIDUAL, m->alpha, &fo, stream));
         esme_gemm_fusion_t fup{};
         fup.f16 = 1; fup.overflow_flag = m->half_overflow_flag;
@@ -233,7 +233,7 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         esme_gemm_fusion_t fd{};
         stream_fields(fd); fd.stats_out = w.part_a;
         fd.pair_scale_in = L.ps_ffn_inv; fd.pair_scale_out = i + 1 < m->n_layers ? m->layers[i + 1].ps_attn : nullptr;    // (the final LayerNorm reads the stream unscaled)
-        if (m->half_col_absmax) fd.col_absmax = m->half_col_absmax + (int64_t)(2 * i + 1) * Ep;
+        if (m->half_col_absmax) fd.col_absmax = m->half_col_absmax + (int64_t)(2 * i + 2) * Ep;
         ESME_TRY(esme_hip_gemm_bf16_fused(w.mid, m->ffn_dim, L.down_w, L.down_b, w.xs, ldxs, w.xs, ldxs, T, Ep, m->ffn_dim,
                                           ESME_EPI_RESIDUAL, m->alpha, &fd, stream));
         stats = w.part_a; stats_nblk = nblk;

@@ -444,7 +444,7 @@ template <int NCH, bool F16>
 __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __restrict__ x32, int64_t ld32, u16* __restrict__ x16,
                                                              int64_t ld16, int64_t lo_off, const float* __restrict__ scale,
                                                              const int32_t* __restrict__ ext_sel, int ext_n, int64_t ext_off,
-                                                             f32x2* __restrict__ sums, int64_t T, int E) {
+                                                             f32x2* __restrict__ sums, unsigned int* __restrict__ col_absmax, int64_t T, int E) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -464,6 +464,17 @@ __global__ __launch_bounds__(256) void stream_operand_kernel(const float* __rest
                     const f32x4 c0 = *reinterpret_cast<const f32x4*>(scale + e0), c1 = *reinterpret_cast<const f32x4*>(scale + e0 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = __fmul_rn(v[j], c0[j]); v[4 + j] = __fmul_rn(v[4 + j], c1[j]); }
+                }
+                if (col_absmax) {
+                    // plan guard of precision 'half' (esme_hip_stream_operand_guarded): running max |stored value| per column.  The current maxima are READ first
+                    // (plain loads, possibly stale -- they only decide whether an atomic is worth issuing): a running maximum is raised O(log T) times per
+                    // column, so after the first few rows almost no lane issues one.
+                    const u32x4 m0 = *reinterpret_cast<const u32x4*>(col_absmax + e0), m1 = *reinterpret_cast<const u32x4*>(col_absmax + e0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned int b = __float_as_uint(fabsf(v[j]));
+                        if (b > (j < 4 ? m0[j] : m1[j - 4])) atomicMax(col_absmax + e0 + j, b);
+                    }
                 }
             }
             const u32x4 pk = pack8t<F16>(v);
@@ -864,9 +875,11 @@ extern "C" int esme_hip_residual_f32(float* x32, int64_t ld32, const void* o, in
     return check_launch("residual_f32");
 }
 
-extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, const float* scale,
-                                              const int32_t* ext_sel, int ext_n, int64_t ext_off, float* sums, int64_t T, int E, void* stream) {
+extern "C" int esme_hip_stream_operand_guarded(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, const float* scale,
+                                               const int32_t* ext_sel, int ext_n, int64_t ext_off, float* sums, uint32_t* col_absmax, int64_t T, int E,
+                                               void* stream) {
     ESME_CHECK_ARG(T >= 0 && E > 0, "stream_operand: bad sizes");
+    ESME_CHECK_ARG(!col_absmax || (lo_off != 0 && aligned16(col_absmax)), "stream_operand: col_absmax belongs to the pair form and must be 16-byte aligned");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(x32 && x16, "stream_operand: null pointer");
     ESME_CHECK_ARG(E % 8 == 0 && ld32 % 4 == 0 && ld16 % 8 == 0 && ld32 >= E && ld16 >= E, "stream_operand: E / row strides not multiples of 8");
@@ -877,8 +890,8 @@ extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, vo
                    "stream_operand: the extension tile is 64 columns between hi and lo (E <= ext_off, ext_off + 64 <= lo_off) with <= 64 selected channels");
     const dim3 grid((unsigned int)((T + 3) / 4)), block(256);
     const hipStream_t s = (hipStream_t)stream;
-#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, ext_sel, ext_n, ext_off, (f32x2*)sums, T, E); \
-                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, ext_sel, ext_n, ext_off, (f32x2*)sums, T, E); } while (0)
+#define ESME_SO(N) do { if (f16) hipLaunchKernelGGL((stream_operand_kernel<N, true>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, ext_sel, ext_n, ext_off, (f32x2*)sums, col_absmax, T, E); \
+                        else hipLaunchKernelGGL((stream_operand_kernel<N, false>), grid, block, 0, s, x32, ld32, (u16*)x16, ld16, lo_off, scale, ext_sel, ext_n, ext_off, (f32x2*)sums, col_absmax, T, E); } while (0)
     if (E <= 512) ESME_SO(1);
     else if (E <= 1024) ESME_SO(2);
     else if (E <= 1536) ESME_SO(3);
@@ -887,6 +900,11 @@ extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, vo
     else ESME_FAIL(ESME_ERR_UNSUPPORTED, "stream_operand: E > 5120 unsupported");
 #undef ESME_SO
     return check_launch("stream_operand");
+}
+
+extern "C" int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, const float* scale,
+                                              const int32_t* ext_sel, int ext_n, int64_t ext_off, float* sums, int64_t T, int E, void* stream) {
+    return esme_hip_stream_operand_guarded(x32, ld32, x16, ld16, lo_off, f16, scale, ext_sel, ext_n, ext_off, sums, nullptr, T, E, stream);
 }
 
 extern "C" int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16, float* sums,

@@ -93,6 +93,8 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_pair_to_f32': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    'esme_hip_stream_operand_guarded': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_int,
+                                                c_void_p]),
     'esme_hip_stream_operand_scaled': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int,
                                                c_void_p]),
     'esme_hip_forward_exact_workspace_bytes': (c_int64, [c_void_p, c_int64]),
@@ -535,15 +537,18 @@ def residual_f32_(x32: torch.Tensor, o: torch.Tensor, alpha: float, x16: torch.T
 
 
 def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Tensor], pair: bool = False,
-                   scale: Optional[torch.Tensor] = None, ext_sel: Optional[torch.Tensor] = None) -> None:
+                   scale: Optional[torch.Tensor] = None, ext_sel: Optional[torch.Tensor] = None, col_absmax: Optional[torch.Tensor] = None) -> None:
     """x16 <- round(x32) in x16's dtype (bfloat16, or float16 for precision 'half'); sums (1, T, 2) <- row {sum, sum sq} of the ROUNDED
     values: the operand and the statistics the LayerNorm-folded GEMMs read at the start of a forward on an fp32 stream.  `pair`: x16 is
     (T, W >= 2E) = [hi | ... | lo] (lo in the last E columns) with lo = round(v - hi), v = scale * x32 (`scale`: float32 (E) or None = 1):
     the stream itself as a 16-bit pair (gemm_fused(resid_pair=, pair_scale=)); `sums` then describes the fp32 values x32 themselves.
     `ext_sel` (int32, <= 64 ascending column indices; the pair must be (T, 2E + 64) = [hi | ext | lo]): the extension K-tile receives lo of
-    those columns, zeros behind them (esme_gemm_fusion_t.ext_sel)."""
+    those columns, zeros behind them (esme_gemm_fusion_t.ext_sel).  `col_absmax` (int32 (E), pair form): the plan guard's running max |scale * x32| per
+    column as float bit patterns (esme_hip_stream_operand_guarded)."""
     if x16.dtype not in (torch.bfloat16, torch.float16):
         raise TypeError('stream_operand: x16 must be bfloat16 or float16')
+    if col_absmax is not None and (not pair or col_absmax.numel() != x32.shape[1] or not col_absmax.is_contiguous()):
+        raise ValueError('stream_operand: `col_absmax` is a contiguous int32 (E) buffer of the pair form')
     xp, ld32 = _rows2d(x32, 'stream_operand x32', torch.float32)
     yp, ld16 = _rows2d(x16, 'stream_operand x16', x16.dtype)
     T, E = x32.shape
@@ -554,12 +559,13 @@ def stream_operand(x32: torch.Tensor, x16: torch.Tensor, sums: Optional[torch.Te
     if ext_sel is not None and (not pair or x16.shape[1] != 2 * E + 64 or ext_sel.numel() > 64):
         raise ValueError('stream_operand: `ext_sel` needs the (T, 2E + 64) pair layout and at most 64 columns')
     with _Traced('stream_operand', (T, E)):
-        _check(load().esme_hip_stream_operand_scaled(xp, ld32, yp, ld16, x16.shape[1] - E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
-                                                     _dev(scale, 'stream scale', torch.float32) if scale is not None else None,
-                                                     _dev(ext_sel, 'ext_sel', torch.int32) if ext_sel is not None else None,
-                                                     ext_sel.numel() if ext_sel is not None else 0, E if ext_sel is not None else 0,
-                                                     _dev(sums, 'sums', torch.float32) if sums is not None else None, T, E, _stream()),
-               'esme_hip_stream_operand_scaled')
+        _check(load().esme_hip_stream_operand_guarded(xp, ld32, yp, ld16, x16.shape[1] - E if pair else 0, 1 if x16.dtype == torch.float16 else 0,
+                                                      _dev(scale, 'stream scale', torch.float32) if scale is not None else None,
+                                                      _dev(ext_sel, 'ext_sel', torch.int32) if ext_sel is not None else None,
+                                                      ext_sel.numel() if ext_sel is not None else 0, E if ext_sel is not None else 0,
+                                                      _dev(sums, 'sums', torch.float32) if sums is not None else None,
+                                                      _dev(col_absmax, 'col_absmax', torch.int32) if col_absmax is not None else None, T, E, _stream()),
+               'esme_hip_stream_operand_guarded')
 
 
 def pair_to_f32(xs: torch.Tensor, width: Optional[int] = None) -> torch.Tensor:

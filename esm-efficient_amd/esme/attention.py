@@ -178,14 +178,15 @@ class HalfGuard:
     """Device side of the plan guard of precision 'half' (esme_gemm_fusion_t.col_absmax / .qk_sumsq): running maxima the kernels keep next to
     results they hold in registers anyway, as float bit patterns in int32 tensors.
 
-      col   (2 L, phys_dim): row 2 i = max |hi| per stream column after layer i's attention branch, row 2 i + 1 after its FFN branch -- of the
-            STORED stream, i.e. times the column scaling of the LayerNorm that reads it next (ESM2._guard_scales undoes it);
+      col   (2 L + 1, phys_dim): row 0 = max |value| per stream column at the start (the embedding output, where a token-triggered massive channel
+            is most visible), row 1 + 2 i after layer i's attention branch, row 2 + 2 i after its FFN branch -- of the STORED stream, i.e. times
+            the column scaling of the LayerNorm that reads it next (ESM2._guard_scales undoes it);
       qk    (L, 2, heads): max over rows of the squared row norm of q (then k) per head, for layers whose q / k are single fp16 values and whose
             rotary is fused into the projection (ESM-2 / ESM-1 blocks; zeros elsewhere: not covered).
     Sticky across forwards until `clear()`; ESM2.check_plan reads them at a synchronisation point."""
 
     def __init__(self, n_layers: int, phys_dim: int, heads: int, device):
-        self.col = torch.zeros(2 * n_layers, phys_dim, dtype=torch.int32, device=device)
+        self.col = torch.zeros(2 * n_layers + 1, phys_dim, dtype=torch.int32, device=device)
         self.qk = torch.zeros(n_layers, 2, heads, dtype=torch.int32, device=device)
 
     def clear(self):
@@ -446,7 +447,7 @@ class FlashMultiheadAttention(nn.Module):
         plan = ctx.plan if (f16 and ctx is not None) else None
         qk_pair = bool(plan is not None and plan.pairs_at(self.layer_index))
         guard = ctx.guard if (f16 and ctx is not None) else None
-        g_col = guard.col[2 * self.layer_index] if guard is not None else None          # plan guard: column maxima of the stream after this branch
+        g_col = guard.col[2 * self.layer_index + 1] if guard is not None else None          # plan guard: column maxima of the stream after this branch
         if qk_pair:
             # precision 'half' on a model with large attention scores: q / k leave the LN-folded projection as fp16 (hi, lo) pairs, are rotated
             # with FP32 tables (ctx.cos / ctx.sin are float32 then) and multiplied in three MFMA passes; v, P and the output stay single fp16
@@ -708,7 +709,7 @@ class FlashTransformerLayer(nn.Module):
         self.self_attn(x16, cu_lens, max_len, None, ctx, alpha=alpha, out=x16, x_stats=ctx.sums, stats_out=ctx.part_b,
                        resid32=r32, resid_pair=rp, pair_scale=sa, pair_ext=ext)
         self._ffn(x16, None, alpha, x16, x_stats=ctx.part_b, stats_out=ctx.part_a, resid32=r32, resid_pair=rp, pair_scale=sf, pair_ext=ext,
-                  ovf=ctx.ovf, col_absmax=ctx.guard.col[2 * self.self_attn.layer_index + 1] if (ctx.f16 and ctx.guard is not None) else None)
+                  ovf=ctx.ovf, col_absmax=ctx.guard.col[2 * self.self_attn.layer_index + 2] if (ctx.f16 and ctx.guard is not None) else None)
         ctx.sums = ctx.part_a
 
     def forward_exact(self, cu_lens, max_len, ctx: ForwardContext):

@@ -239,9 +239,11 @@ class ESM2(nn.Module):
         return torch.from_numpy(tokens), torch.from_numpy(cu), int(max(lengths))
 
     def _guard_scales(self, device):
-        """(2 L, phys_dim) float32: the per-column scaling the STORED pair stream carries at each guard site (HalfGuard.col rows): rho of the FFN
-        LayerNorm after layer i's attention branch, rho of layer i + 1's attention LayerNorm after its FFN branch, 1 after the last layer."""
-        rows, L = [], len(self.layers)          # (stream_scale() is cached per layer on the parameters' versions; this runs at synchronisation points only)
+        """(2 L + 1, phys_dim) float32: the per-column scaling the STORED pair stream carries at each guard site (HalfGuard.col rows): rho of layer 0's
+        attention LayerNorm at the start, rho of the FFN LayerNorm after layer i's attention branch, rho of layer i + 1's attention LayerNorm after
+        its FFN branch, 1 after the last layer."""
+        L = len(self.layers)                    # (stream_scale() is cached per layer on the parameters' versions; this runs at synchronisation points only)
+        rows = [self.layers[0].self_attn.stream_scale()[0]]
         for i, layer in enumerate(self.layers):
             rows.append(layer.stream_scale()[0])
             rows.append(self.layers[i + 1].self_attn.stream_scale()[0] if i + 1 < L else torch.ones(self.phys_dim, dtype=torch.float32, device=device))
@@ -262,7 +264,7 @@ class ESM2(nn.Module):
     def _calibrate_half(self, device):
         """One forward of the plain 'half' form over the calibration batch (_calibration_batch: the whole vocabulary, + the caller's own data if
         given), measured by the SAME device maxima the run-time guard keeps (HalfGuard: largest |value| of every stream channel after every
-        branch of every layer relative to the median channel's; squared q / k row norms per head) plus the embedding output and, for blocks
+        branch of every layer and at the start relative to the median channel's; squared q / k row norms per head) plus, for blocks
         whose projection does not carry the q / k guard (ESM-C, head dim 128, no rotary), a torch-side bound of |score| per layer."""
         from esme.attention import HalfPlan, HalfGuard
         tokens, cu, max_len = self._calibration_batch()
@@ -277,7 +279,6 @@ class ESM2(nn.Module):
         try:
             with torch.no_grad():
                 self._forward_representation(tokens, (cu, max_len), False, None, [L - 1])      # (`layers=`: the module-by-module path, which feeds the probe)
-                x0 = self._embedding_phys(tokens, (cu, max_len))[:, :self.embed_dim].float().abs().amax(dim=0)
         except BaseException:
             self._half_plan = None                                      # (no half-built plan survives a failed calibration)
             raise
@@ -285,8 +286,6 @@ class ESM2(nn.Module):
             self._calib_probe = None
             self.precision, self._half_guard = saved
         ratio, g_bound, covered = self._guard_measure(guard, device)
-        med0 = x0.median()
-        ratio = torch.maximum(ratio, torch.where(med0 > 0, x0 / med0.clamp_min(1e-30), torch.zeros_like(x0)))
         bounds = [float(b) for b in torch.stack(probe).tolist()] if probe else []        # one per layer, in layer order (torch-side, every layout)
         if len(bounds) == L:                                                              # the kernels' own figure where they keep one: the larger counts
             bounds = [max(b, float(g)) if c else b for b, g, c in zip(bounds, g_bound.tolist(), covered.tolist())]
@@ -319,7 +318,7 @@ class ESM2(nn.Module):
         if not self.half_guard or not len(self.layers):
             return None
         g = getattr(self, '_half_guard', None)
-        if g is None or g.col.device != torch.device(device) or g.col.shape != (2 * len(self.layers), self.phys_dim):
+        if g is None or g.col.device != torch.device(device) or g.col.shape != (2 * len(self.layers) + 1, self.phys_dim):
             from esme.attention import HalfGuard
             g = self._half_guard = HalfGuard(len(self.layers), self.phys_dim, self.layers[0].self_attn.num_heads, device)
         return g
@@ -593,7 +592,8 @@ class ESM2(nn.Module):
             ctx.sums = torch.empty(1, T, 2, dtype=torch.float32, device=x.device)
             # (stored scaled per column by rho of the first attention LayerNorm: attention._fold_layernorm_pow2)
             scales = [layer.self_attn.stream_scale() for layer in self.layers]
-            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True, scale=scales[0][0], ext_sel=ctx.plan.ext_sel)
+            _hip.stream_operand(x32, ctx.xs, ctx.sums, pair=True, scale=scales[0][0], ext_sel=ctx.plan.ext_sel,
+                                col_absmax=ctx.guard.col[0] if ctx.guard is not None else None)
             del x32
             x16 = ctx.xs[:, :Ep + ext]
             ctx.order = _hip.seq_order(cu_lens)

@@ -109,6 +109,12 @@ int esme_hip_stream_operand(const float* x32, int64_t ld32, void* x16, int64_t l
 int esme_hip_stream_operand_scaled(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
                                    const float* scale, const int32_t* ext_sel, int ext_n, int64_t ext_off,
                                    float* sums, int64_t T, int E, void* stream);
+/* The same with the plan guard of precision 'half' (ABI 9; esme_gemm_fusion_t.col_absmax): col_absmax (uint32 (E), 16-byte aligned, device; NULL = off)
+ * receives, per column, the float bit pattern of the running max over rows of |scale[e] * x32[t, e]| -- the stream as the FIRST LayerNorm-folded
+ * projection reads it (the embedding output: where a token-triggered massive channel is most visible). */
+int esme_hip_stream_operand_guarded(const float* x32, int64_t ld32, void* x16, int64_t ld16, int64_t lo_off, int f16,
+                                    const float* scale, const int32_t* ext_sel, int ext_n, int64_t ext_off,
+                                    float* sums, uint32_t* col_absmax, int64_t T, int E, void* stream);
 
 /* out[t, e] = x[t, e] + x[t, lo_off + e] in fp32 for a 16-bit pair stream (bf16, or IEEE fp16 when f16 != 0): the raw layer outputs that
  * forward_representation(layers=[...]) (esme/esm.py:225-227,249-264) returns when the stream is a pair (precision 'half'). */
@@ -559,8 +565,9 @@ typedef struct esme_model_desc {
     int* half_overflow_flag;     /* esme_hip_forward_half: the run-time range guard (esme_gemm_fusion_t.overflow_flag), int32 on the device or NULL */
     const float* cos32; const float* sin32;      /* esme_hip_forward_half with half_qk_pair: fp32 rotary tables of the flagged layers */
     /* esme_hip_forward_half: the plan guard (esme_gemm_fusion_t.col_absmax / .qk_sumsq; ABI 9), device buffers or NULL:
-     *   half_col_absmax  uint32 (2 * n_layers, phys_dim): row 2 i = the stream after layer i's attention branch (scaled for its FFN LayerNorm:
-     *       ps_ffn), row 2 i + 1 = after its FFN branch (scaled for layer i + 1's attention LayerNorm; the last row unscaled);
+     *   half_col_absmax  uint32 (2 * n_layers + 1, phys_dim): row 0 = the stream at the start (scaled for layer 0's attention LayerNorm: ps_attn),
+     *       row 1 + 2 i = after layer i's attention branch (scaled for its FFN LayerNorm: ps_ffn), row 2 + 2 i = after its FFN branch (scaled for
+     *       layer i + 1's attention LayerNorm; the last row unscaled);
      *   half_qk_sumsq    uint32 (n_layers, 2, heads): layers whose q / k are NOT pairs and whose rotary is fused into the projection. */
     uint32_t* half_col_absmax; uint32_t* half_qk_sumsq;
 } esme_model_desc_t;

@@ -53,14 +53,20 @@ def test_residual_epilogue_column_maxima(M, N, K, tile):
     for guard in (None, col):
         xs = torch.empty(M, 2 * N, dtype=H16, device=DEV)
         _hip.stream_operand(x32.to(DEV), xs, None, pair=True, scale=rho.to(DEV))
-        st = torch.empty(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=DEV)
         with _hip.gemm_options(tile=tile):
+            st = torch.empty(_hip.stats_blocks(M, N), M, 2, dtype=torch.float32, device=DEV)      # (one partial per column tile of the configuration in force)
             _hip.gemm_fused(a, w, b, _hip.EPI_RESIDUAL, None, 0.7, stats_out=st, resid_pair=xs, pair_scale=((1.0 / rho).to(DEV), rho2.to(DEV)), col_absmax=guard)
         outs.append((xs, st))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     want = outs[1][0][:, :N].float().abs().amax(dim=0)
     assert torch.equal(as_f32(col), want)
     assert float(as_f32(col)[7]) > 10 * float(as_f32(col).median()) and float(as_f32(col)[100]) > 500
+    # the start of the stream (esme_hip_stream_operand_guarded): max |rho * x| per column in fp32, the pair itself bit-identical
+    c0 = torch.zeros(N, dtype=torch.int32, device=DEV)
+    xs0, xs1 = torch.empty(M, 2 * N, dtype=H16, device=DEV), torch.empty(M, 2 * N, dtype=H16, device=DEV)
+    _hip.stream_operand(x32.to(DEV), xs0, None, pair=True, scale=rho.to(DEV))
+    _hip.stream_operand(x32.to(DEV), xs1, None, pair=True, scale=rho.to(DEV), col_absmax=c0)
+    assert torch.equal(xs0, xs1) and torch.equal(as_f32(c0), (x32 * rho).abs().amax(dim=0).to(DEV))
     # running maximum: a second launch on a smaller stream leaves it where it was
     xs = torch.empty(M, 2 * N, dtype=H16, device=DEV)
     _hip.stream_operand((x32 * 0.01).to(DEV), xs, None, pair=True, scale=rho.to(DEV))
