@@ -148,11 +148,15 @@ __device__ __forceinline__ float lanes8_max_f32(float v) {
     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
-// sum of squares of 8 packed fp16 values in fp32 (v_dot2_f32_f16: both products exact, fp32 accumulation)
+// sum of squares of 8 packed fp16 values in fp32 (v_dot2_f32_f16: both products exact, fp32 accumulation).  Inline asm ON PURPOSE: hipcc (ROCm 7.2)
+// selects v_dot2c_f32_f16 for __builtin_amdgcn_fdot2 and, in the GEMM epilogue, emitted it four times on the FIRST dword with the accumulator
+// allocated on top of the second (found by the first GPU run of tests/test_half_guard_gpu.py: 1.3-1.6x too large).  One statement, with the
+// hazard the compiler cannot see inside inline asm spelled out: a DOT result read by a DIFFERENT VALU opcode needs 3 wait states (the chain itself
+// accumulates through SrcC back to back); without them the consumer read the sum before the last dword had landed (0.83-0.85x).
 __device__ __forceinline__ float sumsq8_f16(const u32x4 v) {
     float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const f16x2 h = __builtin_bit_cast(f16x2, v[i]); s = __builtin_amdgcn_fdot2(h, h, s, false); }
+    asm volatile("v_dot2_f32_f16 %0, %1, %1, %0\n\tv_dot2_f32_f16 %0, %2, %2, %0\n\tv_dot2_f32_f16 %0, %3, %3, %0\n\tv_dot2_f32_f16 %0, %4, %4, %0\n\ts_nop 3"
+                 : "+v"(s) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
     return s;
 }
 // running maximum of a NON-NEGATIVE float kept in memory as its bit pattern (integer order = float order there; NaN / inf stick on top)

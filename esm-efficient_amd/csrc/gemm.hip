@@ -854,9 +854,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n), v, a.stream_out);
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n), vl, a.stream_out);
                 }
-                if (guard_cols) {                              // (rows past M re-read row M - 1: harmless duplicates)
+                if (guard_cols) {                              // (rows past M are masked out: they re-read row M - 1 of a stream that is updated in place)
+                    const unsigned int keep = m < a.M ? 0x7fff7fffu : 0u;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cmx[q] = pk_absmax_f16(cmx[q], v[q]);
+                    for (int q = 0; q < 4; ++q) cmx[q] = pk_max_u16(cmx[q], v[q] & keep);
                 }
             }
         }
