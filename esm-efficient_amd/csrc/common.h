@@ -129,6 +129,12 @@ __device__ __forceinline__ unsigned int pk_absmax_f16(unsigned int acc, unsigned
     const u16x2 a = __builtin_bit_cast(u16x2, acc), b = __builtin_bit_cast(u16x2, v & 0x7fff7fffu);
     return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(a, b));
 }
+// acc <- max(acc, |v|) for two packed fp16 values in ONE instruction: gfx950's three-operand packed maximum with the third operand negated
+// (max(acc, v, -v)); IEEE "maximum": a NaN sticks.  acc must hold non-negative values (it then keeps doing so: compatible with pk_max_u16 above).
+__device__ __forceinline__ unsigned int pk_absmax3_f16(unsigned int acc, const unsigned int v) {
+    asm volatile("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(acc) : "v"(v));
+    return acc;
+}
 __device__ __forceinline__ unsigned int pk_max_u16(unsigned int x, unsigned int y) {
     return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y)));
 }

@@ -738,13 +738,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         char* slab_lo = slab + RPP * ROWB;
         const f32x4* sc_in = pscale + sp * (BN / 2) + ((wn * WTN) >> 2);     // this wave's 64 columns of {1 / rho_in, rho_out}
         const f32x4* sc_out = sc_in + BN / 4;
-        // plan guard (esme_gemm_fusion_t.col_absmax): running max |hi| of the lane's 8 stored columns over the tile's rows, as packed unsigned
-        // 16-bit patterns -- 4 registers, 2 VALU per dword in the store loop (the values are in registers there anyway)
+        // plan guard (esme_gemm_fusion_t.col_absmax): running max |hi| of the lane's 8 stored columns over the tile's rows, as packed non-negative
+        // fp16 patterns -- 4 registers, ONE VALU per dword in the store loop (the values are in registers there anyway)
         u32x4 cmx = {0u, 0u, 0u, 0u};
         unsigned int* const guard_cols = a.col_absmax;
+        // Lane l publishes column (l & 7) * 8 + (l >> 3) of the wave's 64 at the end of the tile.  Its CURRENT maximum is read long before it is
+        // needed (a plain load, possibly stale: it only decides whether an atomic is worth issuing -- a running maximum is raised O(log tiles) times per
+        // column, so after the first few tiles almost none is; unfiltered, the ~500 000 same-line atomics of a launch queued up at the L2 and cost the
+        // persistent kernel ~15 us per launch at the tile seam: profiles/r06_half_guard_cost.txt).
+        // (read at the top of the LAST pass, where its latency hides under that pass's residual loads and most accumulators are dead: kept live from the
+        // start of the epilogue it cost the persistent kernel two spilled registers)
+        unsigned int gcur = 0u;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (pass) __builtin_amdgcn_wave_barrier();        // the stores of the previous pass have read the slabs
+            if (pass == NPASS - 1 && guard_cols) {
+                const int gc = nw0 + (lane & 7) * 8 + (lane >> 3);
+                gcur = guard_cols[gc < n_out ? gc : n_out - 1];
+            }
 #pragma unroll
             for (int it = 0; it < RPP / 8; ++it) {
                 const int r = it * 8 + (lane >> 3);
@@ -854,24 +865,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n), v, a.stream_out);
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n), vl, a.stream_out);
                 }
-                if (guard_cols) {                              // (rows past M are masked out: they re-read row M - 1 of a stream that is updated in place)
-                    const unsigned int keep = m < a.M ? 0x7fff7fffu : 0u;
+                if (guard_cols) {
+                    if (mw0 + (pass + 1) * RPP <= a.M) {       // (wave-uniform) every row of this pass exists: one v_pk_maximum3_f16 per dword = half a VALU per element
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) cmx[q] = pk_max_u16(cmx[q], v[q] & keep);
+                        for (int q = 0; q < 4; ++q) cmx[q] = pk_absmax3_f16(cmx[q], v[q]);
+                    } else {                                   // last row tile: rows past M are masked out (they re-read row M - 1 of a stream that is updated in place)
+                        const unsigned int keep = m < a.M ? 0x7fff7fffu : 0u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) cmx[q] = pk_max_u16(cmx[q], v[q] & keep);
+                    }
                 }
             }
         }
-        if (guard_cols) {                                      // once per tile: the 8 lanes that hold the same column chunk combine, lanes 0..7 publish 8 columns each
+        if (guard_cols) {                                      // once per tile: the 8 lanes that hold the same column chunk combine; each lane then picks ITS column
 #pragma unroll
             for (int q = 0; q < 4; ++q) cmx[q] = lanes8_max_pk_u16(cmx[q]);
-            const int n = nw0 + (lane & 7) * 8;
-            if (lane < 8 && n < n_out) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    atomic_max_nonneg(guard_cols + n + 2 * q, lo16<true>(cmx[q]));
-                    atomic_max_nonneg(guard_cols + n + 2 * q + 1, hi16<true>(cmx[q]));
-                }
-            }
+            const int e = lane >> 3;                           // element 0..7 of the chunk's 8 columns
+            unsigned int w01 = (e & 2) ? cmx[1] : cmx[0], w23 = (e & 2) ? cmx[3] : cmx[2];
+            const unsigned int w = (e & 4) ? w23 : w01;
+            const unsigned int mine = __float_as_uint((e & 1) ? hi16<true>(w) : lo16<true>(w));
+            const int gcol = nw0 + (lane & 7) * 8 + e;
+            if (gcol < n_out && mine > gcur) atomicMax(guard_cols + gcol, mine);
         }
         sp ^= 1;
         } else {
@@ -1002,6 +1016,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
         constexpr bool QKG = F16 && LNF && ROTD > 0 && !PAIR;
         const bool qk_guard = QKG && a.qk_sumsq != nullptr && nw0 < a.rot_cols;
         float qk_max = 0.f;
+        unsigned int* qk_slot = nullptr;                          // this lane's head (lanes 0..7, first chunk of a head): its current maximum is read before the loop,
+        unsigned int qk_cur = 0u;                                 // used after it (a filter for the atomic, as for col_absmax above)
+        if constexpr (QKG) {
+            if (qk_guard && lane < 8 && (n % ROTD) == 0 && n < a.rot_cols) {
+                const int ea = a.rot_cols >> 1;                   // width of q (= of k)
+                qk_slot = a.qk_sumsq + (n >= ea ? ea / ROTD : 0) + (n % ea) / ROTD;
+                qk_cur = *qk_slot;
+            }
+        }
         if (col_ok || STATS) {
 #pragma unroll
             for (int it = 0; it < RPP / RPI; ++it) {
@@ -1037,11 +1060,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             }
         }
         if constexpr (QKG) {
-            if (qk_guard) {                                    // rows combine (lanes 8 apart), then one atomic per head of the wave's 64 columns
+            if (qk_guard) {                                    // rows combine (lanes 8 apart), then at most one atomic per head of the wave's 64 columns
                 qk_max = lanes8_max_f32(qk_max);
-                const int ea = a.rot_cols >> 1;                // width of q (= of k)
-                if (lane < 8 && (n % ROTD) == 0 && n < a.rot_cols)
-                    atomic_max_nonneg(a.qk_sumsq + (n >= ea ? ea / ROTD : 0) + (n % ea) / ROTD, qk_max);
+                if (qk_slot && __float_as_uint(qk_max) > qk_cur) atomicMax(qk_slot, __float_as_uint(qk_max));
             }
         }
         if constexpr (PERSIST) { if (pass == 0) ESME_TRACE_SEAM(22, 1); else ESME_TRACE_SEAM(25, 1); }
