@@ -1122,6 +1122,396 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 }
 
 
+// =============================================================================================
+// Head dims 64 / 32, ONE 32-row query block per wave, software-pipelined over KEY TILES (round 6): "attn_sb".
+//
+// attn_pp64_kernel hides a block's softmax under the MFMAs of the wave's OTHER block; that takes two blocks' accumulators and Q fragments
+// (233 of 256 registers at head dim 64), which is why the q/k-pair form of precision 'half' (three score passes: + the lo fragments of q, 32
+// registers) ran on the first-generation, non-pipelined structure at 14 % of the matrix peak.  Here a wave owns ONE
+// block and the pipeline runs along the key axis instead: in phase t
+//     VALU:  softmax of tile t's scores (parity buffer sacc[t & 1])  ->  P(t) (pw[t & 1]), row sums
+//     MFMA:  O^T += V(t-1)^T P(t-1)^T  (P of the previous phase)   then   S^T(t+1) = K(t+1) Q^T  into the other parity buffer
+// -- the same three independent streams as the ping-pong kernel with half the accumulators: 64 (scores) + 32 (O^T) + 16 (Q) [+ 16 (Q lo)] + 32 (P)
+// registers.  With q / k as pairs (QKP) a phase issues 8 + 3 x 8 = 32 MFMAs against the same 16 score pairs: the loop turns from VALU-bound to
+// MFMA-bound, i.e. the two extra score passes cost matrix-pipe time the plain kernel leaves idle (52 % busy) rather than a second trip.
+// Online softmax with a DEFERRED rescale: the MFMAs of phase t add P(t-1), which was formed against the reference maximum of phase t-1, so a maximum
+// raised in phase t rescales the row sum at once but O^T only after the phase's MFMAs (before P(t) is added in phase t + 1).
+// LDS: ring of THREE slots (K tile [+ K lo tile] + V tile); phase t reads K(t+1) and V(t-1), prefetches K(t+3) into K(t)'s slot and V(t+1) into
+// V(t-2)'s (both last read in phase t-1; two phases to land, counted vmcnt + one raw barrier per phase as in attn_pp64_kernel).  48 KB (72 KB with
+// K lo) per workgroup of 4 waves = 128 query rows: two workgroups per CU.
+// QP / F16 / speculative pass / redo: exactly attn_pp64_kernel's (see there); QKP runs with exact maxima (a.spec = 0): with scores in the
+// hundreds a later key beats the first tile's maximum by more than fp16's range on most rows, and the speculative pass would be redone anyway.
+template <int D, bool F16, bool QKP, bool QP>
+__global__ __launch_bounds__(256, 2) void attn_sb_kernel(const AttnSplitArgs sa) {
+    static_assert(!QKP || F16, "q/k pairs: the fp16 form");
+    static_assert(!(F16 && QP), "fp16 P needs a reference maximum");
+    static_assert(D == 64 || D == 32, "head dims 64 and 32");
+    const AttnArgs& a = sa.a;
+    constexpr int NW = 4, NT = 256, DS = D / 16, DB = D / 32;
+    constexpr int ROWB = D * 2, K_BYTES = KT * D * 2, KP = QKP ? 2 : 1;
+    constexpr int V_OFF = KP * K_BYTES, SLOT = V_OFF + D * 128, NS = 3, ROWS = NW * 32;
+    constexpr int NPV = 4 * DB, NQK1 = 2 * DS, NQK = NQK1 * (QKP ? 3 : 1), NM = NPV + NQK;      // MFMAs of a phase
+    extern __shared__ __attribute__((aligned(16))) char smem_sb[];
+    char* smem = smem_sb;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned int xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3;          // (block id -> work item: as attn_pp64_kernel)
+    const int qt = (int)(bi % (unsigned int)a.nqt);
+    const unsigned int hb = (bi / (unsigned int)a.nqt) * 8u + xcd;
+    if (hb >= (unsigned int)a.nhb) return;
+    const int h = (int)(hb % (unsigned int)a.H), bi_seq = (int)(hb / (unsigned int)a.H);
+    const int b = a.order ? a.order[bi_seq] : bi_seq;
+    const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
+    const int q0 = qt * ROWS;
+    if (q0 >= S) return;
+
+    const unsigned int ld = (unsigned int)a.ld;
+    const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
+    const unsigned int kv_bytes = ((unsigned int)(S - 1) * ld + D) * 2u;
+    auto make_rsrc = [&](const u16* p) -> u32x4 {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        return u32x4{(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v),
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)(v >> 32) & 0xffffu)),
+                     (unsigned int)__builtin_amdgcn_readfirstlane((int)kv_bytes), 0x00020000u};
+    };
+    const u32x4 krs = make_rsrc(a.k + (int64_t)s0 * a.ld + h * D);
+    const u32x4 klrs = make_rsrc(a.k + (QKP ? sa.lo_in : 0) + (int64_t)s0 * a.ld + h * D);
+    const u32x4 vrs = make_rsrc(a.v + (int64_t)s0 * a.ld + h * D);
+    auto dma16 = [&](const u32x4 rs, const unsigned int voff, const char* dst) {
+        ESME_LDS_CHECK(dst, 1024, smem, NS * SLOT);
+        const unsigned int d = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(uintptr_t)dst);
+        unsigned int keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(d), "s"(rs) : "memory");
+    };
+
+    // ---- Q fragments of the wave's block (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 ..]; QKP: the lo halves too
+    bf16x8 qf[DS], qfl[QKP ? DS : 1];
+    const int wrow0 = q0 + wave * 32;
+    const bool wave_active = wrow0 < S;
+    {
+        const int qr = wrow0 + l31;
+        const unsigned int qc = qr < S ? qr : S - 1;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+            qf[ds] = *reinterpret_cast<const bf16x8*>(qb + (qc * ld + ds * 16 + hi * 8));
+            if constexpr (QKP) qfl[ds] = *reinterpret_cast<const bf16x8*>(qb + sa.lo_in + (qc * ld + ds * 16 + hi * 8));
+        }
+    }
+
+    // ---- staging (as attn_pp64_kernel: LDS-DMA, source-address swizzle, descriptor bounds = zeros past the sequence end)
+    constexpr int KI = K_BYTES / (NW * 1024);                    // DMA instructions per wave per K (or V) tile part (2 or 1)
+    constexpr int CPR = D / 8;
+    const unsigned int tile_bytes = (unsigned int)KT * ld * 2u;
+    unsigned int kg0, vg0;
+    {
+        const int r = wave * (64 / CPR) + lane / CPR, pch = lane % CPR;
+        kg0 = ((unsigned int)r * ld + ((pch ^ kswz<D>(r)) * 8)) * 2u;
+        vg0 = ((unsigned int)r * ld + ((D == 64 ? (pch ^ (((r >> 1) & 1) << 2)) : pch) * 8)) * 2u;
+    }
+    const unsigned int kg_step = (unsigned int)(NW * (64 / CPR)) * ld * 2u;
+    // piece p of a tile's prefetch: [0, KI) K hi, [KI, KP*KI) K lo, then KI pieces of V
+    auto dma_k_piece = [&](const int tile, char* slot, const int p) {
+        const int part = p / KI, i = p % KI;
+        dma16(part ? klrs : krs, (unsigned int)tile * tile_bytes + kg0 + i * kg_step, slot + part * K_BYTES + (i * NW + wave) * 1024);
+    };
+    auto dma_v_piece = [&](const int tile, char* slot, const int i) {
+        dma16(vrs, (unsigned int)tile * tile_bytes + vg0 + i * kg_step, slot + V_OFF + (i * NW + wave) * 1024);
+    };
+    auto dma_k = [&](const int tile, char* slot) {
+#pragma unroll
+        for (int p = 0; p < KP * KI; ++p) dma_k_piece(tile, slot, p);
+    };
+    auto dma_v = [&](const int tile, char* slot) {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) dma_v_piece(tile, slot, i);
+    };
+
+    const int krow_perm = (l31 & 3) | (((l31 >> 3) & 1) << 2) | (((l31 >> 2) & 1) << 3) | (l31 & 16);
+    int kfo[DS];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) kfo[i] = krow_perm * ROWB + (((i * 2 + hi) ^ kswz<D>(krow_perm)) << 4);
+    int vb[DB];
+    {
+        const int j = (lane & 15) >> 2, p = lane & 3, gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) vb[db] = V_OFF + (hi * 8 + j) * ROWB + (D == 64 ? ((db ^ (j >> 1)) * 64) : 0) + gsel * 32 + p * 8;
+    }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto vfrag = [&](const char* Vs, const int db, const int ks) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4* ltr_t;
+        const char* p = Vs + vb[db] + ks * (16 * ROWB);
+        ESME_LDS_CHECK(p, 8, smem, NS * SLOT); ESME_LDS_CHECK(p + 4 * ROWB, 8, smem, NS * SLOT);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p));
+        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ltr_t)(p + 4 * ROWB));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 oacc[DB], sacc[2][2];       // sacc[parity of the key tile][32-key block]
+    u32x4 pw[2][2][2];                 // P of tile parity p as packed 16-bit values: [p][32-key block][16-key step]
+    float mc, lrun;
+    const float c = a.scale_log2, thr = a.thr;
+    int ovf = 0;
+
+    // MFMA m of a phase.  m < NPV: O^T += V^T P^T (db-minor: consecutive MFMAs alternate between the two accumulators); then the score passes,
+    // 32-key-block-minor.  QKP pass order: Kh Qh^T (clears the accumulator), Kl Qh^T, Kh Ql^T.
+    auto frag = [&](const int m, const char* Ks, const char* Vs) -> bf16x8 {
+        if (m < NPV) return vfrag(Vs, m % DB, m / DB);
+        const int j = (m - NPV) % NQK1, pass = (m - NPV) / NQK1;
+        const char* p = Ks + (pass == 1 ? K_BYTES : 0) + (j & 1) * (32 * ROWB) + kfo[j >> 1];
+        ESME_LDS_CHECK(p, 16, smem, NS * SLOT);
+        return *reinterpret_cast<const bf16x8*>(p);
+    };
+
+    // One phase: softmax of the scores in sacc[P] (key tile at kv0), interleaved with the phase's MFMAs (P(t-1) V(t-1) into O^T, K(t+1) Q^T into
+    // sacc[P ^ 1]).  Returns nothing; `alpha` != 1 (wave-uniform flag `resc`) is applied to O^T after the MFMAs.
+    auto phase = [&](auto P_, const bool need_max, const bool tail, const char* Ks, const char* Vs, const int kv0, auto&& hook) __attribute__((always_inline)) {
+        constexpr int P = decltype(P_)::value, PN = P ^ 1;
+        bf16x8 fr[3];
+        fr[0] = frag(0, Ks, Vs);
+        fr[1] = frag(1, Ks, Vs);
+        auto mfma_step = [&](const int m) {
+            if (m + 2 < NM) fr[(m + 2) % 3] = frag(m + 2, Ks, Vs);
+            if (m >= NPV) {
+                const int j = (m - NPV) % NQK1, pass = (m - NPV) / NQK1, kbk = j & 1, ds = j >> 1;
+                const bf16x8 qop = (QKP && pass == 2) ? qfl[QKP ? ds : 0] : qf[ds];
+                if (pass == 0 && ds == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    sacc[PN][kbk] = mfma_32x32x16<F16>(fr[m % 3], qop, z);
+                } else {
+                    sacc[PN][kbk] = mfma_32x32x16<F16>(fr[m % 3], qop, sacc[PN][kbk]);
+                }
+            } else {
+                const int db = m % DB, ks = m / DB;
+                oacc[db] = mfma_32x32x16<F16>(fr[m % 3], __builtin_bit_cast(bf16x8, pw[PN][ks >> 1][ks & 1]), oacc[db]);
+            }
+        };
+        float ps0, ps1, ps2, ps3;
+        float xa0, xa1, pa0 = 0.f, pa1 = 0.f;
+        auto pair_fma = [&](const int p, const float nm) {
+            const int kbk = p >> 3, r = (2 * p) & 15;
+            xa0 = fmaf(sacc[P][kbk][r], c, nm);
+            xa1 = fmaf(sacc[P][kbk][r + 1], c, nm);
+        };
+        auto pair_sum_pack = [&](const int p, const float q0_, const float q1_) {
+            const int kbk = p >> 3, r = (2 * p) & 15;
+            pw[P][kbk][r >> 3][(r & 7) >> 1] = pack16<F16>(q0_, q1_);
+            if (p & 1) { ps2 += q0_; ps3 += q1_; } else { ps0 += q0_; ps1 += q1_; }
+        };
+        auto softmax_slot = [&](const int m, const float nm) {      // pair step m = 0..15
+            const float q0_ = pa0, q1_ = pa1;
+            if constexpr (QP) {
+                const int kb2 = m >> 3, r2 = (2 * m) & 15;
+                pa0 = __builtin_amdgcn_exp2f(sacc[P][kb2][r2]);
+                pa1 = __builtin_amdgcn_exp2f(sacc[P][kb2][r2 + 1]);
+                if (m >= 1) pair_sum_pack(m - 1, q0_, q1_);
+                const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
+                asm volatile("" : "+v"(pw[P][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(pa0), "+v"(pa1));
+            } else {
+                const float x0 = xa0, x1 = xa1;
+                if (m + 1 < 16) pair_fma(m + 1, nm);
+                pa0 = __builtin_amdgcn_exp2f(x0);
+                pa1 = __builtin_amdgcn_exp2f(x1);
+                if (m >= 1) pair_sum_pack(m - 1, q0_, q1_);
+                const int pk = m >= 1 ? m - 1 : 0, kbk = pk >> 3, r = (2 * pk) & 15;
+                asm volatile("" : "+v"(pw[P][kbk][r >> 3]), "+v"(ps0), "+v"(ps1), "+v"(ps2), "+v"(ps3), "+v"(xa0), "+v"(xa1), "+v"(pa0), "+v"(pa1));
+            }
+        };
+        auto tile_max = [&]() -> float {
+            float tmax = sacc[P][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[P][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[P][1][r]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c;
+        };
+        if (tail) {
+            int lim = S - kv0 - 8 * hi;
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbk * 32 + 16 * (r >> 3) + (r & 7) >= lim) sacc[P][kbk][r] = -1e30f;
+        }
+        float alpha = 1.0f;
+        bool resc = false;
+        if (need_max) {
+            asm volatile("" ::: "memory");
+            const float tmc = tile_max();
+            if (__any(tmc > mc + thr)) {                      // raise the reference maximum: the row sum now, O^T after this phase's MFMAs
+                const float mn = fmaxf(mc, tmc);
+                alpha = __builtin_amdgcn_exp2f(mc - mn);
+                mc = mn;
+                lrun *= alpha;
+                resc = true;
+            }
+            if constexpr (QP) {
+                const float mref = mc;
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[P][kbk][r] -= mref;
+            }
+        }
+        ps0 = ps1 = ps2 = ps3 = 0.f;
+        const float nm = -mc;
+        if constexpr (!QP) pair_fma(0, nm);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            mfma_step(m);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NM >= 16) { if (m % (NM / 16) == 0) softmax_slot(m / (NM / 16), nm); }
+            else {
+#pragma unroll
+                for (int u = 0; u < 16 / NM; ++u) softmax_slot(m * (16 / NM) + u, nm);
+            }
+            hook(m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pair_sum_pack(15, pa0, pa1);
+        const float psum = (ps0 + ps1) + (ps2 + ps3);
+        if (__any(!(psum < (F16 ? 3.0e4f : 1e30f)))) ovf = 1;
+        lrun += psum;
+        if (resc) {                                           // (wave-uniform) the deferred rescale of O^T
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    const int nt = (S + KT - 1) / KT;
+    bool exact = !a.spec;
+    constexpr int NPK = KP * KI, NPIECE = NPK + KI;            // prefetch DMA instructions of a phase per wave: K(t+3) parts, V(t+1)
+    for (;;) {
+        mc = -1e30f; lrun = (QP && !wave_active) ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { if (i < DB) oacc[i < DB ? i : 0][r] = 0.f; sacc[0][i][r] = 0.f; sacc[1][i][r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { pw[0][i][s] = u32x4{0u, 0u, 0u, 0u}; pw[1][i][s] = u32x4{0u, 0u, 0u, 0u}; }
+        }
+        // ---- prologue: K tiles 0..2 and V tile 0 by LDS-DMA; V of slot 2 (= "tile -1") zeroed: phase 0 multiplies it by P = 0
+        dma_k(0, smem);
+        dma_v(0, smem);
+        if (nt > 1) dma_k(1, smem + SLOT);
+        if (nt > 2) dma_k(2, smem + 2 * SLOT);
+#pragma unroll
+        for (int ds = 0; ds < DS; ds += 2) asm volatile("" : "+v"(qf[ds]), "+v"(qf[ds + 1]) : : "memory");
+        if constexpr (QKP) {
+#pragma unroll
+            for (int ds = 0; ds < DS; ds += 2) asm volatile("" : "+v"(qfl[ds]), "+v"(qfl[ds + 1]) : : "memory");
+        }
+        {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            char* v2 = smem + 2 * SLOT + V_OFF;
+#pragma unroll
+            for (int i = 0; i < (D * 128) / (NT * 16); ++i) *reinterpret_cast<u32x4*>(v2 + (i * NT + tid) * 16) = z;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave_active) {                      // S^T(tile 0) into sacc[0]
+#pragma unroll
+            for (int pass = 0; pass < (QKP ? 3 : 1); ++pass)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds)
+#pragma unroll
+                    for (int kbk = 0; kbk < 2; ++kbk) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(smem + (pass == 1 ? K_BYTES : 0) + kbk * (32 * ROWB) + kfo[ds]);
+                        sacc[0][kbk] = mfma_32x32x16<F16>(kf, (QKP && pass == 2) ? qfl[QKP ? ds : 0] : qf[ds], sacc[0][kbk]);
+                    }
+        }
+        const bool ragged = (S & (KT - 1)) != 0;
+        // phase t: reads K(t+1) [slot (t+1) % 3] and V(t-1) [slot (t+2) % 3]; prefetches K(t+3) into slot t % 3 and V(t+1) into slot (t+1) % 3's V
+        // region (V(t-2)'s).  At its end: K(t+2) and V(t) (issued in phase t-1) must have landed; this phase's own DMAs may stay in flight.
+        auto step = [&](auto P_, const int t) __attribute__((always_inline)) {
+            const bool pf_k = t + 3 < nt, pf_v = t + 1 < nt;         // block-uniform
+            char* kslot = smem + (t % NS) * SLOT;
+            char* vslot = smem + ((t + 1) % NS) * SLOT;
+            if (wave_active) {
+                const char* Ks = smem + ((t + 1) % NS) * SLOT;
+                const char* Vs = smem + ((t + 2) % NS) * SLOT;
+                const bool tail = t == nt - 1 && ragged;
+                const bool need_max = exact || (!QP && t == 0);
+                phase(P_, need_max, tail, Ks, Vs, t * KT, [&](const int m) {
+#pragma unroll
+                    for (int p = 0; p < NPIECE; ++p) {
+                        if (m == ((2 * p + 1) * NM) / (2 * NPIECE)) {        // the pieces spread over the phase, each behind an MFMA
+                            if (p < NPK) { if (pf_k) dma_k_piece(t + 3, kslot, p); }
+                            else if (pf_v) dma_v_piece(t + 1, vslot, p - NPK);
+                        }
+                    }
+                });
+            } else {
+                if (pf_k) dma_k(t + 3, kslot);
+                if (pf_v) dma_v(t + 1, vslot);
+            }
+            if (pf_k) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NPIECE) : "memory");
+            else if (pf_v) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+        // (V(0) was drained with the prologue; V(1) is issued in phase 0 and first read in phase 2)
+        for (int t = 0; t < nt; t += 2) {
+            step(I0{}, t);
+            if (t + 1 < nt) step(I1{}, t + 1);
+        }
+        if (wave_active) {                          // drain: O^T += V(nt-1) P(nt-1)
+            const char* Vs = smem + ((nt - 1) % NS) * SLOT;
+            auto drain = [&](auto P_) __attribute__((always_inline)) {
+                constexpr int P = decltype(P_)::value;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int db = 0; db < DB; ++db)
+                        oacc[db] = mfma_32x32x16<F16>(vfrag(Vs, db, ks), __builtin_bit_cast(bf16x8, pw[P][ks >> 1][ks & 1]), oacc[db]);
+            };
+            if ((nt - 1) & 1) drain(I1{}); else drain(I0{});
+        }
+        if constexpr (QP) {
+            if (!exact) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun), __float_as_uint(lrun), false, false);
+                if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > 1e-30f))) ovf = 1;
+            }
+        }
+        if (exact || !__syncthreads_or(ovf)) break;
+        exact = true;
+        ovf = 0;
+    }
+    if (!wave_active) return;
+
+    // ---- epilogue: normalise, transpose through a wave-private slab in the slot no wave reads any more (tile nt's), whole rows out
+    constexpr int OCH = D / 8;
+    char* slab = smem + (nt % NS) * SLOT + wave * (32 * ROWB);
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun), __float_as_uint(lrun), false, false);
+        const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk = {pack16<F16>(oacc[db][4 * g] * inv, oacc[db][4 * g + 1] * inv),
+                            pack16<F16>(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv)};
+                ESME_LDS_CHECK(slab + l31 * ROWB + (((db * 4 + g) ^ (l31 & (OCH - 1))) << 4) + hi * 8, 8, smem, NS * SLOT);
+                *reinterpret_cast<u32x2*>(slab + l31 * ROWB + (((db * 4 + g) ^ (l31 & (OCH - 1))) << 4) + hi * 8) = pk;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / (64 / OCH); ++it) {
+            const int r = it * (64 / OCH) + lane / OCH, ch = lane % OCH;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (OCH - 1))) << 4));
+            if (wrow0 + r < S) *reinterpret_cast<u32x4*>(a.o + (int64_t)(s0 + wrow0 + r) * a.ldo + h * D + ch * 8) = v;
+        }
+    }
+}
+
 #ifdef ESME_ATTN_W4          // lab build only (tools/lab/build_alt.sh attn.hip ... with -DESME_ATTN_W4): measured slower, see the note below
 // =============================================================================================
 // Head dim 64, ONE wave per SIMD (round 4): 4 waves per workgroup, each wave owns FOUR 32-row query blocks (128 rows; 512 per
@@ -1493,6 +1883,26 @@ static int launch_pp64(AttnArgs& a, int B, int max_len, hipStream_t s) {
     return check_launch("attn_varlen_fwd");
 }
 
+template <int D, bool F16, bool QKP, bool QP>
+static int launch_sb(AttnSplitArgs& sa, int B, int max_len, hipStream_t s) {
+    constexpr int smem = 3 * ((QKP ? 2 : 1) * KT * D * 2 + D * 128);
+    auto kern = attn_sb_kernel<D, F16, QKP, QP>;
+    static std::atomic<unsigned long long> done{0ull};         // dynamic-LDS attribute: per (kernel, device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return fail(ESME_ERR_LAUNCH, "attn: cannot raise the dynamic LDS limit");
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    sa.a.nqt = (max_len + 127) / 128;
+    const int64_t blocks = (int64_t)sa.a.nqt * (((int64_t)sa.a.H * B + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "attn: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned int)blocks), dim3(256), smem, s, sa);
+    return check_launch("attn_varlen_fwd");
+}
+
 #ifdef ESME_ATTN_W4
 static int launch_w4(AttnArgs& a, int B, int max_len, hipStream_t s) {
     constexpr int smem = 4 * (KT * 64 * 2 + 64 * 128);
@@ -1543,6 +1953,13 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     const hipStream_t s = (hipStream_t)stream;
     // (the ping-pong kernel addresses K / V with 32-bit byte offsets inside one sequence: (max_len + one tile) rows must fit)
     const bool fits32 = ((int64_t)max_len + KT) * ld_qkv * 2 < 0xffffffffLL;
+    if ((d == 64 || d == 32) && g_attn_variant == 2 && ld_o % 8 == 0 && aligned16(o) && fits32) {
+        // per-call option 2: the single-block pipelined kernel (attn_sb_kernel: 128 query rows per workgroup) -- what the q/k-pair entry runs; here for
+        // A/B measurements of the plain forms against the ping-pong kernel
+        AttnSplitArgs sa{a, 0, 0};
+        if (d == 64) return f16 ? launch_sb<64, true, false, false>(sa, B, max_len, s) : (qp ? launch_sb<64, false, false, true>(sa, B, max_len, s) : launch_sb<64, false, false, false>(sa, B, max_len, s));
+        return f16 ? launch_sb<32, true, false, false>(sa, B, max_len, s) : (qp ? launch_sb<32, false, false, true>(sa, B, max_len, s) : launch_sb<32, false, false, false>(sa, B, max_len, s));
+    }
     if (d == 64 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o) && fits32) {
         // head dim 64 (ESM2-650M / 3B, ESM-C): the software-pipelined kernel.  4 waves = 256 query rows per workgroup, two
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
@@ -1627,9 +2044,11 @@ extern "C" int esme_hip_attn_varlen_fwd_split(const void* q, const void* k, cons
     }
 }
 
-extern "C" int esme_hip_attn_varlen_fwd_qkpair_f16(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qk, void* o,
-                                                   int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
-                                                   int max_len, float softmax_scale, const int32_t* seq_order, void* stream) {
+extern "C" int esme_hip_attn_varlen_fwd_qkpair_f16_opts(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qk, void* o,
+                                                        int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                                        int max_len, float softmax_scale, const esme_attn_opts_t* opts, void* stream) {
+    ESME_CHECK_ARG(!opts || opts->struct_bytes == (int)sizeof(esme_attn_opts_t), "attn_qkpair: options struct of another ABI");
+    const int32_t* seq_order = opts ? opts->seq_order : nullptr;
     ESME_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && d > 0 && max_len >= 0, "attn_qkpair: bad sizes");
     if (T == 0 || B == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && v && o && cu_lens, "attn_qkpair: null pointer");
@@ -1640,12 +2059,24 @@ extern "C" int esme_hip_attn_varlen_fwd_qkpair_f16(const void* q, const void* k,
                       0.0f, 0, seq_order}, lo_qk, 0};
     const dim3 grid((unsigned int)((max_len + QT - 1) / QT), (unsigned int)H, (unsigned int)B);
     const hipStream_t s = (hipStream_t)stream;
+    // options variant 2, head dims 64 / 32: the key-axis-pipelined kernel (round 6; exact maxima: spec = 0, thr = 0).  Measured (profiles/r06_attn_sb_bench.txt):
+    // 404 vs 363 us at 100 x 500, 636 vs 641 at 49 x 1 002, 1 140 vs 1 168 at 25 x 2 000 -- not the hoped-for 260 us, so the first-generation kernel stays the default
+    const bool fits32 = ((int64_t)max_len + KT) * ld_qkv * 2 < 0xffffffffLL;
+    if ((d == 64 || d == 32) && opts && opts->variant == 2 && ld_o % 8 == 0 && aligned16(o) && fits32)
+        return d == 64 ? launch_sb<64, true, true, false>(sa, B, max_len, s) : launch_sb<32, true, true, false>(sa, B, max_len, s);
     switch (d) {
         case 16: return launch_split<16, true, true>(sa, grid, s);
         case 32: return launch_split<32, true, true>(sa, grid, s);
         case 64: return launch_split<64, true, true>(sa, grid, s);
         default: ESME_FAIL(ESME_ERR_UNSUPPORTED, "attn_qkpair: head dim must be 16, 32 or 64");
     }
+}
+
+extern "C" int esme_hip_attn_varlen_fwd_qkpair_f16(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qk, void* o,
+                                                   int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                                   int max_len, float softmax_scale, const int32_t* seq_order, void* stream) {
+    esme_attn_opts_t o1{(int)sizeof(esme_attn_opts_t), 0, 0, 0.0f, 0, seq_order, 0, 1};
+    return esme_hip_attn_varlen_fwd_qkpair_f16_opts(q, k, v, ld_qkv, lo_qk, o, ld_o, cu_lens, B, T, H, d, max_len, softmax_scale, &o1, stream);
 }
 
 extern "C" int esme_hip_attn_varlen_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv, void* o,

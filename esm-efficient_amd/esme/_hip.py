@@ -103,6 +103,8 @@ SIGNATURES = {
     'esme_hip_rotary_split_f16': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_attn_varlen_fwd_qkpair_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int,
                                                     c_int, c_float, c_void_p, c_void_p]),
+    'esme_hip_attn_varlen_fwd_qkpair_f16_opts': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_int,
+                                                    c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_residual_f32': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_void_p]),
     'esme_hip_layernorm_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
@@ -679,11 +681,13 @@ def attn_varlen_qkpair(qkv: torch.Tensor, cu_lens: torch.Tensor, max_len: int, h
     B = cu.numel() - 1
     if order is not None and order.numel() != B:
         raise ValueError('attn: `order` must be a permutation of the B sequence indices (seq_order(cu_lens))')
+    base = _TLS.attn_opts                                 # (variant 1 = the first-generation three-pass kernel, for A/B runs: `with attn_options(variant=1)`)
+    ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, 0, 0.0, 0,
+                  _dev(order, 'seq order', torch.int32) if order is not None else None, 0, 1)
     with _Traced('attn_qkpair', (T, heads, head_dim)):
-        _check(load().esme_hip_attn_varlen_fwd_qkpair_f16(qp, qp + 2 * E, qp + 4 * E, ld, 3 * E, op, ldo, _dev(cu, 'cu_lens', torch.int32),
-                                                          B, T, heads, head_dim, int(max_len), float(softmax_scale),
-                                                          _dev(order, 'seq order', torch.int32) if order is not None else None, _stream()),
-               'esme_hip_attn_varlen_fwd_qkpair_f16')
+        _check(load().esme_hip_attn_varlen_fwd_qkpair_f16_opts(qp, qp + 2 * E, qp + 4 * E, ld, 3 * E, op, ldo, _dev(cu, 'cu_lens', torch.int32),
+                                                               B, T, heads, head_dim, int(max_len), float(softmax_scale), ctypes.byref(ao), _stream()),
+               'esme_hip_attn_varlen_fwd_qkpair_f16_opts')
     return out
 
 

@@ -141,7 +141,22 @@ class ESM2(nn.Module):
             self._embed_pad_key = key
         return self._embed_pad
 
+    # ESME_CHECK_TOKENS=1 (or model.debug_checks = True): every forward validates its token ids on the device first -- one synchronisation per call.
+    # The reference's nn.Embedding raises on an id outside the table (esme/esm.py:176-199); esme_hip_embed writes a zero row instead (no trap on the hot
+    # path), a silent divergence for CORRUPT input only: check_tokens() is the explicit form, predict_* call it in precision 'half' (they synchronise anyway).
+    debug_checks = os.environ.get('ESME_CHECK_TOKENS', '0') == '1'
+
+    def check_tokens(self, tokens):
+        """IndexError if a token id lies outside the embedding table (the reference raises there; the HIP lookup returns a zero row).  Synchronises."""
+        if tokens.numel() and not torch.cuda.is_current_stream_capturing():
+            lo, hi = int(tokens.min()), int(tokens.max())
+            if lo < 0 or hi >= self.embed_tokens.weight.shape[0]:
+                raise IndexError(f'token id {lo if lo < 0 else hi} is outside the embedding table of {self.embed_tokens.weight.shape[0]} rows')
+        return self
+
     def _embedding_phys(self, tokens, pad_args=None):
+        if self.debug_checks:
+            self.check_tokens(tokens)
         return _hip.embed(tokens, self._embed_table(),
                           mask_idx=self.alphabet.mask_idx if self.zero_mask_rows else -1,
                           pad_idx=self.alphabet.padding_idx if (tokens.ndim == 2 and self.zero_mask_rows) else -1)
@@ -652,12 +667,14 @@ class ESM2(nn.Module):
                 return y.view(*pair.shape[:-1], y.shape[-1])
             return self.lm_head(self._forward_representation(tokens, pad_args, pad_output, pad_indices, []))
 
-    def _checked(self, run):
+    def _checked(self, run, tokens=None):
         """Run `run()` (a forward ending in a softmax) and, in precision 'half' with half_check = 'sync', look at the range flag and the plan
         guard (one synchronisation; the result is about to be read anyway).  A stale plan is widened and the batch re-run ONCE with it, so
         the value returned rests on a plan that covers this very batch; an overflow raises.  (esme.pipeline reads both with each result
         instead: `_defer_overflow`.)"""
         y = run()
+        if self.precision == 'half' and self.half_check == 'sync' and tokens is not None and not getattr(self, '_defer_overflow', False):
+            self.check_tokens(tokens)
         if self.precision != 'half' or self.half_check != 'sync' or getattr(self, '_defer_overflow', False) or torch.cuda.is_current_stream_capturing():
             return y
         self.check_overflow()
@@ -669,12 +686,12 @@ class ESM2(nn.Module):
 
     def predict_log_prob(self, tokens, pad_args=None, pad_output=False, pad_indices=None, lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            return self._checked(lambda: _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True))
+            return self._checked(lambda: _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=True), tokens)
 
     def predict_prob(self, tokens, log=False, pad_args=None, pad_output=False, pad_indices=None,
                      lora_names=None):
         with _hip.stream_scope(self.embed_tokens.weight.device):
-            return self._checked(lambda: _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log)))
+            return self._checked(lambda: _hip.softmax_rows(self(tokens, pad_args, pad_output, pad_indices, lora_names), log=bool(log)), tokens)
 
     def graphed(self, tokens, pad_args, what: str = 'forward', clone: bool = True):
         """`getattr(self, what)(tokens, pad_args)` replayed from a hipGraph captured on first use of this

@@ -263,6 +263,13 @@ int esme_hip_attn_varlen_fwd_qkpair_f16(const void* q, const void* k, const void
                                         void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
                                         int H, int d, int max_len, float softmax_scale, const int32_t* seq_order,
                                         void* stream);
+/* The same with per-call options (ABI 9): seq_order as esme_hip_attn_varlen_fwd_opts; variant 0 / 1 = the first-generation three-pass kernel (one launch of
+ * attn_split_kernel<D, F16, QKP>), 2 = the key-axis-pipelined kernel for head dims 64 / 32 (round 6: one 32-row query block per wave, softmax of
+ * key tile t under the MFMAs of P(t-1) V(t-1) and K(t+1) Q^T; exact row maxima) -- same results to the last rounding of P; measured no faster
+ * (DESIGN.md section 9), kept as a second implementation. */
+int esme_hip_attn_varlen_fwd_qkpair_f16_opts(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t lo_qk, void* o,
+                                             int64_t ld_o, const int32_t* cu_lens, int B, int64_t T, int H, int d,
+                                             int max_len, float softmax_scale, const esme_attn_opts_t* opts, void* stream);
 
 /* esme_hip_embed_positions with an fp32 result (contiguous (T, E)): token row + learned-position row summed exactly -- the embedding of
  * ESM-1b / ESM-1v in the reference's fp32 forward (esme/esm.py:634-652,694-711). */

@@ -1,0 +1,130 @@
+"""attn_sb_kernel (round 6): ONE 32-row query block per wave, pipelined along the key axis (softmax of key tile t under the MFMAs of P(t-1) V(t-1)
+and K(t+1) Q^T), online softmax with a deferred rescale of O^T, ring of three K / V slots.  Built as the software-pipelined
+three-pass kernel VERDICT r5 asked for (the q/k-pair entry of precision 'half', head dims 64 / 32) -- measured no faster than the first-generation
+kernel (profiles/r06_attn_sb_bench.txt), so it stays behind esme_attn_opts_t.variant = 2 there and as a second implementation of the plain forms -- checked here against the float64 definition, against the ping-pong kernel
+(the speculative / pre-scaled passes run the same arithmetic in the same order: bit-equal) and on the edge lengths of the other attention tests."""
+import pytest
+import torch
+
+from oracle import esm_oracle as O
+from esme import _hip
+from esme import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+H16 = torch.float16
+LOG2E = 1.4426950408889634
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def ref64(q, k, v, cu, H, d, scale=None):
+    T = q.shape[0]
+    return O.varlen_attention(q.double().view(T, H, d), k.double().view(T, H, d), v.double().view(T, H, d), cu, scale).reshape(T, H * d) \
+        if scale is not None else O.varlen_attention(q.double().view(T, H, d), k.double().view(T, H, d), v.double().view(T, H, d), cu).reshape(T, H * d)
+
+
+EDGE = [1, 7, 64, 65, 130, 300, 517, 31, 128, 129]
+
+
+@pytest.mark.parametrize('d,H', [(64, 5), (32, 6)])
+@pytest.mark.parametrize('form', ['bf16', 'qp', 'f16'])
+def test_single_block_kernel_plain_forms(d, H, form):
+    lengths = EDGE + [1100]
+    E, T = H * d, sum(lengths)
+    g = torch.Generator().manual_seed(7 * d + len(form))
+    dt = H16 if form == 'f16' else torch.bfloat16
+    q, k, v = (torch.randn(T, E, generator=g) * s for s in (1.5, 1.5, 1.0))
+    if form == 'qp':
+        q = q * (d ** -0.5 * LOG2E)
+    qkv = torch.cat((q, k, v), dim=1).to(dt).to(DEV)
+    cu = syn.cu_lens_of(lengths)
+    args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
+    kw = dict(q_prescaled=(form == 'qp'))
+    base = _hip.attn_varlen(*args, **kw)
+    with _hip.attn_options(variant=2):
+        out = torch.full((T, E), 9.0, dtype=dt, device=DEV)
+        _hip.attn_varlen(*args, out=out, **kw)
+        out2 = _hip.attn_varlen(*args, order=_hip.seq_order(cu.to(DEV)), **kw)
+    qd = qkv[:, :E].double().cpu()
+    if form == 'qp':
+        qd = qd / (d ** -0.5 * LOG2E)
+    ref = ref64(qd, qkv[:, E:2 * E].double().cpu(), qkv[:, 2 * E:].double().cpu(), cu, H, d)
+    e_sb, e_pp = rel(out.float().cpu(), ref), rel(base.float().cpu(), ref)
+    print(f'\n[attn_sb] d={d} {form}: single-block {e_sb:.2e}, ping-pong {e_pp:.2e}, bit-equal {bool(torch.equal(out, base))}')
+    assert torch.isfinite(out.float()).all() and torch.equal(out, out2)
+    assert e_sb <= (8e-4 if form == 'f16' else 4e-3) and e_sb <= 1.1 * e_pp + 1e-5
+    assert torch.equal(out, base)              # speculative / pre-scaled passes: the same arithmetic in the same order as the ping-pong kernel
+
+
+@pytest.mark.parametrize('d,H', [(64, 4), (32, 4)])
+def test_single_block_kernel_exact_maxima_and_redo(d, H):
+    """Exact row maxima on every tile (the high-precision entry: thr = 0, no speculation) exercises the DEFERRED rescale of O^T -- scores that keep
+    growing along the key axis raise the maximum in every tile; and a key that beats the first tile's maximum by thousands of log2 units makes the
+    speculative pass overflow, which must be redone exactly (bf16) / is caught by the fp16 bound (f16)."""
+    lengths = [700, 130, 65]
+    E, T = H * d, sum(lengths)
+    g = torch.Generator().manual_seed(d)
+    q = torch.randn(T, E, generator=g)
+    k = torch.randn(T, E, generator=g)
+    v = torch.randn(T, E, generator=g)
+    cu = syn.cu_lens_of(lengths)
+    # keys grow along the sequence: every tile brings a new maximum for most rows
+    ramp = torch.cat([torch.linspace(0.5, 3.0, n) for n in lengths]).unsqueeze(1)
+    k = k * ramp
+    for dt, tol in ((torch.bfloat16, 6e-3), (H16, 1e-3)):
+        qkv = torch.cat((q, k, v), dim=1).to(dt).to(DEV)
+        args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
+        ref = ref64(qkv[:, :E].cpu(), qkv[:, E:2 * E].cpu(), qkv[:, 2 * E:].cpu(), cu, H, d)
+        with _hip.attn_options(variant=2):
+            ex = _hip.attn_varlen(*args, exact=True)
+            sp = _hip.attn_varlen(*args)
+        e_ex, e_sp = rel(ex.float().cpu(), ref), rel(sp.float().cpu(), ref)
+        print(f'\n[attn_sb] d={d} {dt}: exact maxima {e_ex:.2e}, speculative {e_sp:.2e}')
+        assert e_ex <= tol and e_sp <= tol
+    # one key far above the first tile's maximum (bf16: P overflows fp32 -> the work item is redone with the classic online softmax)
+    qb = torch.randn(T, E, generator=g) * 0.5
+    kb = torch.randn(T, E, generator=g) * 0.5
+    kb[300] = 0
+    kb[300, :d] = 60.0
+    qb[:, :d] = qb[:, :d].abs() + 20.0                      # head 0: every query of sequence 0 scores ~ +1200 * d^-1/2 * ... on key 300
+    qkv = torch.cat((qb, kb, v), dim=1).to(torch.bfloat16).to(DEV)
+    args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
+    ref = ref64(qkv[:, :E].cpu(), qkv[:, E:2 * E].cpu(), qkv[:, 2 * E:].cpu(), cu, H, d)
+    with _hip.attn_options(variant=2):
+        sp = _hip.attn_varlen(*args)
+        ex = _hip.attn_varlen(*args, exact=True)
+    assert torch.isfinite(sp.float()).all() and rel(sp.float().cpu(), ref) <= 6e-3 and rel(ex.float().cpu(), ref) <= 6e-3
+    assert rel(sp.float()[:lengths[0], :d].cpu(), ref[:lengths[0], :d]) <= 6e-3          # the overflowing head itself (redone with the defer-max threshold)
+
+
+@pytest.mark.parametrize('d,H', [(64, 5), (32, 6)])
+def test_qk_pair_entry_new_kernel_vs_first_generation(d, H):
+    """The q/k-pair entry (three score passes, fp16 P / V / O, exact maxima): pipelined kernel vs the first-generation one on large scores and edge
+    lengths -- both against float64 on the same pairs, and close to each other (same passes; O^T rescaled at a different point)."""
+    lengths = EDGE + [900]
+    E, T = H * d, sum(lengths)
+    g = torch.Generator().manual_seed(3 * d)
+    base_q, base_k = torch.randn(1, H, d, generator=g) * 5, torch.randn(1, H, d, generator=g) * 5
+    q = (base_q + 0.4 * torch.randn(T, H, d, generator=g)).reshape(T, E)
+    k = (base_k + 0.4 * torch.randn(T, H, d, generator=g)).reshape(T, E)
+    v = torch.randn(T, E, generator=g)
+    qkv = torch.zeros(T, 5 * E, dtype=H16, device=DEV)
+    qh, kh = q.to(H16), k.to(H16)
+    qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:3 * E] = qh.to(DEV), kh.to(DEV), v.to(H16).to(DEV)
+    qkv[:, 3 * E:4 * E], qkv[:, 4 * E:] = (q - qh.float()).to(H16).to(DEV), (k - kh.float()).to(H16).to(DEV)
+    cu = syn.cu_lens_of(lengths)
+    new = torch.full((T, E), 9.0, dtype=H16, device=DEV)
+    with _hip.attn_options(variant=2):
+        _hip.attn_varlen_qkpair(qkv, cu.to(DEV), max(lengths), H, d, d ** -0.5, out=new)
+        new2 = _hip.attn_varlen_qkpair(qkv, cu.to(DEV), max(lengths), H, d, d ** -0.5, order=_hip.seq_order(cu.to(DEV)))
+    old = _hip.attn_varlen_qkpair(qkv, cu.to(DEV), max(lengths), H, d, d ** -0.5)
+    qd = qkv[:, :E].double().cpu() + qkv[:, 3 * E:4 * E].double().cpu()
+    kd = qkv[:, E:2 * E].double().cpu() + qkv[:, 4 * E:].double().cpu()
+    ref = ref64(qd, kd, qkv[:, 2 * E:3 * E].double().cpu(), cu, H, d)
+    e_new, e_old = rel(new.float().cpu(), ref), rel(old.float().cpu(), ref)
+    print(f'\n[attn_sb] q/k pairs d={d}: pipelined {e_new:.2e}, first-generation {e_old:.2e}, max |new - old| {float((new.float() - old.float()).abs().max()):.2e}')
+    assert torch.isfinite(new.float()).all() and torch.equal(new, new2)
+    assert e_new <= 6e-4 and e_new <= 1.25 * e_old + 1e-5

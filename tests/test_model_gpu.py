@@ -140,6 +140,19 @@ def test_api_errors():
     from esme import ESM
     with pytest.raises(ValueError):
         ESM.from_pretrained('not_a_model_name')
+    # a token id outside the embedding table: the reference's nn.Embedding raises (esme/esm.py:176-199); the HIP lookup writes a zero row on the hot path,
+    # check_tokens() / debug_checks / predict_* in precision 'half' raise
+    bad = torch.tensor([0, 5, 77, 2], dtype=torch.int64, device=DEV)
+    pad = (torch.tensor([0, 4], dtype=torch.int32, device=DEV), 4)
+    with pytest.raises(IndexError):
+        model.check_tokens(bad)
+    model.debug_checks = True
+    with pytest.raises(IndexError):
+        model(bad, pad)
+    model.debug_checks = False
+    with pytest.raises(IndexError):
+        model.set_precision('half').predict_log_prob(bad, pad)
+    model.set_precision('fast').check_tokens(t1)
 
 
 def test_sequence_independence_end_to_end():
