@@ -55,6 +55,9 @@ def parse():
     ap.add_argument('--model', default='esm2_650m')
     ap.add_argument('--tokens', type=int, default=50000)
     ap.add_argument('--seq-len', type=int, default=500)
+    ap.add_argument('--layers', type=int, default=0,
+                    help='run only the first N layers of --model (e.g. a 15B-width model whose 48 layers do not fit the synthesis time budget); the metric label '
+                         'and config say so: never the headline')
     ap.add_argument('--batch', choices=['uniform', 'proteome'], default='uniform')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-tokens', type=int, default=4000)
@@ -93,7 +96,7 @@ def pmc_traffic(suffix=''):
     profiles/rNN_traffic.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE).  Counters cannot be read
     from inside the process, so this is the last PROFILED value -- a static file, not an observation of this run -- valid
     for the default workload only; (None, None) otherwise."""
-    for name in ((f'r05_traffic{suffix}.json',) if suffix else ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json')):
+    for name in ((f'r06_traffic{suffix}.json', f'r05_traffic{suffix}.json') if suffix else ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json')):
         path = os.path.join(ROOT, 'profiles', name)
         try:
             with open(path) as f:
@@ -359,6 +362,9 @@ def main():
     from esme import ESM, _hip, synthetic as syn
     _hip.load()
     kind, L, E, H = syn.MODEL_ZOO[args.model]
+    full_L = L
+    if args.layers:
+        L = min(L, args.layers)
 
     # ---- synthetic checkpoint in the reference layout -> from_pretrained
     weights = syn.synthetic_state_dict(kind, L, E, seed=0)
@@ -427,7 +433,7 @@ def main():
     flops_step = syn.algorithmic_flops(kind, L, E, lengths)
 
     result = {
-        'metric': metric_label(args.model, T, args.batch),
+        'metric': metric_label(args.model, T, args.batch) + (f' [first {L} of {full_L} layers only]' if L != full_L else ''),
         'value': round(value, 1), 'unit': 'residues/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if args.precision == 'half' else 'bf16', 'data': 'synthetic',
