@@ -213,7 +213,8 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
             if (rot_fused && m->half_qk_sumsq) fu.qk_sumsq = m->half_qk_sumsq + (int64_t)i * 2 * H;          // plan guard: this layer's q / k row norms
             ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
             if (m->qk_norm) {
-                ESME_TRY(esme_hip_qk_norm_rotary_f16(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
+                ESME_TRY(esme_hip_qk_norm_rotary_f16_guarded(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len,
+                                                             m->half_qk_sumsq ? m->half_qk_sumsq + (int64_t)i * 2 * H : nullptr, stream));
             } else if (m->rotary && !rot_fused) {
                 ESME_TRY(esme_hip_rotary_varlen_f16(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
             }

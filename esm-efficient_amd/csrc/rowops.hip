@@ -562,9 +562,12 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
                                                              const u16* __restrict__ bq, const u16* __restrict__ bk,
                                                              float eps, const u16* __restrict__ cosT,
                                                              const u16* __restrict__ sinT, const int32_t* __restrict__ pos,
-                                                             int64_t T, int E, int d, int max_len, float q_scale) {
+                                                             int64_t T, int E, int d, int max_len, float q_scale, unsigned int* __restrict__ qk_sumsq) {
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;                     // waves 0, 1: q; 2, 3: k
+    float gmax[NCH];                                     // plan guard (F16, qk_sumsq != NULL): running max over this wave's rows of the squared row norm of the head this lane sits in, per chunk
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) gmax[c] = 0.f;
     const bool is_k = wv >= 2;
     const int64_t row0 = ((int64_t)blockIdx.x * 2 + (wv & 1)) * RPW;
     if (row0 >= T) return;
@@ -682,6 +685,18 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
                 float r[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = fmaf(a[j], cs[j], __fmul_rn(o2[j], sn[j]));
+                if constexpr (F16) {
+                    if (qk_sumsq) {                           // (wave-uniform) |r|^2 over the head: the rotation preserves it; lanes of a head are neighbours
+                        float ss = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ss = fmaf(r[j], r[j], ss);
+                        if (d >= 16) ss += dpp_f32<0xB1>(ss);
+                        if (d >= 32) ss += dpp_f32<0x4E>(ss);
+                        if (d >= 64) ss += dpp_f32<0x141>(ss);
+                        if (d >= 128) ss += dpp_f32<0x128>(ss);
+                        gmax[c] = fmaxf(gmax[c], ss);
+                    }
+                }
                 if (!is_k && q_scale != 1.0f) {              // softmax_scale * log2(e) folded into q (fp32, before the rounding): attention's q_prescaled
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r[j] *= q_scale;
@@ -692,6 +707,20 @@ __global__ __launch_bounds__(256) void qk_norm_rotary_kernel(u16* __restrict__ q
 #pragma unroll
         for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
         craw = cnxt; sraw = snxt;
+    }
+    if constexpr (F16) {
+        if (qk_sumsq) {                                       // one filtered atomic per head and wave (esme_gemm_fusion_t.qk_sumsq's layout: [q | k][head])
+            const int lph = d >> 3;                           // lanes per head
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int e0 = (c * 64 + lane) * 8;
+                if (e0 < E && (lane % lph) == 0) {
+                    unsigned int* slot = qk_sumsq + (is_k ? E / d : 0) + e0 / d;
+                    const unsigned int b = __float_as_uint(gmax[c]);
+                    if (b > *slot) atomicMax(slot, b);
+                }
+            }
+        }
     }
 }
 
@@ -1105,7 +1134,7 @@ extern "C" int esme_hip_segment_mean(const void* x, int64_t ldx, const int32_t* 
 static int qk_norm_rotary_impl(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
                                const void* bk, float eps, const void* cosT, const void* sinT,
                                const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, float q_scale,
-                               bool f16, void* stream) {
+                               bool f16, void* stream, uint32_t* qk_sumsq = nullptr) {
     ESME_CHECK_ARG(T >= 0 && heads > 0 && head_dim > 0 && max_len > 0, "qk_norm_rotary: bad sizes");
     if (T == 0) return ESME_OK;
     ESME_CHECK_ARG(q && k && wq && wk && cosT && sinT && pos, "qk_norm_rotary: null pointer");
@@ -1125,9 +1154,9 @@ static int qk_norm_rotary_impl(void* q, void* k, int64_t ld, const void* wq, con
     const hipStream_t s = (hipStream_t)stream;
 #define ESME_QKN(N)                                                                                                 \
     do { if (f16) hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW, true>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
-                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale); \
+                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale, qk_sumsq); \
     else hipLaunchKernelGGL((qk_norm_rotary_kernel<N, RPW>), grid, block, 0, s, (u16*)q, (u16*)k, ld, (const u16*)wq, (const u16*)wk, \
-                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale); } while (0)
+                       (const u16*)bq, (const u16*)bk, eps, (const u16*)cosT, (const u16*)sinT, pos, T, E, head_dim, max_len, q_scale, (unsigned int*)nullptr); } while (0)
     if (E <= 512) ESME_QKN(1);
     else if (E <= 1024) ESME_QKN(2);
     else if (E <= 1536) ESME_QKN(3);
@@ -1148,6 +1177,13 @@ extern "C" int esme_hip_qk_norm_rotary_f16(void* q, void* k, int64_t ld, const v
                                            const void* bk, float eps, const void* cosT, const void* sinT,
                                            const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, void* stream) {
     return qk_norm_rotary_impl(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, 1.0f, true, stream);
+}
+
+extern "C" int esme_hip_qk_norm_rotary_f16_guarded(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                                   const void* bk, float eps, const void* cosT, const void* sinT,
+                                                   const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, uint32_t* qk_sumsq, void* stream) {
+    ESME_CHECK_ARG(!qk_sumsq || (reinterpret_cast<uintptr_t>(qk_sumsq) & 3u) == 0, "qk_norm_rotary: misaligned qk_sumsq");
+    return qk_norm_rotary_impl(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, 1.0f, true, stream, qk_sumsq);
 }
 
 extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,

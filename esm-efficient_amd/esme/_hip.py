@@ -91,6 +91,8 @@ SIGNATURES = {
                                                c_int64, c_int, c_int, c_int, c_float, c_void_p]),
     'esme_hip_qk_norm_rotary_f16': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'esme_hip_qk_norm_rotary_f16_guarded': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                            c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'esme_hip_pair_to_f32': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand_guarded': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_int,
@@ -438,7 +440,8 @@ def rotary_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
 
 
 def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, bq, bk, eps: float,
-                    cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, heads: int, q_scale: float = 1.0) -> None:
+                    cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, heads: int, q_scale: float = 1.0,
+                    qk_sumsq: Optional[torch.Tensor] = None) -> None:
     """In place on the (T, H*d) views q and k: LayerNorm over H*d (weights wq / wk, optional biases), bf16
     rounding, rotary -- one pass instead of three (ESM-C's q/k normalisation).  `q_scale` != 1: q leaves multiplied by it
     (softmax_scale * log2(e) folded into q for attn_varlen(q_prescaled=True)).  float16 q / k / tables: precision 'half'."""
@@ -452,12 +455,15 @@ def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torc
         if q_scale != 1.0:
             raise ValueError('qk_norm_rotary: q_scale is not available for float16 operands')
         with _Traced('qk_norm_rotary', (T, E)):
-            _check(load().esme_hip_qk_norm_rotary_f16(
+            if qk_sumsq is not None and (qk_sumsq.numel() != 2 * heads or not qk_sumsq.is_contiguous()):
+                raise ValueError('qk_norm_rotary: qk_sumsq is a contiguous int32 (2, heads) buffer')
+            _check(load().esme_hip_qk_norm_rotary_f16_guarded(
                 qp, kp, ld, _dev(wq, 'wq', torch.bfloat16), _dev(wk, 'wk', torch.bfloat16),
                 _dev(bq, 'bq', torch.bfloat16) if bq is not None else None,
                 _dev(bk, 'bk', torch.bfloat16) if bk is not None else None, float(eps),
                 _dev(cos, 'cos', torch.float16), _dev(sin, 'sin', torch.float16), _dev(pos, 'pos', torch.int32),
-                T, heads, E // heads, cos.shape[0], _stream()), 'esme_hip_qk_norm_rotary_f16')
+                T, heads, E // heads, cos.shape[0], _dev(qk_sumsq, 'qk_sumsq', torch.int32) if qk_sumsq is not None else None, _stream()),
+                'esme_hip_qk_norm_rotary_f16_guarded')
         return
     with _Traced('qk_norm_rotary', (T, E)):
         _check(load().esme_hip_qk_norm_rotary_scaled(

@@ -143,9 +143,12 @@ class HalfPlan:
       info      the measurements the decision was taken from (reported by tools / bench).
       ext_key   the channel list as a host tuple: what derived weight copies are keyed on (a device address can be reused by the caching
                 allocator after a recalibration: ADVICE r5)."""
-    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info', 'ext_key')
+    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info', 'ext_key', 'site_ref')
 
-    def __init__(self, ext_sel=None, qk_pair=False, info=None, qk_layers=None):
+    def __init__(self, ext_sel=None, qk_pair=False, info=None, qk_layers=None, site_ref=None):
+        # site_ref: (2 L + 1,) device tensor, the median channel's largest |value| at every guard site as the CALIBRATION batch (1 024+ rows) saw it: the floor of
+        # the run-time guard's reference, so that a batch of a handful of rows (whose per-channel maxima scatter widely) is not mistaken for massive channels
+        self.site_ref = site_ref
         # qk_layers: per-layer flags (the pair form is paid only where a layer's own score bound asks for it); None = every layer
         self.qk_layers = None if qk_layers is None else tuple(bool(f) for f in qk_layers)
         self.ext_sel, self.info = ext_sel, dict(info or {})
@@ -476,7 +479,8 @@ class FlashMultiheadAttention(nn.Module):
             # ESM-C: q/k LayerNorm over the full width + rotary in ONE in-place pass over q and k (+ the softmax scale on q)
             _hip.qk_norm_rotary_(qkv[:, :E], qkv[:, E:2 * E], self.layernorm_q.weight, self.layernorm_k.weight,
                                  self.layernorm_q.bias, self.layernorm_k.bias, self.layernorm_q.eps,
-                                 ctx.cos, ctx.sin, ctx.pos, H, q_scale=_q_scale(self.head_dim) if qp else 1.0)
+                                 ctx.cos, ctx.sin, ctx.pos, H, q_scale=_q_scale(self.head_dim) if qp else 1.0,
+                                 qk_sumsq=guard.qk[self.layer_index] if guard is not None else None)
             q, k, v = (qkv[:, i * E:(i + 1) * E].view(T, H, d) for i in range(3))
         else:
             q, k, v = self._split_qkv(qkv)                  # ESM-C: q/k LayerNorm in place

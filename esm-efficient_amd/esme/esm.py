@@ -264,12 +264,16 @@ class ESM2(nn.Module):
             rows.append(self.layers[i + 1].self_attn.stream_scale()[0] if i + 1 < L else torch.ones(self.phys_dim, dtype=torch.float32, device=device))
         return torch.stack([r.to(device) for r in rows])
 
-    def _guard_measure(self, guard, device):
+    def _guard_measure(self, guard, device, site_ref=None):
         """(channel ratio (E,), score bound per layer (L,), covered (L,) bool) from a HalfGuard's device maxima -- device tensors, no sync.
-        ratio[c] = max over the sites of  max_t |x[t, c]| / median_c' max_t |x[t, c']|  (0 where a site saw nothing)."""
+        ratio[c] = max over the sites of  max_t |x[t, c]| / median_c' max_t |x[t, c']|  (0 where a site saw nothing).  `site_ref`: the calibration's
+        medians, a floor for the reference (a batch of a few rows has widely scattered per-channel maxima: 1 row of N(0, 1) values reaches 6.4 x its median)."""
         E = self.embed_dim
         x = guard.col.view(torch.float32)[:, :E] / self._guard_scales(device)[:, :E]
         med = x.median(dim=1).values
+        self._last_site_median = med
+        if site_ref is not None:
+            med = torch.where(med > 0, torch.maximum(med, site_ref.to(device)), med)
         ratio = torch.where(med[:, None] > 0, x / med[:, None].clamp_min(1e-30), torch.zeros_like(x)).amax(dim=0)
         qk = guard.qk.view(torch.float32)
         att = self.layers[0].self_attn
@@ -325,7 +329,7 @@ class ESM2(nn.Module):
                 'max_channel_ratio': float(ratio.max()), 'max_unselected_channel_ratio': float(others.max()), 'score_bound': bound,
                 'massive_channels': n_mass, 'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0,
                 'score_guard_layers': int(covered.sum()), 'score_bounds': [round(b, 2) for b in bounds]}
-        return HalfPlan(sel, qk_pair, info, qk_layers=flags)
+        return HalfPlan(sel, qk_pair, info, qk_layers=flags, site_ref=self._last_site_median.clone())
 
     # -- the plan checked against the data (round 6) -----------------------------------------------------------------------
     def _guard_buffers(self, device):
@@ -361,7 +365,7 @@ class ESM2(nn.Module):
             g.clear()
             return None                                           # (robust=False: the caller asked for the plain form; nothing to hold it to)
         dev = g.col.device
-        ratio, bound, covered = self._guard_measure(g, dev)
+        ratio, bound, covered = self._guard_measure(g, dev, plan.site_ref)
         sel_mask, flags = self._plan_masks(plan, dev)
         bad_c = (ratio > self.HALF_CHANNEL_RATIO) & ~sel_mask
         bad_l = (bound >= self.HALF_SCORE_BOUND) & ~flags & covered
@@ -408,7 +412,7 @@ class ESM2(nn.Module):
             info['updates'] = info.get('updates', 0) + 1
             info['massive_channels'] = int(cand.numel())
             info['qk_pair_layers'] = sum(new_flags) if pair_ok else 0
-            self._half_plan = HalfPlan(sel, pair_ok and any(new_flags), info, qk_layers=new_flags if pair_ok else None)
+            self._half_plan = HalfPlan(sel, pair_ok and any(new_flags), info, qk_layers=new_flags if pair_ok else None, site_ref=plan.site_ref)
             self.invalidate_graphs()
             verdict['updated'] = True
             msg += " The plan was widened (" + self._half_plan.describe() + "): re-run the batch."
@@ -430,7 +434,7 @@ class ESM2(nn.Module):
         offending layers get q / k pairs where the block has that form), so that the NEXT forward is covered -- re-run the batch that tripped it
         (predict_log_prob / predict_prob do that themselves).  A RuntimeWarning accompanies every stale verdict.  Coverage: the channel check runs
         in every residual epilogue of every model; the score check in the LayerNorm-folded projections with fused rotary (ESM-2 family, head
-        dims 16 / 32 / 64) -- ESM-C (q / k LayerNorm), ESM-1b / 1v (no rotary) and head dim 128 rely on the calibration for it."""
+        dims 16 / 32 / 64) and in ESM-C's q / k LayerNorm + rotary pass -- ESM-1b / 1v (no rotary) and head dim 128 rely on the calibration for it."""
         vec = self._guard_snapshot()
         if vec is None:
             return None

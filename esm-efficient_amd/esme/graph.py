@@ -48,6 +48,11 @@ def external_tensors(model):
     plan = getattr(model, '_half_plan', None)             # precision 'half': the massive-channel list the extension K-tile kernels read
     if plan is not None and getattr(plan, 'ext_sel', None) is not None:
         keep.append(plan.ext_sel)
+    guard = getattr(model, '_half_guard', None)           # ... and the plan guard's device maxima / the range flag the captured kernels write
+    if guard is not None:
+        keep += [guard.col, guard.qk]
+    if getattr(model, '_half_ovf', None) is not None:
+        keep.append(model._half_ovf)
     return keep
 
 
@@ -70,6 +75,9 @@ class GraphedForward:
                 self.fn(self.tokens, (self.cu_lens, self.max_len))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        guard = getattr(self.model, '_half_guard', None)
+        if guard is not None:
+            guard.clear()               # the warm-up forwards ran on placeholder tokens (all id 0): not data the plan should be held to
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             self.out = self.fn(self.tokens, (self.cu_lens, self.max_len))

@@ -161,6 +161,13 @@ int esme_hip_qk_norm_rotary_f16(void* q, void* k, int64_t ld, const void* wq, co
                                 const void* bq, const void* bk, float eps, const void* cos,
                                 const void* sin, const int32_t* pos, int64_t T, int H, int d,
                                 int max_len, void* stream);
+/* The same with the plan guard of precision 'half' (ABI 9): qk_sumsq (uint32 (2, H), device; NULL = off) as esme_gemm_fusion_t.qk_sumsq -- the float bit
+ * patterns of max over rows of the squared row norm of q (then k) per head, after the LayerNorm (the rotation preserves it).  ESM-C's scores are bounded
+ * by its q / k LayerNorm gains, but how a row's energy spreads over the heads is data (reference esme/attention.py:104-105). */
+int esme_hip_qk_norm_rotary_f16_guarded(void* q, void* k, int64_t ld, const void* wq, const void* wk,
+                                        const void* bq, const void* bk, float eps, const void* cos,
+                                        const void* sin, const int32_t* pos, int64_t T, int H, int d,
+                                        int max_len, uint32_t* qk_sumsq, void* stream);
 
 /* Varlen (block-diagonal) multi-head self-attention, non-causal, no dropout:
  * per sequence i and head h, O = softmax(Q K^T * softmax_scale) V over that sequence's
@@ -575,7 +582,8 @@ typedef struct esme_model_desc {
      *   half_col_absmax  uint32 (2 * n_layers + 1, phys_dim): row 0 = the stream at the start (scaled for layer 0's attention LayerNorm: ps_attn),
      *       row 1 + 2 i = after layer i's attention branch (scaled for its FFN LayerNorm: ps_ffn), row 2 + 2 i = after its FFN branch (scaled for
      *       layer i + 1's attention LayerNorm; the last row unscaled);
-     *   half_qk_sumsq    uint32 (n_layers, 2, heads): layers whose q / k are NOT pairs and whose rotary is fused into the projection. */
+     *   half_qk_sumsq    uint32 (n_layers, 2, heads): layers whose q / k are NOT pairs and whose rotary is fused into the projection, or (ESM-C) whose q / k
+     *       pass is esme_hip_qk_norm_rotary_f16_guarded. */
     uint32_t* half_col_absmax; uint32_t* half_qk_sumsq;
 } esme_model_desc_t;
 

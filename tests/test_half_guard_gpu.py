@@ -113,6 +113,33 @@ def test_projection_epilogue_qk_row_norms(d, H, M, tile):
     assert float(as_f32(qk)[0, 1]) > 8 * float(as_f32(qk)[0, 0])
 
 
+@pytest.mark.parametrize('d,H,T', [(64, 18, 700), (64, 15, 333), (32, 8, 1000), (128, 4, 130)])
+def test_qk_norm_rotary_pass_row_norms(d, H, T):
+    """ESM-C's q / k LayerNorm + rotary pass keeps the same guard (esme_hip_qk_norm_rotary_f16_guarded): squared row norm per head of what it stores, and the
+    stored values are bit-identical with and without it."""
+    from esme.rotary import RotaryEmbedding
+    E = H * d
+    g = torch.Generator().manual_seed(T + d)
+    qkv = (torch.randn(T, 3 * E, generator=g) * 2).to(H16)
+    qkv[T // 2, d:2 * d] *= 30.0                      # one row whose energy sits in head 1 of q
+    wq, wk = ((1 + 0.1 * torch.randn(E, generator=g)).to(torch.bfloat16).to(DEV) for _ in range(2))
+    lengths = [T - T // 3, T // 3]
+    pos, _ = _hip.seq_positions(syn.cu_lens_of(lengths).to(DEV), T)
+    cos, sin = RotaryEmbedding(dim=d).tables(max(lengths), DEV, H16)
+    outs = []
+    qk = torch.zeros(2, H, dtype=torch.int32, device=DEV)
+    for guard in (None, qk):
+        buf = qkv.clone().to(DEV)
+        _hip.qk_norm_rotary_(buf[:, :E], buf[:, E:2 * E], wq, wk, None, None, 1e-5, cos, sin, pos, H, qk_sumsq=guard)
+        outs.append(buf)
+    assert torch.equal(outs[0], outs[1])
+    for which in (0, 1):
+        blk = outs[1][:, which * E:(which + 1) * E].float().reshape(T, H, d)
+        want = blk.pow(2).sum(dim=-1).amax(dim=0)
+        assert torch.allclose(as_f32(qk)[which], want, rtol=2e-3, atol=0), (which, as_f32(qk)[which], want)      # (the kernel sums the fp32 values it then rounds to fp16)
+    assert float(as_f32(qk)[0, 1]) > 2 * float(as_f32(qk)[0, 0])
+
+
 def token_outlier_model(kind, L, E, H, scale, token_ids, gain_scale=10.0, vocab='all'):
     w, cols = syn.token_outlier_state_dict(kind, L, E, scale, token_ids, seed=2, gain_scale=gain_scale)
     model = build(kind, L, E, H, seed=2)
@@ -237,6 +264,41 @@ def test_guard_c_entry_equals_module_path_and_is_silent_on_benign_models():
     # the kernels' score figure is the torch-side bound of the calibration (same quantity, measured by the epilogue)
     info = model.half_plan().info
     assert info['score_guard_layers'] == 4 and info['max_unselected_channel_ratio'] <= model.HALF_CHANNEL_RATIO
+    # ESM-C: the q / k pass carries the score guard; same maxima through the C entry and the modules
+    mc = build('esmc', 3, 768, 12, seed=5).to(DEV)
+    mc.set_precision('half')
+    assert mc.half_plan().info['score_guard_layers'] == 3
+    lengths = [100, 37, 260]
+    tokens, cu = sprinkled(lengths, [3, 24, 32], 0.1)
+    args = (tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    y1 = mc(*args)
+    qk1, col1 = mc._half_guard.qk.clone(), mc._half_guard.col.clone()
+    mc._half_guard.clear()
+    mc.c_forward = False
+    y2 = mc(*args)
+    mc.c_forward = True
+    assert torch.equal(y1, y2) and bool(qk1.any()) and torch.equal(mc._half_guard.qk, qk1) and torch.equal(mc._half_guard.col, col1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert mc.check_plan() is None
+
+
+def test_guard_is_silent_on_tiny_batches_and_graph_warmups():
+    """A batch of a handful of rows has widely scattered per-channel maxima (one row of N(0, 1) values reaches 6.4 x its median): the guard's reference is
+    floored by the calibration's medians, so tiny batches -- and the placeholder batch a hipGraph capture warms up on -- do not widen the plan."""
+    model = build('esm2', 3, 640, 20, seed=4).to(DEV)
+    model.set_precision('half')
+    plan = model.half_plan()
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        for lengths in ([3], [1], [2, 5], [7]):
+            tokens, cu = syn.random_tokens(lengths, seed=sum(lengths)), syn.cu_lens_of(lengths)
+            model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+        lengths = [40, 25]
+        tokens, cu = syn.random_tokens(lengths, seed=9), syn.cu_lens_of(lengths)
+        a = model.graphed(tokens.to(DEV), (cu.to(DEV), max(lengths)), 'predict_log_prob')
+        b = model.predict_log_prob(tokens.to(DEV), (cu.to(DEV), max(lengths)))
+    assert model.half_plan() is plan and torch.equal(a, b)
 
 
 def test_esmc_mask_rows_through_predict_mask_margin():
