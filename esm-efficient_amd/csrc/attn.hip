@@ -1131,12 +1131,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         // key-split tile: block 1's partial result (odd key tiles; none when the sequence has one tile) joins block 0's -- same rows, same lanes.  With a
         // reference maximum per block (first even / first odd tile) the two are brought to the larger one first.
         float a0 = 1.f, a1 = nt > 1 ? 1.f : 0.f;
-        if constexpr (!QP) {
-            if (nt > 1) {
-                const float mn = fmaxf(mc[0], mc[1]);
-                a0 = __builtin_amdgcn_exp2f(mc[0] - mn);
-                a1 = __builtin_amdgcn_exp2f(mc[1] - mn);
-            }
+        if (nt > 1) {                                  // (the pre-scaled form has no reference in its speculative pass -- both stay at their initial value: a0 = a1 = 1 -- but its exact redo has)
+            const float mn = fmaxf(mc[0], mc[1]);
+            a0 = __builtin_amdgcn_exp2f(mc[0] - mn);
+            a1 = __builtin_amdgcn_exp2f(mc[1] - mn);
         }
         lrun[0] = lrun[0] * a0 + (nt > 1 ? lrun[1] * a1 : 0.f);
 #pragma unroll
