@@ -43,6 +43,7 @@ struct GemmArgs {
     int f16 = 0;                 // precision 'half': A, W, rotary tables and C are IEEE fp16 (esme_gemm_fusion_t.f16)
     const float* ps_in = nullptr; const float* ps_out = nullptr;   // pair stream stored scaled per column (esme_gemm_fusion_t.pair_scale_in / _out); nullptr = 1
     const int32_t* ext_sel = nullptr; int ext_n = 0; int64_t ext_off = 0;     // pair stream: lo of the selected columns also goes to C[m, ext_off + slot] (the extension K-tile)
+    int ext_base = 0;            // host side (column-split launches): column of the full problem that this launch's column 0 is (ext_sel holds full-problem columns)
     int* ovf = nullptr;          // LN fold: set to 1 when a row's statistics are not finite (precision 'half': a stream value left fp16's range)
     int pair_cols = 0;           // PAIR output: only columns < pair_cols get their lo half (0 = all)
     // plan guard of precision 'half' (esme_gemm_fusion_t.col_absmax / .qk_sumsq): running maxima the host compares with what the mode's calibration assumed

@@ -830,7 +830,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             // where the next LayerNorm-folded GEMM finds it as one more K-tile (A = [hi | lo_sel], W = [W' | W'_sel]: those channels then
             // enter the product at the pair's 22 bits).  Wave-uniform loop over the list; a wave whose 64 columns hold none skips it.
             for (int sidx = 0; sidx < a.ext_n; ++sidx) {
-                const int c = a.ext_sel[sidx] - nw0;
+                const int c = a.ext_sel[sidx] - a.ext_base - nw0;
                 if (c >= 0 && c < OUTC && lane < RPP) {
                     const int64_t m = mw0 + pass * RPP + lane;
                     const u16 lo = *reinterpret_cast<const u16*>(slab_lo + slab_off(lane, c & ~3) + (c & 3) * 2);
@@ -1449,6 +1449,37 @@ extern "C" int esme_hip_gemm_bf16_opts(const void* A, int64_t lda, const void* W
     }
     const int tile = pick_tile(M, N, opts);
     if (tile == 1) return launch_gemm<128, 128, 2, 2>(a, epilogue, rotd, lnf, stats, s);
+    // Column split of a residual GEMM whose width ends in a half-empty 256-column tile (round 6: ESMC-600M, N = 1 152 = 4.5 tiles -- a tenth of the launch's
+    // MFMAs multiply padding, and 126 x 5 = 630 tiles are 2.46 rounds of the 256 CUs where 126 x 4 = 504 are 1.97).  When dropping that column of tiles saves a
+    // whole round, the full tiles run as before and the last 128 columns go to the 128 x 128 configuration in a second launch on offset pointers.  Same bits:
+    // every output element sums its K-tiles in the same order in both configurations, and a 128-wide statistics partial (w0 + w1) is what the half-empty
+    // 256-wide tile emitted ((w0 + w1) + (0 + 0)).  Only with the heuristic tile choice (an explicit esme_gemm_opts_t.tile gets exactly that configuration).
+    // MEASURED (tools/gemm_colsplit_ab.py, profiles/r06_gemm_colsplit_ab.txt, M = 32 064): the round arithmetic does not hold on this power-capped part -- bf16
+    // out-projection 97.3 -> 98.1 us, FFN-down 207.2 -> 213.7 us (the "2.46 rounds" launch already costs 2.46, not 3, tile times); only the fp16 PAIR-stream
+    // epilogue, whose tile seam is the expensive one, gains (FFN-down 255.9 -> 244.1 us, out-projection 119.8 = 119.8): the split is taken there only.
+    if (epilogue == ESME_EPI_RESIDUAL && a.f16 && a.pair_off && !(opts && opts->tile) && N > 256 && N % 256 == 128 && vec_ok && !a.c32) {
+        const int64_t tm = (M + 255) / 256, ncu = cu_count() & ~7;
+        const int64_t full = tm * ((N + 255) / 256), main_tiles = tm * (N / 256);
+        if (ncu >= 8 && main_tiles >= 160 && (main_tiles + ncu - 1) / ncu < (full + ncu - 1) / ncu) {
+            const int c0 = N - 128;
+            GemmArgs a1 = a, a2 = a;
+            a1.N = c0;
+            const int rc1 = launch_gemm<256, 256, 2, 4>(a1, epilogue, rotd, lnf, stats, s);
+            if (rc1 != ESME_OK) return rc1;
+            a2.N = 128;
+            a2.W = a.W + (int64_t)c0 * (a.kt_wrap > 0 ? a.kt_wrap * BK : a.K);
+            if (a.bias) a2.bias = a.bias + c0;
+            if (a.resid) a2.resid = a.resid + c0;
+            a2.C = a.C + c0;
+            if (a.resid32) a2.resid32 = a.resid32 + c0;
+            if (a.ps_in) a2.ps_in = a.ps_in + c0;
+            if (a.ps_out) a2.ps_out = a.ps_out + c0;
+            if (a.col_absmax) a2.col_absmax = a.col_absmax + c0;
+            if (a.stats_out) a2.stats_out = a.stats_out + 2 * (int64_t)(c0 / 256) * a.stat_ld;
+            if (a.ext_off) { a2.ext_base = c0; a2.ext_off = a.ext_off - c0; }
+            return launch_gemm<128, 128, 2, 2>(a2, epilogue, rotd, lnf, stats, s);
+        }
+    }
     // 256 x 256 tiles run one workgroup per CU, so a launch takes ceil(tiles / CUs) rounds.  (Round 2 measured a "tail split"
     // -- the last, partly empty round as 128 x 128 tiles in a second launch -- 1 % SLOWER end to end on this power-capped
     // part; the code is gone.)
