@@ -137,6 +137,67 @@ def test_round5_entry_points_validate_without_gpu():
     assert b'half_ext_n' in lib.esme_hip_last_error()
 
 
+def test_round6_entry_points_validate_without_gpu():
+    """The round-6 entries (the plan guard of precision 'half', per-call options of the q/k-pair attention) reject bad arguments on the host, before any launch."""
+    from esme import _hip
+    lib = _hip.load()
+    # guarded stream operand: the column maxima belong to the pair form and must be 16-byte aligned
+    assert lib.esme_hip_stream_operand_guarded(16, 64, 16, 64, 0, 1, None, None, 0, 0, None, 16, 4, 64, None) == -1
+    assert b'col_absmax' in lib.esme_hip_last_error()
+    assert lib.esme_hip_stream_operand_guarded(16, 64, 16, 128, 64, 1, None, None, 0, 0, None, 20, 4, 64, None) == -1       # misaligned
+    # fused GEMM: col_absmax only on the fp16 pair stream's residual epilogue, qk_sumsq only on the fp16 LN-folded projection with fused rotary
+    fu = _hip.GemmFusion()
+    fu.col_absmax = 16
+    assert lib.esme_hip_gemm_bf16_fused(16, 64, 16, None, 16, 64, 16, 64, 8, 64, 64, 2, 1.0, ctypes.byref(fu), None) == -1
+    assert b'col_absmax' in lib.esme_hip_last_error()
+    fu = _hip.GemmFusion()
+    fu.qk_sumsq, fu.f16 = 16, 1
+    assert lib.esme_hip_gemm_bf16_fused(16, 64, 16, None, None, 0, 16, 64, 8, 64, 64, 0, 1.0, ctypes.byref(fu), None) == -1
+    assert b'qk_sumsq' in lib.esme_hip_last_error()
+    # q/k-pair attention with options: a struct of another ABI is refused; head dim 128 has no pair form
+    ao = _hip.AttnOpts(4, 0, 0, 0.0, 0, None, 0, 1)
+    assert lib.esme_hip_attn_varlen_fwd_qkpair_f16_opts(16, 16, 16, 640, 384, 16, 128, 16, 1, 8, 2, 64, 8, 0.1, ctypes.byref(ao), None) == -1
+    assert b'ABI' in lib.esme_hip_last_error()
+    ao = _hip.AttnOpts(ctypes.sizeof(_hip.AttnOpts), 2, 0, 0.0, 0, None, 0, 1)
+    assert lib.esme_hip_attn_varlen_fwd_qkpair_f16_opts(16, 16, 16, 640, 384, 16, 128, 16, 1, 8, 1, 128, 8, 0.1, ctypes.byref(ao), None) == -2
+    # guarded q/k pass: alignment of the maxima
+    assert lib.esme_hip_qk_norm_rotary_f16_guarded(16, 16, 128, 16, 16, None, None, 1e-5, 16, 16, 16, 4, 2, 64, 8, 18, None) == -1
+    assert b'qk_sumsq' in lib.esme_hip_last_error()
+
+
+def test_calibration_batch_covers_the_vocabulary_and_plan_keys():
+    """precision 'half' (round 6), host side: the calibration batch holds every id of the alphabet except <pad> at least 8 times, cls / eos at the ends of
+    its 8 sequences, is the same on every machine, and takes a caller's batch on board; HalfPlan keys derived weights on the channel LIST."""
+    import torch
+    from esme.esm import ESM2, ESMC
+    from esme.attention import HalfPlan, _ext_key
+    for cls in (ESM2, ESMC):
+        m = cls(num_layers=1, embed_dim=64, attention_heads=4)
+        tok, cu, max_len = m._calibration_batch()
+        tok2, _, _ = m._calibration_batch()
+        assert torch.equal(tok, tok2) and tok.numel() == 1024 and cu.tolist()[0] == 0 and cu.tolist()[-1] == 1024 and max_len == 192
+        counts = torch.bincount(tok, minlength=33)
+        al = m.alphabet
+        for i in range(len(al.alphabet)):
+            if i == al.padding_idx:
+                assert counts[i] == 0
+            else:
+                assert counts[i] >= 8, (cls.__name__, i, int(counts[i]))
+        starts = cu[:-1].long()
+        assert (tok[starts] == al.cls_idx).all() and (tok[cu[1:].long() - 1] == al.eos_idx).all()
+        m.HALF_CALIB_VOCAB = 'residues'
+        tr, _, _ = m._calibration_batch()
+        assert set(tr.tolist()) <= set(range(4, 24)) | {al.cls_idx, al.eos_idx}
+        m.HALF_CALIB_VOCAB = 'all'
+        m.set_precision('half', calib=(torch.tensor([0, 5, 24, 2, 0, 7, 2]), (torch.tensor([0, 4, 7], dtype=torch.int32), 4)))
+        tu, cuu, ml = m._calibration_batch()
+        assert tu.numel() == 1031 and cuu.tolist()[-3:] == [1024, 1028, 1031] and tu[-7:].tolist() == [0, 5, 24, 2, 0, 7, 2]
+    a, b = torch.tensor([3, 9], dtype=torch.int32), torch.tensor([3, 10], dtype=torch.int32)
+    pa, pb = HalfPlan(a), HalfPlan(b)
+    assert pa.ext_key == (3, 9) and _ext_key(a) == (3, 9) and _ext_key(b) == (3, 10) and pa.ext == 64 and HalfPlan().ext == 0
+    assert _ext_key(torch.tensor([1, 2], dtype=torch.int32)) == (1, 2)
+
+
 def test_no_cpu_fallback_and_missing_library(monkeypatch):
     from esme import _hip, ESM2
     x = torch.zeros(4, 64, dtype=torch.bfloat16)
