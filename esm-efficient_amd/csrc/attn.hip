@@ -54,7 +54,6 @@ struct AttnArgs {
     float thr;                   // defer-max threshold in log2 units (0 = rescale whenever a row max grows)
     int spec;                    // ping-pong kernel: speculative softmax after a row's first key tile (see the kernel header)
     const int32_t* order;        // optional: work item i belongs to sequence order[i] (longest first: esme_hip_seq_order); NULL = i
-    int tail_split = 0;          // ping-pong kernel: a sequence's LAST query tile, when it holds <= 128 rows, splits its KEY tiles between the two blocks of a wave (see the kernel)
 };
 
 // swizzle of the 16-byte chunk index inside a K-tile row of D bf16 (CPR chunks per row)
@@ -709,12 +708,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     const int s0 = a.cu[b], S = a.cu[b + 1] - s0;
     const int q0 = qt * ROWS;
     if (q0 >= S) return;
-    // Key-split tail tiles (round 6).  A query tile with at most ROWS / 2 rows left would keep half (or three quarters) of the workgroup's wave slots idle for
-    // the whole walk over the keys -- on a proteome-like batch 14 % of all workgroup-slot time (profiles/r06_attn_ragged_table.txt).  In such a tile every wave takes
-    // 32 rows instead of 64 and gives them to BOTH of its blocks: block 0 walks the even key tiles, block 1 the odd ones, through the same two phases (only
-    // the tile indices and LDS slots change), so the tile costs half the iterations; the two partial results are combined in the epilogue (lane-local:
-    // both blocks hold the same rows).  Block-uniform; depends only on the sequence's own length, so a sequence's output bits do not depend on the batch.
-    const bool pm = NW == 4 && a.tail_split != 0 && S - q0 <= ROWS / 2;
 
     const unsigned int ld = (unsigned int)a.ld;
     const u16* qb = a.q + (int64_t)s0 * a.ld + h * D;
@@ -744,11 +737,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 
     // ---- Q fragments of the wave's two q-blocks (B operand of S^T): lane (q = l31, hi) holds Q[q][ds*16 + hi*8 ..]
     bf16x8 qf[2][DS];
-    const int wrow0 = q0 + wave * (pm ? 32 : 64);          // first query row of this wave
+    const int wrow0 = q0 + wave * 64;                      // first query row of this wave
     const bool wave_active = wrow0 < S;                    // wave-uniform
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
-        const int qr = wrow0 + (pm ? 0 : bb * 32) + l31;
+        const int qr = wrow0 + bb * 32 + l31;
         const unsigned int qc = qr < S ? qr : S - 1;
 #pragma unroll
         for (int ds = 0; ds < DS; ++ds)
@@ -1038,63 +1031,39 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             if (rs_sel == 0) dma16(krs, (unsigned int)tile * tile_bytes + kg0 + i * kg_step, slot + (i * NW + wave) * 1024);
             else dma16(vrs, (unsigned int)tile * tile_bytes + vg0 + i * kg_step, slot + K_BYTES + (i * NW + wave) * 1024);
         };
-        // One loop for both forms (scalars only differ: a second instantiation of the phase pair costs ~150 spilled registers).  Plain form, iteration t:
-        // phase A softmaxes tile t of b0, phase B tile t of b1.  Key-split form, iteration it: phase A softmaxes tile 2 it of b0, phase B tile 2 it + 1 of b1;
-        // the iteration consumes and prefetches TWO K / V tiles (K(2 it + 3), K(2 it + 4), V(2 it + 1), V(2 it + 2): their slots were last read in iteration
-        // it - 1), which must all have landed at its end.
-        const int niter = pm ? (nt + 1) >> 1 : nt;
-        for (int it = 0; it < niter; ++it) {
-            const int tA = pm ? 2 * it : it, tB = pm ? 2 * it + 1 : it;              // tiles whose scores phases A / B turn into P
-            const int kA = pm ? tA + 1 : tA, vA = tA - 1, kB = tB + 1, vB = pm ? tB - 1 : tB;   // K tile of the phase's S^T MFMAs, V tile of its O^T MFMAs
-            const int kp0 = pm ? 2 * it + 3 : it + 3, vp0 = pm ? 2 * it + 1 : it + 2;           // prefetches of this iteration (key-split form: + the next tile each)
-            const bool pf_k = kp0 < nt, pf_v = vp0 < nt, pf_k2 = pm && kp0 + 1 < nt, pf_v2 = pm && vp0 + 1 < nt;       // block-uniform
-            char* kslot = smem + (kp0 & 3) * SLOT;
-            char* vslot = smem + (vp0 & 3) * SLOT;
-            char* kslot2 = smem + ((kp0 + 1) & 3) * SLOT;
-            char* vslot2 = smem + ((vp0 + 1) & 3) * SLOT;
+        for (int t = 0; t < nt; ++t) {
+            const bool pf_k = t + 3 < nt, pf_v = t + 2 < nt;       // block-uniform
+            char* kslot = smem + ((t + 3) & 3) * SLOT;
+            char* vslot = smem + ((t + 2) & 3) * SLOT;
             if (wave_active) {
-                const bool tailA = (tA == nt - 1 && ragged) || tA >= nt, tailB = (tB == nt - 1 && ragged) || tB >= nt;
-                const bool need_max = exact || (!QP && it == 0);
-                phase(I0{}, I1{}, need_max, tailA, smem + (kA & 3) * SLOT, smem + (vA & 3) * SLOT, tA * KT, [&](const int m) {
-                    if (KI == 2) {
-                        if (m == ESME_ATTN_DMA0 && pf_k) dma_piece(0, kp0, kslot, 0);
-                        if (m == ESME_ATTN_DMA1 && pf_k) dma_piece(0, kp0, kslot, KI - 1);
-                        if (m == ESME_ATTN_DMA0 + 4 && pf_k2) dma_piece(0, kp0 + 1, kslot2, 0);
-                        if (m == ESME_ATTN_DMA1 + 4 && pf_k2) dma_piece(0, kp0 + 1, kslot2, KI - 1);
-                    } else {
-                        if (m == NM / 2 - 1 && pf_k) dma_piece(0, kp0, kslot, 0);
-                        if (m == NM - 1 && pf_k2) dma_piece(0, kp0 + 1, kslot2, 0);
-                    }
+                const char* cur = smem + (t & 3) * SLOT;
+                const char* prv = smem + ((t + 3) & 3) * SLOT;
+                const char* nxt = smem + ((t + 1) & 3) * SLOT;
+                const bool tail = t == nt - 1 && ragged;
+                const bool need_max = exact || (!QP && t == 0);
+                phase(I0{}, I1{}, need_max, tail, cur, prv, t * KT, [&](const int m) {
+                    if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_k) dma_piece(0, t + 3, kslot, 0); if (m == ESME_ATTN_DMA1 && pf_k) dma_piece(0, t + 3, kslot, KI - 1); }
+                    else if (m == NM / 2 - 1 && pf_k) dma_piece(0, t + 3, kslot, 0);
                 });
-                phase(I1{}, I0{}, need_max, tailB, smem + (kB & 3) * SLOT, smem + (vB & 3) * SLOT, tB * KT, [&](const int m) {
-                    if (KI == 2) {
-                        if (m == ESME_ATTN_DMA0 && pf_v) dma_piece(1, vp0, vslot, 0);
-                        if (m == ESME_ATTN_DMA1 && pf_v) dma_piece(1, vp0, vslot, KI - 1);
-                        if (m == ESME_ATTN_DMA0 + 4 && pf_v2) dma_piece(1, vp0 + 1, vslot2, 0);
-                        if (m == ESME_ATTN_DMA1 + 4 && pf_v2) dma_piece(1, vp0 + 1, vslot2, KI - 1);
-                    } else {
-                        if (m == NM / 2 - 1 && pf_v) dma_piece(1, vp0, vslot, 0);
-                        if (m == NM - 1 && pf_v2) dma_piece(1, vp0 + 1, vslot2, 0);
-                    }
+                phase(I1{}, I0{}, need_max, tail, nxt, cur, t * KT, [&](const int m) {
+                    if (KI == 2) { if (m == ESME_ATTN_DMA0 && pf_v) dma_piece(1, t + 2, vslot, 0); if (m == ESME_ATTN_DMA1 && pf_v) dma_piece(1, t + 2, vslot, KI - 1); }
+                    else if (m == NM / 2 - 1 && pf_v) dma_piece(1, t + 2, vslot, 0);
                 });
             } else {
-                if (pf_k) dma_k(kp0, kslot);
-                if (pf_k2) dma_k(kp0 + 1, kslot2);
-                if (pf_v) dma_v(vp0, vslot);
-                if (pf_v2) dma_v(vp0 + 1, vslot2);
+                if (pf_k) dma_k(t + 3, kslot);
+                if (pf_v) dma_v(t + 2, vslot);
             }
-            // End of the iteration.  NOT __syncthreads(): with an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of
-            // the barrier, i.e. every key tile would wait for the prefetch issued at its own top.  Plain form: what must have landed
+            // End of iteration t.  NOT __syncthreads(): with an LDS-DMA in flight hipcc puts `s_waitcnt vmcnt(0)` in front of
+            // the barrier, i.e. every key tile would wait for the prefetch issued at its own top.  What must have landed
             // here are the tiles first read in iteration t+1 (K tile t+2, V tile t+1: issued in iteration t-1); the DMAs this
-            // iteration issued may stay in flight.  Key-split form: everything (its prefetches are read in the next iteration).
-            if (pm) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if (it + 3 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * KI) : "memory");
-            else if (it + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
+            // iteration issued may stay in flight.
+            if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * KI) : "memory");
+            else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KI) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (wave_active) {                          // drain: O^T(b1) += V P(b1) of the last tile b1 softmaxed (nt - 1; key-split form: 2 niter - 1, P = 0 if past the end)
-            const char* Vs = smem + (((pm ? 2 * niter : nt) - 1) & 3) * SLOT;
+        if (wave_active) {                          // drain: O^T(b1) += V(nt-1) P(b1, nt-1)
+            const char* Vs = smem + ((nt - 1) & 3) * SLOT;
     #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
     #pragma unroll
@@ -1111,9 +1080,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             if (!exact) {
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
-                    const float lr = (pm && bb == 0) ? lrun[0] + lrun[1] : lrun[bb];      // (key-split form: the two blocks are halves of the same rows' sum)
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lr), __float_as_uint(lr), false, false);
-                    if (!(pm && bb == 1) && __any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > 1e-30f))) ovf = 1;      // (idle waves carry lrun = 1)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
+                    if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > 1e-30f))) ovf = 1;      // (idle waves carry lrun = 1)
                 }
             }
         }
@@ -1126,25 +1094,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     // ---- epilogue: normalise, transpose through a wave-private LDS slab (a slot no wave reads any more: every
     // wave passed the loop's last barrier, only V of tile nt-1 is still in use), store whole 128-B rows
     constexpr int OCH = D / 8;                              // 16-B chunks per output row
-    char* slab = smem + (((pm ? 2 * ((nt + 1) >> 1) : nt) + (wave >> 2)) & 3) * SLOT + (wave & 3) * (32 * ROWB);      // a slot no wave reads any more
-    if (pm) {
-        // key-split tile: block 1's partial result (odd key tiles; none when the sequence has one tile) joins block 0's -- same rows, same lanes.  With a
-        // reference maximum per block (first even / first odd tile) the two are brought to the larger one first.
-        float a0 = 1.f, a1 = nt > 1 ? 1.f : 0.f;
-        if (nt > 1) {                                  // (the pre-scaled form has no reference in its speculative pass -- both stay at their initial value: a0 = a1 = 1 -- but its exact redo has)
-            const float mn = fmaxf(mc[0], mc[1]);
-            a0 = __builtin_amdgcn_exp2f(mc[0] - mn);
-            a1 = __builtin_amdgcn_exp2f(mc[1] - mn);
-        }
-        lrun[0] = lrun[0] * a0 + (nt > 1 ? lrun[1] * a1 : 0.f);
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[0][db][r] = oacc[0][db][r] * a0 + (nt > 1 ? oacc[1][db][r] * a1 : 0.f);
-    }
+    char* slab = smem + ((nt + (wave >> 2)) & 3) * SLOT + (wave & 3) * (32 * ROWB);
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
-        if (bb == 1 && pm) break;
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
         const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
         if (bb) __builtin_amdgcn_wave_barrier();
@@ -2013,7 +1965,6 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
         // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
         const int nw = g_attn_variant == 8 ? 8 : 4;
-        a.tail_split = g_attn_variant == 0;        // key-split tail tiles (round 6); option variant 4 = the same kernel without them (rounds 2-5: A/B runs)
         if (f16) return launch_pp64<4, false, 64, true>(a, B, max_len, s);
 #ifdef ESME_ATTN_W4
         if (qp && g_attn_variant == 16) return launch_w4(a, B, max_len, s);          // one wave per SIMD, four q-blocks per wave (lab build)
@@ -2023,7 +1974,6 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     }
     if (d == 32 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o) && fits32) {
         // head dim 32 (ESM2-150M; ESM2-35M's padded heads): the same software-pipelined kernel at D = 32 (round 4)
-        a.tail_split = g_attn_variant == 0;
         if (f16) return launch_pp64<4, false, 32, true>(a, B, max_len, s);
         return qp ? launch_pp64<4, true, 32>(a, B, max_len, s) : launch_pp64<4, false, 32>(a, B, max_len, s);
     }

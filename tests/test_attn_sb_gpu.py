@@ -43,8 +43,7 @@ def test_single_block_kernel_plain_forms(d, H, form):
     cu = syn.cu_lens_of(lengths)
     args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
     kw = dict(q_prescaled=(form == 'qp'))
-    with _hip.attn_options(variant=4):              # the ping-pong kernel without key-split tail tiles (whose tail rows sum in another order)
-        base = _hip.attn_varlen(*args, **kw)
+    base = _hip.attn_varlen(*args, **kw)
     with _hip.attn_options(variant=2):
         out = torch.full((T, E), 9.0, dtype=dt, device=DEV)
         _hip.attn_varlen(*args, out=out, **kw)
@@ -130,82 +129,3 @@ def test_qk_pair_entry_new_kernel_vs_first_generation(d, H):
     assert torch.isfinite(new.float()).all() and torch.equal(new, new2)
     assert e_new <= 6e-4 and e_new <= 1.25 * e_old + 1e-5
 
-
-TAILS = [1, 17, 33, 64, 65, 100, 128, 129, 256, 257, 300, 384, 385, 512 + 40, 1024 + 127, 1024 + 129]
-
-
-@pytest.mark.parametrize('d,H', [(64, 5), (32, 6)])
-@pytest.mark.parametrize('form', ['bf16', 'qp', 'f16'])
-def test_key_split_tail_tiles(d, H, form):
-    """Ping-pong kernel, round 6: a sequence's last query tile with <= 128 rows gives every wave 32 rows whose KEY tiles are split between the wave's two
-    blocks (even / odd), combined in the epilogue.  Against float64; against the same kernel without the split (esme_attn_opts_t.variant = 4): rows of full
-    tiles are bit-identical, tail rows agree to the rounding of P; a sequence's bits do not depend on what it is packed with; the dispatch order changes no bit."""
-    lengths = TAILS
-    E, T = H * d, sum(lengths)
-    g = torch.Generator().manual_seed(11 * d + len(form))
-    dt = H16 if form == 'f16' else torch.bfloat16
-    q, k, v = (torch.randn(T, E, generator=g) * s for s in (1.5, 1.5, 1.0))
-    if form == 'qp':
-        q = q * (d ** -0.5 * LOG2E)
-    qkv = torch.cat((q, k, v), dim=1).to(dt).to(DEV)
-    cu = syn.cu_lens_of(lengths)
-    args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
-    kw = dict(q_prescaled=(form == 'qp'))
-    out = torch.full((T, E), 9.0, dtype=dt, device=DEV)
-    _hip.attn_varlen(*args, out=out, **kw)
-    out2 = _hip.attn_varlen(*args, order=_hip.seq_order(cu.to(DEV)), **kw)
-    with _hip.attn_options(variant=4):
-        old = _hip.attn_varlen(*args, **kw)
-    qd = qkv[:, :E].double().cpu()
-    if form == 'qp':
-        qd = qd / (d ** -0.5 * LOG2E)
-    ref = ref64(qd, qkv[:, E:2 * E].double().cpu(), qkv[:, 2 * E:].double().cpu(), cu, H, d)
-    e_new, e_old = rel(out.float().cpu(), ref), rel(old.float().cpu(), ref)
-    print(f'\n[key-split tails] d={d} {form}: with {e_new:.2e}, without {e_old:.2e}')
-    assert torch.isfinite(out.float()).all() and torch.equal(out, out2)
-    assert e_new <= (8e-4 if form == 'f16' else 4e-3) and e_new <= 1.15 * e_old + 1e-5
-    starts = cu.tolist()
-    for s0, n in zip(starts[:-1], lengths):
-        full = n if (n % 256 == 0 or n % 256 > 128) else n - n % 256        # rows of the tiles the split does not touch
-        assert torch.equal(out[s0:s0 + full], old[s0:s0 + full]), n
-    # alone == packed, bit for bit (the split depends on the sequence's own length only)
-    for i in (0, 4, 10, 15):
-        s0, n = starts[i], lengths[i]
-        one = _hip.attn_varlen(qkv[s0:s0 + n, :E], qkv[s0:s0 + n, E:2 * E], qkv[s0:s0 + n, 2 * E:], torch.tensor([0, n], dtype=torch.int32, device=DEV), n, H, **kw)
-        assert torch.equal(one, out[s0:s0 + n]), n
-
-
-@pytest.mark.parametrize('d', [64, 32])
-def test_key_split_tail_tiles_exact_maxima_and_overflow_redo(d):
-    """The key-split form with exact maxima on every tile (two running maxima, one per block, reconciled in the epilogue) and with a speculative pass that
-    overflows (a key in an ODD tile beats both blocks' first-tile maxima by thousands of log2 units): redone exactly, finite, right."""
-    H = 4
-    lengths = [300, 100, 1100]                  # tails of 44, 100 and 76 rows
-    E, T = H * d, sum(lengths)
-    g = torch.Generator().manual_seed(d + 1)
-    q, k, v = (torch.randn(T, E, generator=g) for _ in range(3))
-    ramp = torch.cat([torch.linspace(0.5, 3.0, n) for n in lengths]).unsqueeze(1)
-    k = k * ramp
-    cu = syn.cu_lens_of(lengths)
-    for dt, tol in ((torch.bfloat16, 6e-3), (H16, 1e-3)):
-        qkv = torch.cat((q, k, v), dim=1).to(dt).to(DEV)
-        args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
-        ref = ref64(qkv[:, :E].cpu(), qkv[:, E:2 * E].cpu(), qkv[:, 2 * E:].cpu(), cu, H, d)
-        ex, sp = _hip.attn_varlen(*args, exact=True), _hip.attn_varlen(*args)
-        assert rel(ex.float().cpu(), ref) <= tol and rel(sp.float().cpu(), ref) <= tol
-    qb, kb = torch.randn(T, E, generator=g) * 0.5, torch.randn(T, E, generator=g) * 0.5
-    kb[70] = 0
-    kb[70, :d] = 60.0                            # key 70 of sequence 0: tile 1 (odd)
-    qb[:, :d] = qb[:, :d].abs() + 20.0
-    qkv = torch.cat((qb, kb, v), dim=1).to(torch.bfloat16).to(DEV)
-    args = (qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], cu.to(DEV), max(lengths), H)
-    ref = ref64(qkv[:, :E].cpu(), qkv[:, E:2 * E].cpu(), qkv[:, 2 * E:].cpu(), cu, H, d)
-    sp = _hip.attn_varlen(*args)
-    assert torch.isfinite(sp.float()).all() and rel(sp.float().cpu(), ref) <= 6e-3
-    qs = torch.cat((qb * (d ** -0.5 * LOG2E), kb, v), dim=1).to(torch.bfloat16).to(DEV)      # the pre-scaled form: overflowing AND vanishing sums
-    qs[cu[1]:cu[2], :E] = 0
-    qs[cu[1]:cu[2], :d] = -40.0                  # sequence 1 (one key-split tile): every score of head 0 far below zero -> the no-maximum sum vanishes
-    args = (qs[:, :E], qs[:, E:2 * E], qs[:, 2 * E:], cu.to(DEV), max(lengths), H)
-    ref = ref64(qs[:, :E].double().cpu() / (d ** -0.5 * LOG2E), qs[:, E:2 * E].cpu(), qs[:, 2 * E:].cpu(), cu, H, d)
-    sq = _hip.attn_varlen(*args, q_prescaled=True)
-    assert torch.isfinite(sq.float()).all() and rel(sq.float().cpu(), ref) <= 6e-3
