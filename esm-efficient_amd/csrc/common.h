@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned int pk_absmax_f16(unsigned int acc, unsigned
 // acc <- max(acc, |v|) for two packed fp16 values in ONE instruction: gfx950's three-operand packed maximum with the third operand negated
 // (max(acc, v, -v)); IEEE "maximum": a NaN sticks.  acc must hold non-negative values (it then keeps doing so: compatible with pk_max_u16 above).
 __device__ __forceinline__ unsigned int pk_absmax3_f16(unsigned int acc, const unsigned int v) {
-    asm volatile("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(acc) : "v"(v));
+    asm("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(acc) : "v"(v));
     return acc;
 }
 __device__ __forceinline__ unsigned int pk_max_u16(unsigned int x, unsigned int y) {

@@ -30,7 +30,6 @@
 #endif
 #include <atomic>
 #include <cstdlib>
-#include <type_traits>
 
 #ifndef ESME_GEMM_P3N
 #define ESME_GEMM_P3N 4            // eighths of a K-tile's LDS-DMA pieces issued two sub-steps early (sub-step 3 of the previous tile)
@@ -854,6 +853,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
             const int rl = lane / CH, ch = lane % CH;
             const int n = nw0 + ch * 8;
             const bool col_ok = n < n_out;
+            // The maxima are kept whether the guard is on or off, and the loop is written as two unrolled trips over the (wave-uniform) "every row of this
+            // pass exists" so that NO branch sits inside the unrolled iterations: a branch there ends the basic block of every iteration, the slab reads of a
+            // pass are no longer batched ahead of its stores, and the launch was 8 % slower with the guard switched OFF (profiles/r06_half_guard_regression.txt).
+            const bool full_pass = mw0 + (pass + 1) * RPP <= a.M;
+#pragma unroll
+            for (int fsel = 0; fsel < 2; ++fsel) {
+            if ((fsel == 1) != full_pass) continue;
 #pragma unroll
             for (int it = 0; it < RPP / RPI; ++it) {
                 const int r = it * RPI + rl;
@@ -865,16 +871,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n), v, a.stream_out);
                     store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + a.pair_off + n), vl, a.stream_out);
                 }
-                if (guard_cols) {
-                    if (mw0 + (pass + 1) * RPP <= a.M) {       // (wave-uniform) every row of this pass exists: one v_pk_maximum3_f16 per dword = half a VALU per element
+                if (fsel == 1) {                               // one v_pk_maximum3_f16 per dword = half a VALU per element
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) cmx[q] = pk_absmax3_f16(cmx[q], v[q]);
-                    } else {                                   // last row tile: rows past M are masked out (they re-read row M - 1 of a stream that is updated in place)
-                        const unsigned int keep = m < a.M ? 0x7fff7fffu : 0u;
+                    for (int q = 0; q < 4; ++q) cmx[q] = pk_absmax3_f16(cmx[q], v[q]);
+                } else {                                       // last row tile: rows past M are masked out (they re-read row M - 1 of a stream that is updated in place)
+                    const unsigned int keep = m < a.M ? 0x7fff7fffu : 0u;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) cmx[q] = pk_max_u16(cmx[q], v[q] & keep);
-                    }
+                    for (int q = 0; q < 4; ++q) cmx[q] = pk_max_u16(cmx[q], v[q] & keep);
                 }
+            }
             }
         }
         if (guard_cols) {                                      // once per tile: the 8 lanes that hold the same column chunk combine; each lane then picks ITS column
@@ -1025,7 +1030,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 qk_cur = *qk_slot;
             }
         }
+        // (the wave-uniform guard switch is taken ONCE, outside the unrolled store loop: tested inside it, it ended the basic block of every iteration and the
+        // slab reads of a pass were no longer batched ahead of its stores -- profiles/r06_half_guard_regression.txt)
+        // Written as a two-trip unrolled loop over the switch's value (one trip where the guard does not exist), so that `gsel` is a constant inside.
         if (col_ok || STATS) {
+#pragma unroll
+        for (int gsel = 0; gsel < (QKG ? 2 : 1); ++gsel) {
+            if (QKG && (gsel == 1) != qk_guard) continue;
 #pragma unroll
             for (int it = 0; it < RPP / RPI; ++it) {
                 const int r = it * RPI + rl;
@@ -1033,14 +1044,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                 ESME_LDS_CHECK(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4), 16, smem, 2 * STAGE);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(slab + r * ROWB + ((ch ^ (r & (CH - 1))) << 4));
                 if (col_ok && m < a.M && ESME_TUNE_STORE_OK) store_stream(reinterpret_cast<u32x4*>(a.C + m * a.ldc + n + (PAIR ? half * a.pair_off : 0)), v, a.stream_out);
-                if constexpr (QKG) {
-                    if (qk_guard) {
-                        float ss = sumsq8_f16(v);
-                        ss += dpp_f32<0xB1>(ss);                                   // lane ^ 1: 16 columns
-                        if constexpr (ROTD >= 32) ss += dpp_f32<0x4E>(ss);         // lane ^ 2: 32 columns
-                        if constexpr (ROTD == 64) ss += dpp_f32<0x141>(ss);        // the other quad: 64 columns
-                        qk_max = fmaxf(qk_max, ss);
-                    }
+                if (QKG && gsel == 1) {
+                    float ss = sumsq8_f16(v);
+                    ss += dpp_f32<0xB1>(ss);                                   // lane ^ 1: 16 columns
+                    if constexpr (ROTD >= 32) ss += dpp_f32<0x4E>(ss);         // lane ^ 2: 32 columns
+                    if constexpr (ROTD == 64) ss += dpp_f32<0x141>(ss);        // the other quad: 64 columns
+                    qk_max = fmaxf(qk_max, ss);
                 }
                 if constexpr (STATS) {
                     // statistics of what the next LayerNorm will read (the ROUNDED values): this lane
@@ -1058,6 +1067,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const GemmArgs 
                     if (ch == 0) blkst[wn * BM + wm * WTM + pass * RPP + r] = col_ok ? f32x2{t1, t2} : f32x2{0.f, 0.f};
                 }
             }
+        }
         }
         if constexpr (QKG) {
             if (qk_guard) {                                    // rows combine (lanes 8 apart), then at most one atomic per head of the wave's 64 columns
@@ -1176,7 +1186,13 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
         const bool want = a.opt_persist < 0 ? persist_default() != 0 : a.opt_persist != 0;
-        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16, RP>(a, s);
+        // Not with the plan guard of precision 'half' on the pair-stream residual epilogue (round 6, tools/lab/pair_gemm_probe.py, profiles/r06_half_guard_regression.txt):
+        // the four registers of running column maxima cost the persistent form 5 % of the whole launch once a workgroup walks >= 3 tiles (FFN-down 563 -> 590 us at
+        // M = 50 000; nothing at 1 or 2 rounds, nothing measurable in any counter but SQ_WAIT_ANY, the K loop is instruction-for-instruction the same), in every
+        // formulation tried (v_pk_maximum3_f16 / v_pk_max_u16, branch-free, maxima from a second slab read, reduced to one register per pass); the one-tile-per-workgroup
+        // form pays nothing for them and is as fast on this epilogue as the persistent form without them (563 / 218 us against 563 / 219).
+        const bool guard_rp = RP && a.col_absmax != nullptr;
+        if (want && !guard_rp && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16, RP>(a, s);
 
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
