@@ -1181,18 +1181,17 @@ static int launch_one(GemmArgs& a, hipStream_t s) {
     set_raster<BM, BN>(a);
     int64_t blocks = (int64_t)a.tiles_m * a.tiles_n;
     if (blocks > 0x7fffffffLL) return fail(ESME_ERR_UNSUPPORTED, "gemm: grid too large");
-    if constexpr (!PERSIST && !PAIR && BM == 256 && BN == 256 && (ROTD == 0 || ESME_GEMM_PERSIST_ROT)) {     // (fused rotary: the epilogue's tables + the address set-up spill)
+    if constexpr (!PERSIST && !PAIR && !RP && BM == 256 && BN == 256 && (ROTD == 0 || ESME_GEMM_PERSIST_ROT)) {     // (fused rotary: the epilogue's tables + the address set-up spill)
         // Big tiles run one workgroup per CU (128 KB of LDS): once a launch is several rounds long, ONE persistent
         // workgroup per CU walks the tiles instead, fetching the next tile's first K-tile under the current epilogue.
         const int ncu = cu_count() & ~7;
         const bool want = a.opt_persist < 0 ? persist_default() != 0 : a.opt_persist != 0;
-        // Not with the plan guard of precision 'half' on the pair-stream residual epilogue (round 6, tools/lab/pair_gemm_probe.py, profiles/r06_half_guard_regression.txt):
-        // the four registers of running column maxima cost the persistent form 5 % of the whole launch once a workgroup walks >= 3 tiles (FFN-down 563 -> 590 us at
-        // M = 50 000; nothing at 1 or 2 rounds, nothing measurable in any counter but SQ_WAIT_ANY, the K loop is instruction-for-instruction the same), in every
-        // formulation tried (v_pk_maximum3_f16 / v_pk_max_u16, branch-free, maxima from a second slab read, reduced to one register per pass); the one-tile-per-workgroup
-        // form pays nothing for them and is as fast on this epilogue as the persistent form without them (563 / 218 us against 563 / 219).
-        const bool guard_rp = RP && a.col_absmax != nullptr;
-        if (want && !guard_rp && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16, RP>(a, s);
+        // NOT the pair-stream residual epilogue of precision 'half' (RP) since round 6 (tools/lab/pair_gemm_probe.py, profiles/r06_half_guard_regression.txt): the
+        // four registers of running column maxima the plan guard keeps in its store loop cost the PERSISTENT form 5 % of the whole launch once a workgroup walks
+        // >= 3 tiles (FFN-down 563 -> 590 us at M = 50 000; nothing at 1 or 2 rounds; the K loop is instruction-for-instruction the same and the loss is all
+        // SQ_WAIT_ANY), in every formulation tried and with the guard switched off at run time; the one-tile-per-workgroup form pays nothing for them and is as
+        // fast on this epilogue as the persistent form was without them (563 / 218 us against 563 / 219).
+        if (want && a.vec_ok && ncu >= 8 && blocks >= 2 * (int64_t)ncu) return launch_one<BM, BN, WM, WN, EPI, ROTD, LNF, STATS, true, R32, false, F16, RP>(a, s);
 
     }
     if constexpr (PERSIST) blocks = cu_count() & ~7;
