@@ -678,9 +678,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 // F16 (precision 'half'): q, k, v, P and o are IEEE fp16 (11 significant bits).  fp16 ends at 65 504, so there is no QP form (P = exp2(score) with
 // no reference at all); the speculative pass against the FIRST tile's maximum stays (P = 2^(how far a later score beats that maximum): a
 // handful on real data) with the overflow test tightened to fp16's range -- a work item that trips it is redone with exact maxima (P <= 1).
+// QP && F16 (round 6): the no-reference form with a FIXED reference of 4 (log2 units) -- the score accumulators start at -4.0 (an inline constant of the MFMA's C
+// operand: no instruction, no register), so P = 2^(s - 4) stays inside fp16 for scores up to 20 (13.9 in natural units: e^13.9 = 10^6 times the weight of a zero
+// score).  A row whose scores go higher trips the overflow test (partial sum >= 3e4), a row whose sum falls below 2^-8 (every score below about -2.8: its P values would
+// sit in fp16's subnormals) trips the vanished-sum test: both redo the work item with exact maxima, exactly as the bf16 form does at 1e30 / 1e-30.
 template <int NW, bool QP = false, int D = 64, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
-    static_assert(!F16 || !QP, "fp16 P needs a reference maximum");
+    constexpr float S0 = (QP && F16) ? -4.0f : 0.0f;            // where the score accumulators start
     constexpr int DS = D / 16, DB = D / 32, NT = NW * 64;
     constexpr int ROWB = D * 2;                  // bytes per K / V row
     constexpr int K_BYTES = KT * D * 2;          // 8 KB (head dim 64) / 4 KB (32)
@@ -837,8 +841,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             if (m >= NPV) {
                 const int j = m - NPV, kbk = j & 1, ds = j >> 1;
                 if (ds == 0) {
-                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], z);
+                    if constexpr (QP && F16) {
+                        sacc[bm][kbk] = mfma_32x32x16_f16_cm4(fr[m % 3], qf[bm][ds]);     // starts at S0 = -4 (inline constant)
+                    } else {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], z);
+                    }
                 } else {
                     sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], sacc[bm][kbk]);
                 }
@@ -984,7 +992,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
     #pragma unroll
             for (int i = 0; i < 2; ++i) {
     #pragma unroll
-                for (int r = 0; r < 16; ++r) { if (i < DB) oacc[bb][i < DB ? i : 0][r] = 0.f; sacc[bb][i][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { if (i < DB) oacc[bb][i < DB ? i : 0][r] = 0.f; sacc[bb][i][r] = S0; }
     #pragma unroll
                 for (int s = 0; s < 2; ++s) pw[bb][i][s] = u32x4{0u, 0u, 0u, 0u};
             }
@@ -1081,7 +1089,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
-                    if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > 1e-30f))) ovf = 1;      // (idle waves carry lrun = 1)
+                    if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > (F16 ? 0.00390625f : 1e-30f)))) ovf = 1;      // (idle waves carry lrun = 1)
                 }
             }
         }
@@ -1946,7 +1954,8 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     // the 4-wave head-dim-64 kernel in its no-reference-maximum form
     const bool f16 = opts && opts->f16;                         // fp16 operands: speculative / defer-max passes bounded to fp16's range (see the kernels)
     const bool qp = opts && opts->q_prescaled;
-    ESME_CHECK_ARG(!(f16 && qp), "attn: fp16 operands do not combine with q_prescaled (no reference maximum: P would leave fp16's range)");
+    ESME_CHECK_ARG(!(f16 && qp) || ((d == 64 || d == 32) && g_attn_variant != 1 && g_attn_variant != 2 && ld_o % 8 == 0 && aligned16(o)),
+                   "attn: fp16 operands combine with q_prescaled only in the ping-pong kernel (head dims 64 / 32: fixed reference 4, redo outside fp16's range)");
     AttnArgs a{(const u16*)q, (const u16*)k, (const u16*)v, ld_qkv, (u16*)o, ld_o, cu_lens, H,
                qp ? 1.0f : softmax_scale * 1.4426950408889634f, 1, H * B, exact ? 0.0f : g_attn_thr, exact ? 0 : g_attn_spec,
                opts ? opts->seq_order : nullptr};
@@ -1965,7 +1974,7 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
         // workgroups per CU (one's prologue / epilogue overlaps the other's main loop): measured faster than 8 waves
         // (one workgroup per CU) from S = 130 to S = 2 000; the 8-wave form stays behind the tuning hook.
         const int nw = g_attn_variant == 8 ? 8 : 4;
-        if (f16) return launch_pp64<4, false, 64, true>(a, B, max_len, s);
+        if (f16) return qp ? launch_pp64<4, true, 64, true>(a, B, max_len, s) : launch_pp64<4, false, 64, true>(a, B, max_len, s);
 #ifdef ESME_ATTN_W4
         if (qp && g_attn_variant == 16) return launch_w4(a, B, max_len, s);          // one wave per SIMD, four q-blocks per wave (lab build)
 #endif
@@ -1974,7 +1983,7 @@ static int attn_fwd(const void* q, const void* k, const void* v, int64_t ld_qkv,
     }
     if (d == 32 && g_attn_variant != 1 && ld_o % 8 == 0 && aligned16(o) && fits32) {
         // head dim 32 (ESM2-150M; ESM2-35M's padded heads): the same software-pipelined kernel at D = 32 (round 4)
-        if (f16) return launch_pp64<4, false, 32, true>(a, B, max_len, s);
+        if (f16) return qp ? launch_pp64<4, true, 32, true>(a, B, max_len, s) : launch_pp64<4, false, 32, true>(a, B, max_len, s);
         return qp ? launch_pp64<4, true, 32>(a, B, max_len, s) : launch_pp64<4, false, 32>(a, B, max_len, s);
     }
     // two 32-row q-blocks per wave when the longest sequence fills at least one 256-row tile

@@ -91,6 +91,16 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// D = A x B - 4.0 (fp16 operands): the accumulator's start value as an INLINE CONSTANT of the C operand -- hipcc folds a zero splat into the instruction but
+// materialises any other splat in 16 registers per use (16 v_mov in front of every such MFMA), so the instruction is spelled out.  Inline asm hides the MFMA from
+// the hazard recogniser: the result must not be read by anything (another MFMA's C operand included) before an independent MFMA has been issued behind it -- the
+// ping-pong attention kernel alternates its two accumulators, its only user.
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16_cm4(const bf16x8 a, const bf16x8 b) {
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, -4.0" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // Results that the kernel itself never reads again (GEMM outputs of 128 - 512 MB, the residual stream) leave with the non-temporal hint
 // (`global_store ... nt`): they do not displace the A / W panels the same launch is re-reading from its 4 MB L2.  Measured on the headline
 // workload, interleaved on one box: 61.08 -> 59.92 ms per step (GEMMs 55.7 -> 54.7 ms, attention 6.10 -> 6.00): profiles/r04_nt_stores_ab.txt.

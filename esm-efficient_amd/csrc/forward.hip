@@ -187,6 +187,11 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
     int rc;
 #define ESME_TRY(call) do { rc = (call); if (rc != ESME_OK) return rc; } while (0)
     esme_attn_opts_t aopts{(int)sizeof(esme_attn_opts_t), 0, 0, 8.0f, 1, nullptr, 0, 1};
+    // the fixed-reference form of the fp16 attention kernel in the layers without q / k pairs (ABI 10; the caller's plan decides: attn_q_prescale):
+    // softmax_scale * log2(e) rides in the QKV epilogue (fused rotary) or in ESM-C's q/k pass, exactly as in esme_hip_forward
+    const bool qp = m->attn_q_prescale && m->rotary && (dp == 64 || dp == 32) && Ea % 64 == 0 && (rot_fused || m->qk_norm);
+    const float qs = m->softmax_scale * 1.4426950408889634f;
+    aopts.q_prescaled = qp ? 1 : 0;
     if (B > 1 && B <= 1024) {
         ESME_TRY(esme_hip_seq_order(cu_lens, B, w.order, stream));
         aopts.seq_order = w.order;
@@ -211,10 +216,12 @@ extern "C" int esme_hip_forward_half(const esme_model_desc_t* m, const float* x3
         } else {
             if (rot_fused) { fu.cos = m->cos; fu.sin = m->sin; fu.pos = pos; fu.head_dim = dp; fu.max_len = m->table_len; fu.rot_cols = (int)(2 * Ea); }
             if (rot_fused && m->half_qk_sumsq) fu.qk_sumsq = m->half_qk_sumsq + (int64_t)i * 2 * H;          // plan guard: this layer's q / k row norms
+            if (qp && rot_fused) { fu.q_scale = qs; fu.q_cols = (int)Ea; }
             ESME_TRY(esme_hip_gemm_bf16_fused(w.xs, ldxs, L.qkv_w, nullptr, nullptr, 0, w.qkv, 3 * Ea, T, (int)(3 * Ea), Kf, ESME_EPI_NONE, 1.0f, &fu, stream));
             if (m->qk_norm) {
-                ESME_TRY(esme_hip_qk_norm_rotary_f16_guarded(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len,
-                                                             m->half_qk_sumsq ? m->half_qk_sumsq + (int64_t)i * 2 * H : nullptr, stream));
+                uint32_t* const gq = m->half_qk_sumsq ? m->half_qk_sumsq + (int64_t)i * 2 * H : nullptr;
+                if (qp) ESME_TRY(esme_hip_qk_norm_rotary_f16_scaled(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, qs, gq, stream));
+                else ESME_TRY(esme_hip_qk_norm_rotary_f16_guarded(q, k, 3 * Ea, L.lnq_w, L.lnk_w, L.lnq_b, L.lnk_b, m->ln_eps, m->cos, m->sin, pos, T, H, dp, m->table_len, gq, stream));
             } else if (m->rotary && !rot_fused) {
                 ESME_TRY(esme_hip_rotary_varlen_f16(q, k, 3 * Ea, m->cos, m->sin, pos, T, H, dp, m->table_len, stream));
             }

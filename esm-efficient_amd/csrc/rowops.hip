@@ -1186,6 +1186,14 @@ extern "C" int esme_hip_qk_norm_rotary_f16_guarded(void* q, void* k, int64_t ld,
     return qk_norm_rotary_impl(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, 1.0f, true, stream, qk_sumsq);
 }
 
+extern "C" int esme_hip_qk_norm_rotary_f16_scaled(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
+                                                  const void* bk, float eps, const void* cosT, const void* sinT,
+                                                  const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, float q_scale, uint32_t* qk_sumsq, void* stream) {
+    ESME_CHECK_ARG(!qk_sumsq || (reinterpret_cast<uintptr_t>(qk_sumsq) & 3u) == 0, "qk_norm_rotary: misaligned qk_sumsq");
+    ESME_CHECK_ARG(q_scale > 0.f && q_scale == q_scale, "qk_norm_rotary: q_scale must be positive");
+    return qk_norm_rotary_impl(q, k, ld, wq, wk, bq, bk, eps, cosT, sinT, pos, T, heads, head_dim, max_len, q_scale, true, stream, qk_sumsq);
+}
+
 extern "C" int esme_hip_qk_norm_rotary(void* q, void* k, int64_t ld, const void* wq, const void* wk, const void* bq,
                                        const void* bk, float eps, const void* cosT, const void* sinT,
                                        const int32_t* pos, int64_t T, int heads, int head_dim, int max_len, void* stream) {

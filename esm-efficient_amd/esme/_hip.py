@@ -17,7 +17,7 @@ import torch
 
 _LIB_NAME = 'libesme_hip.so'
 _LIB_PATH = os.environ.get('ESME_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU = 0, 1, 2, 3
 
@@ -93,6 +93,8 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'esme_hip_qk_norm_rotary_f16_guarded': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'esme_hip_qk_norm_rotary_f16_scaled': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                            c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'esme_hip_pair_to_f32': (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'esme_hip_stream_operand_guarded': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_int,
@@ -452,11 +454,18 @@ def qk_norm_rotary_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torc
         raise ValueError('qk_norm_rotary: q and k must share a row stride')
     T, E = q.shape
     if dt == torch.float16:
-        if q_scale != 1.0:
-            raise ValueError('qk_norm_rotary: q_scale is not available for float16 operands')
         with _Traced('qk_norm_rotary', (T, E)):
             if qk_sumsq is not None and (qk_sumsq.numel() != 2 * heads or not qk_sumsq.is_contiguous()):
                 raise ValueError('qk_norm_rotary: qk_sumsq is a contiguous int32 (2, heads) buffer')
+            if q_scale != 1.0:                         # (ABI 10: the fixed-reference form of the fp16 attention kernel; the guard sees the unscaled norms)
+                _check(load().esme_hip_qk_norm_rotary_f16_scaled(
+                    qp, kp, ld, _dev(wq, 'wq', torch.bfloat16), _dev(wk, 'wk', torch.bfloat16),
+                    _dev(bq, 'bq', torch.bfloat16) if bq is not None else None,
+                    _dev(bk, 'bk', torch.bfloat16) if bk is not None else None, float(eps),
+                    _dev(cos, 'cos', torch.float16), _dev(sin, 'sin', torch.float16), _dev(pos, 'pos', torch.int32),
+                    T, heads, E // heads, cos.shape[0], float(q_scale), _dev(qk_sumsq, 'qk_sumsq', torch.int32) if qk_sumsq is not None else None, _stream()),
+                    'esme_hip_qk_norm_rotary_f16_scaled')
+                return
             _check(load().esme_hip_qk_norm_rotary_f16_guarded(
                 qp, kp, ld, _dev(wq, 'wq', torch.bfloat16), _dev(wk, 'wk', torch.bfloat16),
                 _dev(bq, 'bq', torch.bfloat16) if bq is not None else None,
@@ -482,7 +491,8 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     dispatch the longest sequences' work first -- speed only, the result is the same bit for bit.  `q_prescaled`: q already
     carries softmax_scale * log2(e) (gemm_fused(..., q_scale=)); `softmax_scale` is ignored and the head-dim-64 kernel runs its
     no-reference-maximum form.  float16 q, k, v (precision 'half'): float16 output, P in fp16 (the speculative pass is bounded to fp16's
-    range and falls back to exact maxima per work item)."""
+    range and falls back to exact maxima per work item); with `q_prescaled` (head dims 32 / 64): P = 2^(score - 4), scores up to 20 (log2 units) inside
+    fp16, anything beyond -- or a row whose sum falls into the subnormals -- redone with exact maxima per work item."""
     f16 = q.dtype == torch.float16
     dt = torch.float16 if f16 else torch.bfloat16
     qp, ld = _rows2d(q, 'attn q', dt)
@@ -503,12 +513,12 @@ def attn_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_lens: torc
     if q_prescaled and exact:
         raise ValueError('attn: q_prescaled is not available through the exact entry (pass the unscaled q)')
     if f16:
-        if q_prescaled:
-            raise ValueError('attn: q_prescaled is not available for float16 operands (P must stay <= 1)')
+        if q_prescaled and d not in (32, 64):
+            raise ValueError('attn: q_prescaled with float16 operands is the ping-pong kernel\'s form (head dims 32 / 64)')
         base = ao
         ao = AttnOpts(ctypes.sizeof(AttnOpts), base.variant if base else 0, base.q_blocks if base else 0,
                       0.0 if exact else (base.defer_max_thr if base else 8.0), 0 if exact else (base.speculative if base else 1),
-                      _dev(order, 'seq order', torch.int32) if order is not None else None, 0, 1)
+                      _dev(order, 'seq order', torch.int32) if order is not None else None, 1 if q_prescaled else 0, 1)
         exact = False                                   # (everything fp16 goes through the options entry; `exact` rides in thr = 0, spec = 0)
     elif (order is not None or q_prescaled) and not exact:
         base = ao

@@ -142,10 +142,14 @@ class HalfPlan:
                 (esme_hip_attn_varlen_fwd_qkpair_f16): needed once |score| reaches the hundreds (2^-12 |q||k| is then tenths of a score unit).
       info      the measurements the decision was taken from (reported by tools / bench).
       ext_key   the channel list as a host tuple: what derived weight copies are keyed on (a device address can be reused by the caching
-                allocator after a recalibration: ADVICE r5)."""
-    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info', 'ext_key', 'site_ref')
+                allocator after a recalibration: ADVICE r5).
+      qp        the fixed-reference form of the fp16 attention kernel in the layers without pairs (round 6; ESM2.HALF_QP_BOUND)."""
+    __slots__ = ('ext_sel', 'qk_pair', 'qk_layers', 'info', 'ext_key', 'site_ref', 'qp')
 
-    def __init__(self, ext_sel=None, qk_pair=False, info=None, qk_layers=None, site_ref=None):
+    def __init__(self, ext_sel=None, qk_pair=False, info=None, qk_layers=None, site_ref=None, qp=False):
+        # qp: the layers WITHOUT q / k pairs fold softmax_scale * log2(e) into q and run the fp16 attention kernel in its fixed-reference form (P = 2^(score - 4): no
+        # maximum, no subtraction; scores above 13.9 or rows that vanish are redone per work item) -- set where the calibrated score bound leaves that window room
+        self.qp = bool(qp)
         # site_ref: (2 L + 1,) device tensor, the median channel's largest |value| at every guard site as the CALIBRATION batch (1 024+ rows) saw it: the floor of
         # the run-time guard's reference, so that a batch of a handful of rows (whose per-channel maxima scatter widely) is not mistaken for massive channels
         self.site_ref = site_ref
@@ -166,7 +170,7 @@ class HalfPlan:
 
     def describe(self) -> str:
         where = '' if (not self.qk_pair or self.qk_layers is None) else f' in {sum(self.qk_layers)} of {len(self.qk_layers)} layers'
-        return f"ext channels {0 if self.ext_sel is None else self.ext_sel.numel()}, q/k pairs {'on' if self.qk_pair else 'off'}{where}"
+        return f"ext channels {0 if self.ext_sel is None else self.ext_sel.numel()}, q/k pairs {'on' if self.qk_pair else 'off'}{where}" + (', fixed-reference attention' if self.qp else '')
 
 
 def _ext_key(ext_sel: torch.Tensor):
@@ -449,6 +453,8 @@ class FlashMultiheadAttention(nn.Module):
             raise NotImplementedError("precision='half' runs the LayerNorm-folded path on the fp32 / pair stream (ESM-C: with the fused q/k pass)")
         plan = ctx.plan if (f16 and ctx is not None) else None
         qk_pair = bool(plan is not None and plan.pairs_at(self.layer_index))
+        if f16 and plan is not None and plan.qp and not qk_pair:      # precision 'half', fixed-reference attention (esme_hip_forward_half takes the same decision from attn_q_prescale)
+            qp = bool((rot_fusable or qk_pass) and d in (32, 64) and E % 64 == 0 and not ctx.exact_attn)
         guard = ctx.guard if (f16 and ctx is not None) else None
         g_col = guard.col[2 * self.layer_index + 1] if guard is not None else None          # plan guard: column maxima of the stream after this branch
         if qk_pair:

@@ -80,7 +80,7 @@ class ModelDescriptor:
         d.ln_eps, d.alpha = float(att0.norm.eps), 1.0 / float(first.residue_scaling)
         d.softmax_scale = att0.head_dim ** -0.5
         from esme.attention import _ATTN_QP
-        d.attn_q_prescale = int(_ATTN_QP)                     # ONE flag drives both paths (esme.attention reads it the same way)
+        d.attn_q_prescale = int(bool(plan is not None and plan.qp)) if f16 else int(_ATTN_QP)      # ONE flag drives both paths (esme.attention reads it the same way; 'half': the plan's)
         d.layers = arr
         ln = model.emb_layer_norm_after
         d.final_ln_w, d.final_ln_b = _ptr(ln.weight), _ptr(ln.bias)

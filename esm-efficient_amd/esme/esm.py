@@ -177,11 +177,15 @@ class ESM2(nn.Module):
     half_robust = {'0': False, '1': True}.get(os.environ.get('ESME_HALF_ROBUST', 'auto'), 'auto')
     HALF_CHANNEL_RATIO = 6.0       # a channel is "massive" when its largest |value| at some stream site exceeds this multiple of the median channel's largest |value| there
     HALF_SCORE_BOUND = 32.0        # q / k become pairs when max |q_i| max |k_j| / sqrt(d) reaches this (2^-12 relative x that = 1e-2 of a score unit)
+    HALF_QP_BOUND = 16.0           # the fp16 attention kernel runs its fixed-reference form (P = 2^(score log2(e) - 4), no maximum: HalfPlan.qp) when every layer's calibrated
+                                   # bound max |q_i| max |k_j| / sqrt(d) stays below this: a score above the form's 13.9 then needs q and k within 30 degrees of parallel AT
+                                   # their largest norms; a work item that gets there anyway is redone with exact maxima by the kernel (correct either way: speed only)
     # The plan is CHECKED against every batch (round 6): the residual / projection epilogues keep running maxima of exactly the two quantities
     # above (esme.attention.HalfGuard), `check_plan()` compares them with the plan at a synchronisation point -- predict_log_prob / predict_prob
     # do (and re-run the batch once with the widened plan when it was stale), esme.pipeline.StreamedInference does with each result -- and
     # `model(...)` stays asynchronous: call check_plan() yourself.  ESME_HALF_GUARD=0 switches the bookkeeping off.
     half_guard = os.environ.get('ESME_HALF_GUARD', '1') != '0'
+    half_qp = os.environ.get('ESME_HALF_QP', '1') != '0'       # (A/B switch of HalfPlan.qp; read here only)
     half_check = 'sync'            # 'sync': predict_* check overflow + plan inline (one device synchronisation per call); 'defer': they do not -- the
                                    # caller polls check_overflow() / check_plan() (graph replays, latency-sensitive loops)
     HALF_CALIB_VOCAB = 'all'       # calibration tokens: 'all' = every id of the alphabet (specials, X B U Z O . -, <mask>); 'residues' = ids 4..23 + cls / eos (round 5)
@@ -277,7 +281,9 @@ class ESM2(nn.Module):
         ratio = torch.where(med[:, None] > 0, x / med[:, None].clamp_min(1e-30), torch.zeros_like(x)).amax(dim=0)
         qk = guard.qk.view(torch.float32)
         att = self.layers[0].self_attn
-        bound = (qk[:, 0] * qk[:, 1]).sqrt().amax(dim=1) * (att.head_dim ** -0.5)
+        # (HalfPlan.qp with the rotary fused into the projection: the epilogue's guard sees q AFTER softmax_scale * log2(e) went in; ESM-C's q/k pass measures before)
+        prescaled = bool(getattr(getattr(self, '_half_plan', None), 'qp', False)) and not att.pre_layernorm
+        bound = (qk[:, 0] * qk[:, 1]).sqrt().amax(dim=1) * ((1.0 / 1.4426950408889634) if prescaled else att.head_dim ** -0.5)
         return ratio, bound, qk.amax(dim=(1, 2)) > 0
 
     def _calibrate_half(self, device):
@@ -329,7 +335,12 @@ class ESM2(nn.Module):
                 'max_channel_ratio': float(ratio.max()), 'max_unselected_channel_ratio': float(others.max()), 'score_bound': bound,
                 'massive_channels': n_mass, 'qk_pair_supported': bool(pair_ok), 'qk_pair_layers': (L if flags is None else sum(flags)) if qk_pair else 0,
                 'score_guard_layers': int(covered.sum()), 'score_bounds': [round(b, 2) for b in bounds]}
-        return HalfPlan(sel, qk_pair, info, qk_layers=flags, site_ref=self._last_site_median.clone())
+        # the fixed-reference form of the fp16 attention kernel (round 6): where the kernels have it and every layer that would use it stays below HALF_QP_BOUND
+        qp_ok = (att.rot_emb is not None and att.head_pad in (32, 64) and att.attn_dim % 64 == 0 and not att.padded and len(bounds) == L)
+        plain = [b for i, b in enumerate(bounds) if not (qk_pair and (flags is None or flags[i]))]
+        qp = bool(self.half_qp and qp_ok and plain and max(plain) < self.HALF_QP_BOUND)
+        info['fixed_reference_attention'] = qp
+        return HalfPlan(sel, qk_pair, info, qk_layers=flags, site_ref=self._last_site_median.clone(), qp=qp)
 
     # -- the plan checked against the data (round 6) -----------------------------------------------------------------------
     def _guard_buffers(self, device):
@@ -412,7 +423,7 @@ class ESM2(nn.Module):
             info['updates'] = info.get('updates', 0) + 1
             info['massive_channels'] = int(cand.numel())
             info['qk_pair_layers'] = sum(new_flags) if pair_ok else 0
-            self._half_plan = HalfPlan(sel, pair_ok and any(new_flags), info, qk_layers=new_flags if pair_ok else None, site_ref=plan.site_ref)
+            self._half_plan = HalfPlan(sel, pair_ok and any(new_flags), info, qk_layers=new_flags if pair_ok else None, site_ref=plan.site_ref, qp=plan.qp)
             self.invalidate_graphs()
             verdict['updated'] = True
             msg += " The plan was widened (" + self._half_plan.describe() + "): re-run the batch."

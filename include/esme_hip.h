@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESME_HIP_ABI_VERSION 9
+#define ESME_HIP_ABI_VERSION 10
 
 enum {
     ESME_OK = 0,
@@ -168,6 +168,12 @@ int esme_hip_qk_norm_rotary_f16_guarded(void* q, void* k, int64_t ld, const void
                                         const void* bq, const void* bk, float eps, const void* cos,
                                         const void* sin, const int32_t* pos, int64_t T, int H, int d,
                                         int max_len, uint32_t* qk_sumsq, void* stream);
+/* The same with q (not k) multiplied by q_scale in fp32 before its one fp16 rounding (ABI 10): softmax_scale * log2(e) folded into q for the fixed-reference
+ * form of the fp16 attention kernel (esme_attn_opts_t.q_prescaled with f16).  qk_sumsq, if given, holds the norms BEFORE the scale (what the plan thresholds). */
+int esme_hip_qk_norm_rotary_f16_scaled(void* q, void* k, int64_t ld, const void* wq, const void* wk,
+                                       const void* bq, const void* bk, float eps, const void* cos,
+                                       const void* sin, const int32_t* pos, int64_t T, int H, int d,
+                                       int max_len, float q_scale, uint32_t* qk_sumsq, void* stream);
 
 /* Varlen (block-diagonal) multi-head self-attention, non-causal, no dropout:
  * per sequence i and head h, O = softmax(Q K^T * softmax_scale) V over that sequence's
@@ -205,8 +211,11 @@ typedef struct esme_attn_opts {
     const int32_t* seq_order;
     int q_prescaled;
     int f16;                     /* != 0: q, k, v and o are IEEE fp16 (precision 'half').  P is fp16 as well: the speculative pass keeps its first-tile
-                                  * reference maximum and redoes a work item with exact maxima when a P would leave fp16's range; does not
-                                  * combine with q_prescaled (no reference at all) */
+                                  * reference maximum and redoes a work item with exact maxima when a P would leave fp16's range.  With q_prescaled
+                                  * (ABI 10; head dims 64 / 32, the ping-pong kernel): the no-reference form with a FIXED reference of 4 (log2 units) --
+                                  * the score accumulators start at -4.0, P = 2^(score - 4) stays inside fp16 for scores up to 20 (13.9 natural units);
+                                  * a work item with a higher score, or with a row whose sum falls below 2^-8 (P in fp16's subnormals), is redone
+                                  * with exact maxima: always correct, fast where a model's scores stay inside that window */
 } esme_attn_opts_t;
 int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv,
                                   void* o, int64_t ld_o, const int32_t* cu_lens, int B, int64_t T,
@@ -595,7 +604,10 @@ int esme_hip_forward(const esme_model_desc_t* model, void* x, int64_t ldx, const
 /* The layer stack in precision 'half' (see esme_gemm_fusion_t.f16) through ONE call: IEEE fp16 MFMA operands, the residual stream as an
  * fp16 pair updated in place by the residual GEMMs.  The descriptor is the same struct with the fp16 DERIVED copies: qkv_w / up_w =
  * fp16(W diag(gamma)) with c1 = ITS row sums, out_w / down_w = the bf16 weights converted to fp16 (exact), cos / sin fp16 tables; biases and
- * LayerNorm parameters stay bf16; attn_q_prescale is ignored (P must fit fp16).  With esme_layer_weights_t.ps_* set, qkv_w / up_w =
+ * LayerNorm parameters stay bf16; attn_q_prescale != 0 (ABI 10): the layers WITHOUT q / k pairs fold softmax_scale * log2(e) into q (QKV epilogue /
+ * ESM-C q/k pass) and run attention in the fixed-reference form (esme_attn_opts_t.q_prescaled with f16; head_pad 64 / 32) -- the caller's plan decides
+ * (esme.attention.HalfPlan.qp: only where the calibrated score bound leaves that window room), and half_qk_sumsq then holds the SCALED q's norms
+ * for blocks whose rotary is fused into the projection.  With esme_layer_weights_t.ps_* set, qkv_w / up_w =
  * fp16(W diag(pow2(gamma))) (exact) and the stream travels scaled by rho = gamma / pow2(gamma) of its next LayerNorm (the form the Python
  * package builds: it removes the fp16 rounding of W * gamma, a quarter of the mode's error).
  *  x32:   fp32 (T, phys_dim), row stride ld32: the stream at the start (embedding rows; ESM-1b / 1v: token + learned-position sums);
