@@ -26,6 +26,9 @@
 // than 2^8), so the common tile does no O-wide VALU pass.
 #include "common.h"
 #include "launch.h"
+#ifndef ESME_ATTN_CM4_ASM
+#define ESME_ATTN_CM4_ASM 0
+#endif
 #include "gemm.h"
 
 #ifndef ESME_ATTN_ABL           // lab builds only (timing ablations of attn_pp64_kernel, WRONG results; profiles/r05_attn_rowsum_ablation.txt):
@@ -678,8 +681,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 // F16 (precision 'half'): q, k, v, P and o are IEEE fp16 (11 significant bits).  fp16 ends at 65 504, so there is no QP form (P = exp2(score) with
 // no reference at all); the speculative pass against the FIRST tile's maximum stays (P = 2^(how far a later score beats that maximum): a
 // handful on real data) with the overflow test tightened to fp16's range -- a work item that trips it is redone with exact maxima (P <= 1).
-// QP && F16 (round 6): the no-reference form with a FIXED reference of 4 (log2 units) -- the score accumulators start at -4.0 (an inline constant of the MFMA's C
-// operand: no instruction, no register), so P = 2^(s - 4) stays inside fp16 for scores up to 20 (13.9 in natural units: e^13.9 = 10^6 times the weight of a zero
+// QP && F16 (round 6): the no-reference form with a FIXED reference of 4 (log2 units) -- the score accumulators start at -4.0 (the C operand of each score block's
+// first MFMA: sixteen registers kept for the purpose; as an inline constant of the instruction only behind ESME_ATTN_CM4_ASM, see common.h), so P = 2^(s - 4) stays inside fp16 for scores up to 20 (13.9 in natural units: e^13.9 = 10^6 times the weight of a zero
 // score).  A row whose scores go higher trips the overflow test (partial sum >= 3e4), a row whose sum falls below 2^-8 (every score below about -2.8: its P values would
 // sit in fp16's subnormals) trips the vanished-sum test: both redo the work item with exact maxima, exactly as the bf16 form does at 1e30 / 1e-30.
 template <int NW, bool QP = false, int D = 64, bool F16 = false>
@@ -829,6 +832,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         return *reinterpret_cast<const bf16x8*>(Ks + ((m - NPV) & 1) * (32 * ROWB) + kfo[(m - NPV) >> 1]);
     };
 
+    // QP && F16: sixteen registers of -4.0, made opaque so that they are kept (hipcc would otherwise rebuild the splat with 16 v_mov in front of every use)
+    f32x16 zneg = {S0, S0, S0, S0, S0, S0, S0, S0, S0, S0, S0, S0, S0, S0, S0, S0};
+    if constexpr (QP && F16) asm volatile("" : "+v"(zneg));
     // One phase: softmax of block BS on its finished scores, interleaved with the 16 MFMAs of block BM.
     // SPEC: speculative softmax (no tile maximum; see the header).  TAIL: mask the keys past the sequence end.
     auto phase = [&](auto BS_, auto BM_, const bool need_max, const bool tail, const char* Ks, const char* Vs, const int kv0, auto&& hook) __attribute__((always_inline)) {
@@ -842,7 +848,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
                 const int j = m - NPV, kbk = j & 1, ds = j >> 1;
                 if (ds == 0) {
                     if constexpr (QP && F16) {
+#if ESME_ATTN_CM4_ASM
                         sacc[bm][kbk] = mfma_32x32x16_f16_cm4(fr[m % 3], qf[bm][ds]);     // starts at S0 = -4 (inline constant)
+#else
+                        sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], zneg);   // starts at S0 = -4 (a register block kept for the purpose)
+#endif
                     } else {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                         sacc[bm][kbk] = mfma_32x32x16<F16>(fr[m % 3], qf[bm][ds], z);

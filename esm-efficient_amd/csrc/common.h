@@ -91,10 +91,11 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// D = A x B - 4.0 (fp16 operands): the accumulator's start value as an INLINE CONSTANT of the C operand -- hipcc folds a zero splat into the instruction but
-// materialises any other splat in 16 registers per use (16 v_mov in front of every such MFMA), so the instruction is spelled out.  Inline asm hides the MFMA from
-// the hazard recogniser: the result must not be read by anything (another MFMA's C operand included) before an independent MFMA has been issued behind it -- the
-// ping-pong attention kernel alternates its two accumulators, its only user.
+// D = A x B - 4.0 (fp16 operands) with the accumulator's start value as an INLINE CONSTANT of the C operand.  hipcc folds a zero splat into the instruction but
+// materialises any other splat in registers, so the instruction is spelled out -- LAB ONLY (ESME_ATTN_CM4_ASM in attn.hip; 2 % faster than the shipped register
+// block of -4.0): inline asm hides the MFMA from the hazard recogniser, and nothing stops the register allocator from spilling the result straight after the
+// statement -- a memory read of MFMA results without the ~18 wait states they need.  The shipped schedule does not do that; the LDS-bounds debug build
+// (224 spills in this kernel) did, and returned wrong attention outputs (tools/debug_lds_check.sh, round 6).
 __device__ __forceinline__ f32x16 mfma_32x32x16_f16_cm4(const bf16x8 a, const bf16x8 b) {
     f32x16 d;
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, -4.0" : "=&v"(d) : "v"(a), "v"(b));
