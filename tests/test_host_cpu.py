@@ -163,6 +163,18 @@ def test_round6_entry_points_validate_without_gpu():
     # guarded q/k pass: alignment of the maxima
     assert lib.esme_hip_qk_norm_rotary_f16_guarded(16, 16, 128, 16, 16, None, None, 1e-5, 16, 16, 16, 4, 2, 64, 8, 18, None) == -1
     assert b'qk_sumsq' in lib.esme_hip_last_error()
+    # the same with the softmax scale folded into q (ABI 10: the fixed-reference form of the fp16 attention kernel): the scale must be a positive number
+    assert lib.esme_hip_qk_norm_rotary_f16_scaled(16, 16, 128, 16, 16, None, None, 1e-5, 16, 16, 16, 4, 2, 64, 8, 0.18, 18, None) == -1
+    assert b'qk_sumsq' in lib.esme_hip_last_error()
+    for bad in (0.0, -1.0, float('nan')):
+        assert lib.esme_hip_qk_norm_rotary_f16_scaled(16, 16, 128, 16, 16, None, None, 1e-5, 16, 16, 16, 4, 2, 64, 8, bad, None, None) == -1
+        assert b'q_scale' in lib.esme_hip_last_error()
+    assert lib.esme_hip_qk_norm_rotary_f16_scaled(16, 16, 128, 16, 16, None, None, 1e-5, 16, 16, 16, 0, 2, 64, 8, 0.18, None, None) == 0       # T = 0: nothing to do
+    # fp16 attention with q_prescaled: the fixed-reference form exists for head dims 64 / 32 only
+    cu_dummy = 16
+    ao = _hip.AttnOpts(ctypes.sizeof(_hip.AttnOpts), 0, 0, 8.0, 1, None, 1, 1)
+    assert lib.esme_hip_attn_varlen_fwd_opts(16, 16, 16, 128, 16, 128, cu_dummy, 1, 32, 1, 128, 32, 0.125, ctypes.byref(ao), None) == -1
+    assert b'q_prescaled' in lib.esme_hip_last_error()
 
 
 def test_calibration_batch_covers_the_vocabulary_and_plan_keys():
