@@ -683,8 +683,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(const AttnSplitArgs 
 // handful on real data) with the overflow test tightened to fp16's range -- a work item that trips it is redone with exact maxima (P <= 1).
 // QP && F16 (round 6): the no-reference form with a FIXED reference of 4 (log2 units) -- the score accumulators start at -4.0 (the C operand of each score block's
 // first MFMA: sixteen registers kept for the purpose; as an inline constant of the instruction only behind ESME_ATTN_CM4_ASM, see common.h), so P = 2^(s - 4) stays inside fp16 for scores up to 20 (13.9 in natural units: e^13.9 = 10^6 times the weight of a zero
-// score).  A row whose scores go higher trips the overflow test (partial sum >= 3e4), a row whose sum falls below 2^-8 (every score below about -2.8: its P values would
-// sit in fp16's subnormals) trips the vanished-sum test: both redo the work item with exact maxima, exactly as the bf16 form does at 1e30 / 1e-30.
+// score).  A row whose scores go higher trips the overflow test (partial sum >= 3e4), a row whose sum falls below S * 2^-14 (its P values average below fp16's smallest normal
+// number) trips the vanished-sum test: both redo the work item with exact maxima, exactly as the bf16 form does at 1e30 / 1e-30.
 template <int NW, bool QP = false, int D = 64, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a) {
     constexpr float S0 = (QP && F16) ? -4.0f : 0.0f;            // where the score accumulators start
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
         // it by P = 0: no NaN / Inf patterns)
     #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-            mc[bb] = -1e30f; lrun[bb] = (QP && !wave_active) ? 1.f : 0.f;      // (QP: an idle wave must not trip the vanished-sum check)
+            mc[bb] = -1e30f; lrun[bb] = (QP && !wave_active) ? 1e30f : 0.f;    // (QP: an idle wave must not trip the vanished-sum check)
     #pragma unroll
             for (int i = 0; i < 2; ++i) {
     #pragma unroll
@@ -1096,10 +1096,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp64_kernel(const AttnArgs a)
             // (The ROW's sum, i.e. both key halves: lane and lane ^ 32 combined -- a lane whose half of the keys is entirely masked, as in
             // sequences of <= 8 residues, holds 0 by itself and used to send such sequences through the loop twice.)
             if (!exact) {
+                // F16: a row sum below S * 2^-14 means the row's P values average below fp16's smallest NORMAL number -- the terms that carry the row's weight
+                // would sit in the subnormals (fewer than 11 bits; the row sum itself is taken from the unrounded values, so the loss does not cancel).  Above it the
+                // subnormal terms together are worth at most 2^-11 of the row (S terms x 2^-25 absolute against a sum >= S * 2^-14): one fp16 rounding.
+                const float vanish = F16 ? (float)S * 6.103515625e-5f : 1e-30f;
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[bb]), __float_as_uint(lrun[bb]), false, false);
-                    if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > (F16 ? 0.00390625f : 1e-30f)))) ovf = 1;      // (idle waves carry lrun = 1)
+                    if (__any(!(__uint_as_float(sw[0]) + __uint_as_float(sw[1]) > vanish))) ovf = 1;      // (idle waves carry lrun = 1e30)
                 }
             }
         }

@@ -214,7 +214,7 @@ typedef struct esme_attn_opts {
                                   * reference maximum and redoes a work item with exact maxima when a P would leave fp16's range.  With q_prescaled
                                   * (ABI 10; head dims 64 / 32, the ping-pong kernel): the no-reference form with a FIXED reference of 4 (log2 units) --
                                   * the score accumulators start at -4.0, P = 2^(score - 4) stays inside fp16 for scores up to 20 (13.9 natural units);
-                                  * a work item with a higher score, or with a row whose sum falls below 2^-8 (P in fp16's subnormals), is redone
+                                  * a work item with a higher score, or with a row whose sum falls below S * 2^-14 (its P values average below fp16's smallest normal), is redone
                                   * with exact maxima: always correct, fast where a model's scores stay inside that window */
 } esme_attn_opts_t;
 int esme_hip_attn_varlen_fwd_opts(const void* q, const void* k, const void* v, int64_t ld_qkv,

@@ -1,7 +1,7 @@
 """The fixed-reference form of the fp16 attention kernel (round 6; esme_attn_opts_t.q_prescaled with f16, HalfPlan.qp): q arrives multiplied by
 softmax_scale * log2(e), the score accumulators start at -4.0 (the C operand of each score block's first MFMA) and P = 2^(score - 4) is taken
 with NO maximum and NO subtraction.  fp16 holds P for scores up to 20 (13.9 natural units); a work item with a higher score (partial row sum
->= 3e4) or with a row whose sum falls below 2^-8 (its P would sit in fp16's subnormals) is redone with exact maxima.  Checked here:
+>= 3e4) or with a row whose sum falls below S * 2^-14 (its P values average below fp16's smallest normal number) is redone with exact maxima.  Checked here:
   * against float64 on the SAME fp16 inputs (the scaled q as given): ragged batches, head dims 64 and 32, benign scores -- rel-Frobenius
     <= 6e-4 (the bound of tests/test_half_gpu.py::test_attention_f16);
   * scores far above the window (overflow -> redo) and far below it (vanished sums -> redo): finite and within 1e-3;
