@@ -208,6 +208,17 @@ def test_calibration_batch_covers_the_vocabulary_and_plan_keys():
     pa, pb = HalfPlan(a), HalfPlan(b)
     assert pa.ext_key == (3, 9) and _ext_key(a) == (3, 9) and _ext_key(b) == (3, 10) and pa.ext == 64 and HalfPlan().ext == 0
     assert _ext_key(torch.tensor([1, 2], dtype=torch.int32)) == (1, 2)
+    # the fixed-reference attention form is a plan attribute (off unless a calibration switched it on), survives in describe(), and the switches exist
+    assert not HalfPlan().qp and HalfPlan(qp=True).qp and 'fixed-reference' in HalfPlan(qp=True).describe() and 'fixed-reference' not in pa.describe()
+    assert ESM2.HALF_QP_BOUND < ESM2.HALF_SCORE_BOUND and isinstance(ESM2.half_qp, bool)
+    m = ESM2(num_layers=2, embed_dim=64, attention_heads=4)
+    m._half_plan = HalfPlan(qp=True, info={'calibrated': True}, qk_layers=[False, False])
+    m.precision = 'half'
+    vec = torch.zeros(1 + 64 + 2 + 2)
+    vec[0], vec[1 + 3], vec[1 + 64 + 2:] = 1.0, 50.0, 1.0            # a stale verdict: channel 3 at 50 x the median
+    with pytest.warns(RuntimeWarning):
+        v = m._plan_verdict(vec, update=True)
+    assert v['updated'] and m._half_plan.qp and m._half_plan.ext_key == (3,)         # widening the plan keeps the attention form
 
 
 def test_no_cpu_fallback_and_missing_library(monkeypatch):
