@@ -273,6 +273,7 @@ def half_leg(model, tokens, cu, max_len, steps, T, E, kind, lengths, flops_step,
         guard = {'verdict': 'guard off'}
     res = {'what': "model.set_precision('half'): IEEE fp16 MFMA operands (the bf16 checkpoint converts exactly; LayerNorm gains folded as "
                    "powers of two, the rest rides on the stream), residual stream as an fp16 pair, split-operand LM head, fp32 logits; "
+                   "attention in the fixed-reference form where the calibrated plan allows it (plan.fixed_reference_attention); "
                    "same batch, after the timed region",
            'dtype': 'f16', 'steps': steps, 'ms_per_step': round(h_ms, 3),
            'step_ms_events': {'median': round(ems[len(ems) // 2], 3), 'min': round(ems[0], 3), 'max': round(ems[-1], 3)},
